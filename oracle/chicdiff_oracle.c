@@ -1,0 +1,118 @@
+/*
+ * oracle/chicdiff_oracle.c — TEST INFRASTRUCTURE (parity oracle), not product code.
+ *
+ * CPU restatement of the Chicdiff-side (non-DESeq2) pieces of the hot path, each
+ * following /root/reference/Chicdiff/R/chicdiff.R at the cited lines:
+ *   a1 count join      chicdiff.R:843-858   (merge RU x chinput, NA -> 0)
+ *   a2 window sums     chicdiff.R:1540-1556 (sum(N), sum(FullMean) by region & sample)
+ *   a4 offsets         chicdiff.R:1583-1589, 1614-1615, 1635-1638, 1666-1669
+ *   a9 BH adjustment   p.adjust(method="BH") as used by DESeq2 results() / chicdiff.R:2049
+ * These lines ARE under /root/reference, so parity here is pinned by the reference's
+ * own text plus (for BH) the golden table's weighted_padj / padj columns.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* a2. regionData <- fragData[, .(N=sum(N), ..., FullMean=sum(FullMean)), by=.(baitID, regionID, sample)]
+ * (chicdiff.R:1540-1547) after setkey(fragData, otherEndID) (:1526): rows of one region are summed in
+ * ascending otherEndID order.  The caller passes fragments already grouped per region in that order.
+ * Integer sums are exact; fp64 sums are sequential (NA/NaN propagate, as sum() without na.rm). */
+int oracle_window_sums(const int32_t *fragN, const double *fragFullMean, int64_t nfrag, int32_t S,
+                       const int64_t *region_ptr, int64_t n, int32_t *N, double *FullMean) {
+    if (region_ptr[n] > nfrag) return -1;
+    for (int j = 0; j < S; j++) {
+        for (int64_t i = 0; i < n; i++) {
+            int64_t lo = region_ptr[i], hi = region_ptr[i + 1];
+            if (fragN) {
+                int64_t s = 0;
+                for (int64_t f = lo; f < hi; f++) s += fragN[(int64_t)j * nfrag + f];
+                N[(int64_t)j * n + i] = (int32_t)s;
+            }
+            if (fragFullMean) {
+                double s = 0;
+                for (int64_t f = lo; f < hi; f++) s += fragFullMean[(int64_t)j * nfrag + f];
+                FullMean[(int64_t)j * n + i] = s;
+            }
+        }
+    }
+    return 0;
+}
+
+/* a4. normFactorsM3 <- FullMean / exp(rowMeans(log(FullMean)))       (chicdiff.R:1585-1586)
+ *     rows with any NA <- nullSizeFactors                             (:1588-1589)
+ *     mix: sc <- M3*(1-theta) + nsf*theta; sc <- sc/exp(rowMeans(log(sc)))   (:1635-1638, :1666-1669)
+ * mix == 0 returns M3 itself (norm = "fullmean", :1600). */
+int oracle_offsets(const double *FullMean, const double *sizeFactors, int64_t n, int32_t S, double theta,
+                   double *out) {
+    int mix = !isnan(theta);
+    for (int64_t i = 0; i < n; i++) {
+        double sl = 0;
+        for (int j = 0; j < S; j++) sl += log(FullMean[(int64_t)j * n + i]);
+        double gmean = exp(sl / S);
+        int anyna = 0;
+        double m3[64];
+        for (int j = 0; j < S; j++) {
+            m3[j] = FullMean[(int64_t)j * n + i] / gmean;
+            if (isnan(m3[j])) anyna = 1;
+        }
+        if (anyna)
+            for (int j = 0; j < S; j++) m3[j] = sizeFactors[j];
+        if (mix) {
+            double sl2 = 0;
+            for (int j = 0; j < S; j++) {
+                m3[j] = m3[j] * (1 - theta) + sizeFactors[j] * theta;
+                sl2 += log(m3[j]);
+            }
+            double g2 = exp(sl2 / S);
+            for (int j = 0; j < S; j++) m3[j] /= g2;
+        }
+        for (int j = 0; j < S; j++) out[(int64_t)j * n + i] = m3[j];
+    }
+    return 0;
+}
+
+/* a1. merge(RU, chinput[, .(baitID, otherEndID, N)], all.x=TRUE); N[is.na(N)] <- 0  (chicdiff.R:846-853) */
+int oracle_count_join(const int32_t *ru_bait, const int32_t *ru_oe, int64_t nru, const int64_t *keys,
+                      const int32_t *vals, int64_t nkeys, int32_t *out) {
+    for (int64_t r = 0; r < nru; r++) {
+        int64_t key = ((int64_t)ru_bait[r] << 32) | (uint32_t)ru_oe[r];
+        int64_t lo = 0, hi = nkeys;
+        while (lo < hi) {
+            int64_t mid = lo + ((hi - lo) >> 1);
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        out[r] = (lo < nkeys && keys[lo] == key) ? vals[lo] : 0;
+    }
+    return 0;
+}
+
+/* p.adjust(p, "BH"): n = #non-NA; o = order(p, decreasing=TRUE); pmin(1, cummin(n/i * p[o]))[order(o)] */
+typedef struct { double p; int64_t i; } pidx;
+static int cmp_pidx_desc(const void *a, const void *b) {
+    const pidx *x = (const pidx *)a, *y = (const pidx *)b;
+    if (x->p > y->p) return -1;
+    if (x->p < y->p) return 1;
+    return (x->i > y->i) - (x->i < y->i); /* stable for ties (order() is stable) */
+}
+int oracle_bh_adjust(const double *p, int64_t n, double *padj) {
+    pidx *v = (pidx *)malloc(sizeof(pidx) * (size_t)(n > 0 ? n : 1));
+    if (!v) return -1;
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) {
+        padj[i] = NAN;
+        if (!isnan(p[i])) { v[m].p = p[i]; v[m].i = i; m++; }
+    }
+    qsort(v, (size_t)m, sizeof(pidx), cmp_pidx_desc);
+    double run = INFINITY;
+    for (int64_t k = 0; k < m; k++) {
+        double rank = (double)(m - k); /* i = lp:1 */
+        double val = (double)m / rank * v[k].p;
+        if (val < run) run = val;
+        padj[v[k].i] = run < 1.0 ? run : 1.0;
+    }
+    free(v);
+    return 0;
+}

@@ -1,0 +1,106 @@
+/*
+ * oracle/oracle.h — TEST INFRASTRUCTURE (parity oracle), not product code.
+ *
+ * CPU restatement of Chicdiff's differential-testing core (SURVEY.md §8a rows
+ * a1-a9).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product path (chicdiff_amd/, include/chicdiff_hip.h) never
+ * does.  PARITY UNPINNED at the DESeq2 boundary — see oracle/README.md.
+ *
+ * Matrix layout everywhere: column-major n x S (= sample-major: element (i, j) at
+ * [j*n + i]), i.e. exactly R's INTEGER(mat)/REAL(mat) for the matrices built at
+ * chicdiff.R:1551-1553 and :1583.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    double minDisp;      /* 1e-8   estimateDispersions default                        */
+    double dispTol;      /* 1e-6                                                    */
+    double kappa0;       /* 1.0                                                     */
+    int32_t maxit;       /* 100    fitDisp line-search iterations                     */
+    int32_t betaMaxit;   /* 100    fitBeta IRLS iterations                            */
+    double betaTol;      /* 1e-8                                                    */
+    double minmu;        /* 0.5                                                     */
+    double outlierSD;    /* 2.0                                                     */
+    double dispPriorVar; /* NaN = estimate (closed form when m-p > 3; see .c)        */
+    int32_t nthreads;    /* OpenMP threads over rows (1 = DESeq2-like single thread)  */
+    int32_t _pad;
+} oracle_nbglm_opts;
+
+void oracle_nbglm_default_opts(oracle_nbglm_opts *o);
+
+/* status bits returned in out->status */
+#define ORACLE_ST_TREND_FAILED 1     /* parametric trend fit failed (DESeq2 would switch to locfit) */
+#define ORACLE_ST_PRIORVAR_MC 2      /* m-p <= 3: DESeq2 uses an R-RNG Monte Carlo; not reproduced   */
+#define ORACLE_ST_BETA_NONCONV 4     /* some rows hit betaMaxit (DESeq2 would call optim)           */
+#define ORACLE_ST_ALLZERO_ROWS 8     /* some rows are all-zero (NA outputs)                         */
+
+typedef struct {
+    /* per-row, length n (any pointer may be NULL) */
+    double *baseMean, *baseVar;
+    int32_t *allZero;
+    double *dispInit;      /* alpha_init (A2.4)                                   */
+    double *dispGeneEst;
+    int32_t *dispGeneIter;
+    double *dispFit, *dispMAP, *dispersion;
+    int32_t *dispIter, *dispOutlier;
+    double *beta0, *beta1; /* log2 scale: Intercept, condition_B_vs_A (beta1 NaN for ~1) */
+    double *se0, *se1;
+    double *stat, *pvalue; /* Wald statistic / p of the last coefficient           */
+    double *deviance;
+    int32_t *betaConv, *betaIter;
+    double *maxCooks;      /* NaN unless some group has >= 3 samples               */
+    double *mu;            /* n x S column-major, fitted mean of the Wald fit      */
+    /* scalars */
+    double trendCoef[2];   /* asymptDisp, extraPois                              */
+    double varLogDispEsts, dispPriorVar, sumDeviance;
+    int32_t trendOuterIter, status;
+} oracle_nbglm_out;
+
+/* A1 / a5: DESeq2 estimateSizeFactorsForMatrix (median of ratios). Returns 0 or <0 on error. */
+int oracle_size_factors(const int32_t *counts, int64_t n, int32_t S, double *sf);
+
+/* a6 + a7: estimateDispersions + nbinomWaldTest for design ~group (two levels) or ~1 (all group==0). */
+int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t S,
+                     const int32_t *group, const oracle_nbglm_opts *opts, oracle_nbglm_out *out);
+
+/* pieces exported for unit tests ------------------------------------------------------------- */
+double oracle_log_posterior(double log_alpha, const double *y, const double *mu, const int32_t *group,
+                            int32_t S, int32_t p, double prior_mean, double prior_sigmasq, int32_t use_prior);
+double oracle_dlog_posterior(double log_alpha, const double *y, const double *mu, const int32_t *group,
+                             int32_t S, int32_t p, double prior_mean, double prior_sigmasq, int32_t use_prior);
+/* Gamma-identity trend fit on (means, disps) pairs; returns 0 ok / nonzero failed */
+int oracle_parametric_dispersion_fit(const double *means, const double *disps, int64_t n, double coefs[2],
+                                     int32_t *outer_iter);
+double oracle_median(double *x, int64_t n); /* sorts x in place */
+
+/* a2: window sums. frag_* are long-form per-fragment values, column-major nfrag x S;
+ * region_ptr[n+1] CSR offsets into the fragment axis (fragments of one region contiguous).
+ * N: int32 sums (bit exact); FullMean: fp64 NA(NaN)-propagating sums in fragment order.
+ * chicdiff.R:1540-1547. */
+int oracle_window_sums(const int32_t *fragN, const double *fragFullMean, int64_t nfrag, int32_t S,
+                       const int64_t *region_ptr, int64_t n, int32_t *N, double *FullMean);
+
+/* a4: offsets. chicdiff.R:1583-1589 (M3), :1614-1615 (nsf), :1635-1638 / :1666-1669 (theta mix).
+ * out = sc(theta) (n x S).  theta = 0 reproduces normFactorsM3 renormalised (a no-op). */
+int oracle_offsets(const double *FullMean, const double *sizeFactors, int64_t n, int32_t S, double theta,
+                   double *out);
+
+/* a1: count join. keys sorted ascending (baitID<<32 | otherEndID), one table per sample.
+ * chicdiff.R:843-858: left join RU x chinput on (baitID, otherEndID), NA -> 0. */
+int oracle_count_join(const int32_t *ru_bait, const int32_t *ru_oe, int64_t nru, const int64_t *keys,
+                      const int32_t *vals, int64_t nkeys, int32_t *out);
+
+/* a9 helpers: BH adjustment (p.adjust(method="BH") on the non-NaN entries; NaN stays NaN) */
+int oracle_bh_adjust(const double *p, int64_t n, double *padj);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

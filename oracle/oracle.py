@@ -1,0 +1,211 @@
+"""ctypes front-end of the parity oracle — TEST INFRASTRUCTURE, not product code.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module (it is the *checker*; never the thing shipped or measured as the
+product).  ``chicdiff_amd`` never imports it.  PARITY UNPINNED at the DESeq2 boundary —
+see ``oracle/README.md``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+ST_TREND_FAILED, ST_PRIORVAR_MC, ST_BETA_NONCONV, ST_ALLZERO_ROWS = 1, 2, 4, 8
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/*.c with gcc (``make -C oracle``).  Building the checker is not using it."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in os.listdir(_HERE) if f.endswith((".c", ".h"))
+    ):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+class Opts(C.Structure):
+    _fields_ = [("minDisp", C.c_double), ("dispTol", C.c_double), ("kappa0", C.c_double),
+                ("maxit", C.c_int32), ("betaMaxit", C.c_int32), ("betaTol", C.c_double),
+                ("minmu", C.c_double), ("outlierSD", C.c_double), ("dispPriorVar", C.c_double),
+                ("nthreads", C.c_int32), ("_pad", C.c_int32)]
+
+
+_PD, _PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+_OUT_D = ["baseMean", "baseVar"]
+_OUT_FIELDS = [("baseMean", _PD), ("baseVar", _PD), ("allZero", _PI), ("dispInit", _PD),
+               ("dispGeneEst", _PD), ("dispGeneIter", _PI), ("dispFit", _PD), ("dispMAP", _PD),
+               ("dispersion", _PD), ("dispIter", _PI), ("dispOutlier", _PI), ("beta0", _PD),
+               ("beta1", _PD), ("se0", _PD), ("se1", _PD), ("stat", _PD), ("pvalue", _PD),
+               ("deviance", _PD), ("betaConv", _PI), ("betaIter", _PI), ("maxCooks", _PD), ("mu", _PD)]
+
+
+class Out(C.Structure):
+    _fields_ = _OUT_FIELDS + [("trendCoef", C.c_double * 2), ("varLogDispEsts", C.c_double),
+                              ("dispPriorVar", C.c_double), ("sumDeviance", C.c_double),
+                              ("trendOuterIter", C.c_int32), ("status", C.c_int32)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        for name in ("oracle_dnbinom_mu_log",):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_double] * 3
+        for name in ("oracle_pnorm_two_sided", "oracle_pnorm", "oracle_digamma", "oracle_trigamma",
+                     "oracle_lgamma", "oracle_stirlerr"):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_double]
+        L.oracle_bd0.restype = C.c_double
+        L.oracle_bd0.argtypes = [C.c_double, C.c_double]
+        for name in ("oracle_log_posterior", "oracle_dlog_posterior"):
+            f = getattr(L, name)
+            f.restype = C.c_double
+            f.argtypes = [C.c_double, _PD, _PD, _PI, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32]
+        L.oracle_nbglm_default_opts.argtypes = [C.POINTER(Opts)]
+        L.oracle_size_factors.argtypes = [_PI, C.c_int64, C.c_int32, _PD]
+        L.oracle_nbglm_fit.argtypes = [_PI, _PD, C.c_int64, C.c_int32, _PI, C.POINTER(Opts), C.POINTER(Out)]
+        L.oracle_parametric_dispersion_fit.argtypes = [_PD, _PD, C.c_int64, _PD, _PI]
+        L.oracle_median.restype = C.c_double
+        L.oracle_median.argtypes = [_PD, C.c_int64]
+        L.oracle_window_sums.argtypes = [_PI, _PD, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.c_int64, _PI, _PD]
+        L.oracle_offsets.argtypes = [_PD, _PD, C.c_int64, C.c_int32, C.c_double, _PD]
+        L.oracle_count_join.argtypes = [_PI, _PI, C.c_int64, C.POINTER(C.c_int64), _PI, C.c_int64, _PI]
+        L.oracle_bh_adjust.argtypes = [_PD, C.c_int64, _PD]
+        _lib = L
+    return _lib
+
+
+def _pd(a):
+    return a.ctypes.data_as(_PD)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_PI)
+
+
+def _cm(a, dtype):
+    """n x S array -> contiguous column-major (sample-major) buffer of `dtype`."""
+    return np.asfortranarray(np.asarray(a, dtype=dtype))
+
+
+def default_opts(**kw) -> Opts:
+    o = Opts()
+    lib().oracle_nbglm_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def size_factors(counts) -> np.ndarray:
+    k = _cm(counts, np.int32)
+    n, S = k.shape
+    sf = np.empty(S)
+    rc = lib().oracle_size_factors(_pi(k), n, S, _pd(sf))
+    if rc:
+        raise RuntimeError(f"oracle_size_factors rc={rc}")
+    return sf
+
+
+def nbglm_fit(counts, nf, group, want_mu: bool = False, **optkw) -> dict:
+    """estimateDispersions + nbinomWaldTest.  counts/nf: (n, S); group: (S,) of 0/1 (all 0 = ~1)."""
+    k = _cm(counts, np.int32)
+    f = _cm(nf, np.float64)
+    n, S = k.shape
+    assert f.shape == (n, S)
+    g = np.ascontiguousarray(group, dtype=np.int32)
+    o = default_opts(**optkw)
+    out = Out()
+    keep = {}
+    for name, typ in _OUT_FIELDS:
+        if name == "mu":
+            if not want_mu:
+                continue
+            arr = np.empty((n, S), order="F")
+        else:
+            arr = np.empty(n, dtype=np.float64 if typ is _PD else np.int32)
+        keep[name] = arr
+        setattr(out, name, arr.ctypes.data_as(typ))
+    rc = lib().oracle_nbglm_fit(_pi(k), _pd(f), n, S, _pi(g), C.byref(o), C.byref(out))
+    if rc:
+        raise RuntimeError(f"oracle_nbglm_fit rc={rc}")
+    keep.update(trendCoef=np.array(out.trendCoef[:]), varLogDispEsts=out.varLogDispEsts,
+                dispPriorVar=out.dispPriorVar, sumDeviance=out.sumDeviance,
+                trendOuterIter=out.trendOuterIter, status=out.status)
+    keep["log2FoldChange"] = keep["beta1"]
+    keep["lfcSE"] = keep["se1"]
+    return keep
+
+
+def log_posterior(log_alpha, y, mu, group, prior_mean=0.0, prior_sigmasq=1.0, use_prior=False, deriv=False):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    mu = np.ascontiguousarray(mu, dtype=np.float64)
+    g = np.ascontiguousarray(group, dtype=np.int32)
+    p = 2 if g.any() else 1
+    fn = lib().oracle_dlog_posterior if deriv else lib().oracle_log_posterior
+    return fn(log_alpha, _pd(y), _pd(mu), _pi(g), len(y), p, prior_mean, prior_sigmasq, int(use_prior))
+
+
+def parametric_dispersion_fit(means, disps):
+    m = np.ascontiguousarray(means, dtype=np.float64)
+    d = np.ascontiguousarray(disps, dtype=np.float64)
+    coefs = np.empty(2)
+    it = C.c_int32(0)
+    rc = lib().oracle_parametric_dispersion_fit(_pd(m), _pd(d), len(m), _pd(coefs), C.byref(it))
+    return coefs, it.value, rc
+
+
+def window_sums(fragN, fragFullMean, region_ptr):
+    """fragN/fragFullMean: (nfrag, S); region_ptr: (n+1,) -> (N (n,S) int32, FullMean (n,S))."""
+    rp = np.ascontiguousarray(region_ptr, dtype=np.int64)
+    n = len(rp) - 1
+    fn = _cm(fragN, np.int32) if fragN is not None else None
+    ff = _cm(fragFullMean, np.float64) if fragFullMean is not None else None
+    nfrag, S = (fn if fn is not None else ff).shape
+    N = np.zeros((n, S), dtype=np.int32, order="F")
+    FM = np.zeros((n, S), dtype=np.float64, order="F")
+    rc = lib().oracle_window_sums(_pi(fn) if fn is not None else None, _pd(ff) if ff is not None else None,
+                                  nfrag, S, rp.ctypes.data_as(C.POINTER(C.c_int64)), n, _pi(N), _pd(FM))
+    if rc:
+        raise RuntimeError(f"oracle_window_sums rc={rc}")
+    return N, FM
+
+
+def offsets(FullMean, sizeFactors, theta=None):
+    """theta=None -> normFactorsM3 (norm='fullmean'); else the theta-mixed, renormalised sc."""
+    fm = _cm(FullMean, np.float64)
+    n, S = fm.shape
+    sf = np.ascontiguousarray(sizeFactors, dtype=np.float64)
+    out = np.empty((n, S), order="F")
+    lib().oracle_offsets(_pd(fm), _pd(sf), n, S, float("nan") if theta is None else float(theta), _pd(out))
+    return out
+
+
+def count_join(ru_bait, ru_oe, keys, vals):
+    b = np.ascontiguousarray(ru_bait, dtype=np.int32)
+    e = np.ascontiguousarray(ru_oe, dtype=np.int32)
+    k = np.ascontiguousarray(keys, dtype=np.int64)
+    v = np.ascontiguousarray(vals, dtype=np.int32)
+    out = np.empty(len(b), dtype=np.int32)
+    lib().oracle_count_join(_pi(b), _pi(e), len(b), k.ctypes.data_as(C.POINTER(C.c_int64)), _pi(v), len(k), _pi(out))
+    return out
+
+
+def bh_adjust(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.empty_like(p)
+    lib().oracle_bh_adjust(_pd(p), len(p), _pd(out))
+    return out
+
+
+def pnorm_two_sided(z):
+    f = lib().oracle_pnorm_two_sided
+    return np.array([f(float(x)) for x in np.atleast_1d(z)])

@@ -1,0 +1,248 @@
+"""Pin the CPU oracle (oracle/*.c): golden fixture relations, an independent numpy/scipy twin,
+and first-principles properties (stationarity of the CR-APL and of the ridge score).
+
+The reference has no tests and no input->output vectors for the DESeq2 boundary (SURVEY.md
+§4, §8c) — "parity unpinned" — so these are what stands behind the oracle."""
+import mpmath as mp
+import numpy as np
+import pytest
+from scipy import special, stats
+
+import np_twin
+from chicdiff_amd import synth
+from oracle import oracle
+
+
+@pytest.fixture(scope="module")
+def small():
+    d = synth.make(4000, 8)
+    r = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], want_mu=True)
+    return d, r
+
+
+# ---------------------------------------------------------------- golden fixture (reference data)
+def test_fixture_pvalue_is_two_sided_normal(golden):
+    p = oracle.pnorm_two_sided(golden["stat"])
+    assert np.max(np.abs(p - golden["pvalue"]) / golden["pvalue"]) < 1e-14  # down to p = 2.45e-54
+
+
+def test_fixture_stat_is_lfc_over_se(golden):
+    assert np.array_equal(golden["log2FoldChange"] / golden["lfcSE"], golden["stat"])
+
+
+def test_fixture_bh(golden):
+    assert np.array_equal(oracle.bh_adjust(golden["weighted_pvalue"]), golden["weighted_padj"])
+    ok = ~np.isnan(golden["padj"])
+    got = oracle.bh_adjust(np.where(ok, golden["pvalue"], np.nan))
+    assert np.array_equal(got[ok], golden["padj"][ok]) and ok.sum() == 24863 - 2411
+    assert np.allclose(np_twin.bh(golden["weighted_pvalue"]), golden["weighted_padj"], rtol=1e-15)
+
+
+def test_fixture_schema(golden):
+    cols = list(golden["__column_order__"])
+    assert cols[1:17] == ["baseMean", "log2FoldChange", "lfcSE", "stat", "pvalue", "padj", "baitID", "maxOE",
+                          "minOE", "regionID", "OEchr", "OEstart", "OEend", "baitchr", "baitstart", "baitend"]
+
+
+# ---------------------------------------------------------------- special functions
+def test_dnbinom_against_mpmath():
+    mp.mp.dps = 50
+    rng = np.random.default_rng(3)
+    L = oracle.lib()
+    for _ in range(400):
+        x, mu, size = float(rng.integers(0, 3000)), float(np.exp(rng.uniform(-2, 9))), float(np.exp(rng.uniform(-3, 19)))
+        X, M, Z = mp.mpf(x), mp.mpf(mu), mp.mpf(size)
+        ref = mp.loggamma(X + Z) - mp.loggamma(Z) - mp.loggamma(X + 1) + Z * mp.log(Z / (Z + M)) + X * mp.log(M / (Z + M))
+        assert abs(L.oracle_dnbinom_mu_log(x, size, mu) - ref) <= 1e-10 * max(1, abs(ref))
+
+
+def test_psi_functions():
+    L = oracle.lib()
+    xs = np.exp(np.random.default_rng(4).uniform(-11, 20, 2000))
+    dg = np.array([L.oracle_digamma(float(x)) for x in xs])
+    tg = np.array([L.oracle_trigamma(float(x)) for x in xs])
+    assert np.max(np.abs(dg - special.digamma(xs)) / np.maximum(1, np.abs(special.digamma(xs)))) < 1e-14
+    assert np.max(np.abs(tg - special.polygamma(1, xs)) / special.polygamma(1, xs)) < 1e-14
+
+
+# ---------------------------------------------------------------- a5 size factors
+def test_size_factors_match_twin():
+    d = synth.make(5000, 8)
+    assert np.allclose(oracle.size_factors(d["counts"]), np_twin.size_factors(d["counts"]), rtol=1e-14)
+    k = d["counts"][:7].copy()  # odd and even survivor counts, zeros present
+    assert np.allclose(oracle.size_factors(k), np_twin.size_factors(k), rtol=1e-14)
+
+
+# ---------------------------------------------------------------- a6 dispersion objective
+def _apl_mp(a, y, mu, g, prior):
+    al = mp.exp(a)
+    r = 1 / al
+    ll = sum(mp.loggamma(mp.mpf(float(yy)) + r) - mp.loggamma(r) - yy * mp.log(mp.mpf(float(m)) + r)
+             - r * mp.log(1 + mp.mpf(float(m)) * al) for yy, m in zip(y, mu))
+    w = [1 / (1 / mp.mpf(float(m)) + al) for m in mu]
+    wB = sum(x for x, gg in zip(w, g) if gg)
+    wA = sum(x for x, gg in zip(w, g) if not gg)
+    cr = -mp.log(wA * wB if any(g) else wA) / 2
+    pr = 0 if prior is None else -(a - prior[0]) ** 2 / (2 * prior[1])
+    return ll + cr + pr
+
+
+@pytest.mark.parametrize("S,use_prior", [(4, False), (8, False), (8, True), (16, True)])
+def test_log_posterior_matches_twin_and_gradient(S, use_prior):
+    rng = np.random.default_rng(S)
+    g = synth.groups(S)
+    X = np_twin.design(g)
+    for _ in range(50):
+        mu = np.exp(rng.uniform(-0.5, 7, S))
+        y = rng.poisson(mu).astype(float)
+        la = rng.uniform(-12, 2)
+        prior = (rng.uniform(-4, 0), rng.uniform(0.25, 2)) if use_prior else None
+        kw = dict(prior_mean=prior[0], prior_sigmasq=prior[1], use_prior=True) if prior else {}
+        got = oracle.log_posterior(la, y, mu, g, **kw)
+        ref = np_twin.cr_apl(la, y, mu, X, prior)
+        assert abs(got - ref) <= 1e-9 * max(1, abs(ref))
+        with mp.workdps(40):
+            fd = float(mp.diff(lambda t: _apl_mp(t, y.tolist(), mu.tolist(), g.tolist(), prior), mp.mpf(la)))
+        d = oracle.log_posterior(la, y, mu, g, deriv=True, **kw)
+        assert abs(d - fd) <= 1e-8 * max(1, abs(fd))
+
+
+def test_intercept_only_objective():
+    rng = np.random.default_rng(11)
+    S = 4
+    g = np.zeros(S, dtype=np.int32)
+    mu = np.exp(rng.uniform(0, 5, S))
+    y = rng.poisson(mu).astype(float)
+    assert abs(oracle.log_posterior(-2.0, y, mu, g) - np_twin.cr_apl(-2.0, y, mu, np.ones((S, 1)))) < 1e-9
+
+
+def test_gene_estimates_are_stationary(small):
+    """Rows whose line search converged in the interior sit at d APL / d log(alpha) ~ 0."""
+    d, r = small
+    g = d["group"]
+    it = r["dispGeneIter"]
+    interior = (it > 1) & (it < 100) & (r["dispGeneEst"] > 1e-6) & (r["dispGeneEst"] < 9) & (r["allZero"] == 0)
+    idx = np.nonzero(interior)[0][:300]
+    grads = []
+    for i in idx:
+        y = d["counts"][i].astype(float)
+        q = y / d["nf"][i]
+        gm = np.where(g == 1, q[g == 1].mean(), q[g == 0].mean())
+        mu = np.maximum(gm * d["nf"][i], 0.5)
+        grads.append(oracle.log_posterior(np.log(r["dispGeneEst"][i]), y, mu, g, deriv=True))
+    grads = np.abs(grads)
+    # tolerance of the search is 1e-6 in the objective, so the gradient is small, not zero
+    assert np.median(grads) < 2e-2 and np.quantile(grads, 0.99) < 0.5
+
+
+# ---------------------------------------------------------------- A3 trend
+def test_trend_matches_twin(small):
+    d, r = small
+    ok = (r["allZero"] == 0) & (r["dispGeneEst"] > 1e-6)
+    coefs, it, rc = oracle.parametric_dispersion_fit(r["baseMean"][ok], r["dispGeneEst"][ok])
+    ref, it_ref = np_twin.parametric_fit(r["baseMean"][ok], r["dispGeneEst"][ok])
+    assert rc == 0 and it == it_ref
+    assert np.allclose(coefs, ref, rtol=1e-9)
+    assert np.allclose(coefs, r["trendCoef"], rtol=1e-15)
+    res = np.log(r["dispGeneEst"][ok]) - np.log(coefs[0] + coefs[1] / r["baseMean"][ok])
+    assert np.isclose(r["varLogDispEsts"], stats.median_abs_deviation(res, scale="normal") ** 2, rtol=1e-3)
+    mad = 1.4826 * np.median(np.abs(res - np.median(res)))
+    assert np.isclose(r["varLogDispEsts"], mad ** 2, rtol=1e-13)
+    assert np.isclose(r["dispPriorVar"], max(mad ** 2 - special.polygamma(1, 3.0), 0.25), rtol=1e-13)
+
+
+# ---------------------------------------------------------------- A4 MAP
+def test_map_rules(small):
+    d, r = small
+    nz = r["allZero"] == 0
+    out = r["dispOutlier"] == 1
+    assert np.array_equal(r["dispersion"][nz & out], r["dispGeneEst"][nz & out])
+    assert np.array_equal(r["dispersion"][nz & ~out], r["dispMAP"][nz & ~out])
+    thr = np.log(r["dispFit"]) + 2 * np.sqrt(r["varLogDispEsts"])
+    assert np.array_equal(out[nz], (np.log(r["dispGeneEst"]) > thr)[nz])
+    assert np.all(np.isnan(r["dispersion"][~nz])) and np.all(np.isnan(r["pvalue"][~nz]))
+    # the MAP estimate lies between the gene-wise estimate and the trend (shrinkage), up to search tolerance
+    lo = np.minimum(r["dispGeneEst"], r["dispFit"]) * 0.98
+    hi = np.maximum(r["dispGeneEst"], r["dispFit"]) * 1.02
+    conv = nz & (r["dispIter"] < 100) & (r["dispGeneEst"] > 1e-7)
+    assert np.mean((r["dispMAP"] >= lo)[conv] & (r["dispMAP"] <= hi)[conv]) > 0.995
+
+
+# ---------------------------------------------------------------- A5 Wald
+def test_wald_fit_properties(small):
+    d, r = small
+    g = d["group"]
+    X = np_twin.design(g)
+    lam = 1e-6 / np_twin.LN2 ** 2
+    ok = np.nonzero((r["allZero"] == 0) & (r["betaConv"] == 1))[0][:400]
+    for i in ok:
+        y = d["counts"][i].astype(float)
+        nf = d["nf"][i]
+        a = r["dispersion"][i]
+        b = np.array([r["beta0"][i], r["beta1"][i]]) * np_twin.LN2
+        mu = nf * np.exp(X @ b)
+        if mu.min() > 0.5:  # no minmu floor active: exact ridge-penalised MLE
+            sc = np_twin.wald_score(b, y, nf, X, a, lam)
+            scale = np.abs(X.T @ (y / (1 + a * mu))) + 1
+            assert np.all(np.abs(sc) < 2e-4 * scale)  # IRLS stops on a 1e-8 relative deviance change
+        cov = np_twin.wald_cov(b, nf, X, a, lam)
+        assert np.isclose(r["lfcSE"][i], np.sqrt(cov[1, 1]) / np_twin.LN2, rtol=1e-9)
+        assert np.isclose(r["deviance"][i], -2 * np_twin.nb_loglik(y, mu, a), rtol=1e-6, atol=1e-6)
+        assert np.allclose(r["mu"][i], mu, rtol=1e-12)
+    nz = r["allZero"] == 0
+    assert np.allclose(r["stat"][nz], (r["log2FoldChange"] / r["lfcSE"])[nz], rtol=0, atol=0)
+    assert np.allclose(r["pvalue"][nz], 2 * stats.norm.sf(np.abs(r["stat"][nz])), rtol=1e-12)
+
+
+def test_constant_offsets_closed_form():
+    """With nf == 1 and no floor, beta1 is the log2 ratio of group means (ridge is ~2e-6)."""
+    rng = np.random.default_rng(5)
+    n, S = 500, 8
+    k = rng.negative_binomial(5, 5 / (5 + 200.0), (n, S)).astype(np.int32)
+    g = synth.groups(S)
+    r = oracle.nbglm_fit(k, np.ones((n, S)), g)
+    ref = np.log2(k[:, g == 1].mean(1) / k[:, g == 0].mean(1))
+    assert np.allclose(r["log2FoldChange"], ref, atol=1e-5)
+
+
+def test_intercept_only_fit():
+    d = synth.make(1500, 4)
+    r = oracle.nbglm_fit(d["counts"], d["nf"], np.zeros(4, dtype=np.int32), dispPriorVar=0.7)
+    nz = r["allZero"] == 0
+    q = d["counts"] / d["nf"]
+    assert np.allclose(r["beta0"][nz], np.log2(q.mean(1))[nz], rtol=1e-14)
+    assert np.all(np.isnan(r["beta1"]))
+    i = np.nonzero(nz)[0][0]
+    mu = d["nf"][i] * 2 ** r["beta0"][i]
+    assert np.isclose(r["deviance"][i], -2 * np_twin.nb_loglik(d["counts"][i], mu, r["dispersion"][i]), rtol=1e-7)
+    assert np.isclose(np.nansum(r["deviance"]), np.nansum(r["deviance"][nz]))
+
+
+# ---------------------------------------------------------------- a2 / a4 / a1
+def test_window_sums_and_offsets():
+    d = synth.make(300, 4, fragments=11)
+    N, FM = oracle.window_sums(d["fragN"], d["fragFullMean"], d["region_ptr"])
+    assert np.array_equal(N, d["counts"])  # multinomial split sums back to the region counts
+    ref = d["fragFullMean"].reshape(300, 11, 4).sum(axis=1)
+    assert np.allclose(FM, ref, rtol=1e-14, equal_nan=True) and np.isnan(FM).any()
+    sf = oracle.size_factors(N)
+    m3 = oracle.offsets(FM, sf)
+    na = np.isnan(FM).any(axis=1)
+    assert np.allclose(m3[na], sf[None, :]) and np.allclose(np.log(m3[~na]).mean(1), 0, atol=1e-13)
+    for th in (0.0, 0.25, 1.0):
+        sc = oracle.offsets(FM, sf, th)
+        ref = m3 * (1 - th) + sf[None, :] * th
+        ref = ref / np.exp(np.log(ref).mean(1, keepdims=True))
+        assert np.allclose(sc, ref, rtol=1e-14)
+
+
+def test_count_join():
+    rng = np.random.default_rng(9)
+    bait = rng.integers(1000, 1100, 5000).astype(np.int32)
+    oe = rng.integers(0, 3000, 5000).astype(np.int32)
+    keys = np.unique((bait.astype(np.int64) << 32) | oe)[::2]
+    vals = rng.integers(1, 50, len(keys)).astype(np.int32)
+    got = oracle.count_join(bait, oe, keys, vals)
+    lut = dict(zip(keys.tolist(), vals.tolist()))
+    ref = np.array([lut.get((int(b) << 32) | int(e), 0) for b, e in zip(bait, oe)], dtype=np.int32)
+    assert np.array_equal(got, ref) and (got == 0).any() and (got > 0).any()
