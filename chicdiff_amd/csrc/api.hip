@@ -1,0 +1,583 @@
+// api.hip — host side of include/chicdiff_hip.h: context, workspace, and the launch sequence of
+// one fit.  Everything is enqueued on one HIP stream; the host blocks only (a) to learn that the
+// trend state machine has finished (once per batch of IRLS passes) and (b) to read the fit's
+// scalars back at the end.  With world_size > 1 every global sum goes through the caller's
+// sum-all-reduce callback (RCCL via torch.distributed in this repo), on the same stream.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace cd;
+
+struct KTimer {
+    std::string name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double ms = 0;
+    int launches = 0;
+};
+
+struct chicdiff_hip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    chicdiff_allreduce_fn allreduce = nullptr;
+    void *allreduce_user = nullptr;
+    int world = 1, rank = 0;
+    char err[512] = {0};
+    // workspace
+    int64_t cap_n = 0;
+    int cap_S = 0;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    FitWork w{};
+    double *d_sf = nullptr;   // kMaxS doubles
+    double *d_lgm = nullptr;  // n doubles (size factors)
+    double *d_nf_tmp = nullptr;
+    FitScalars *h_sc = nullptr;  // pinned
+    // timing
+    bool timing = false;
+    std::vector<KTimer> timers;
+    std::vector<std::pair<int, hipEvent_t>> pending;
+};
+
+static char g_create_err[512];
+
+static int fail(chicdiff_hip_ctx *c, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c ? c->err : g_create_err, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail(c, CHICDIFF_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+const char *chicdiff_hip_last_error(const chicdiff_hip_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+void chicdiff_hip_default_opts(chicdiff_nbglm_opts *o) {
+    o->minDisp = 1e-8;
+    o->dispTol = 1e-6;
+    o->kappa0 = 1.0;
+    o->maxit = 100;
+    o->betaMaxit = 100;
+    o->betaTol = 1e-8;
+    o->minmu = 0.5;
+    o->outlierSD = 2.0;
+    o->dispPriorVar = NAN;
+}
+
+int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
+    if (!out) return fail(nullptr, CHICDIFF_E_INVALID, "ctx out pointer is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, CHICDIFF_E_HIP, "no HIP device available (%s): the HIP path cannot run, and there is no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, CHICDIFF_E_INVALID, "device %d out of range [0,%d)", device, ndev);
+    chicdiff_hip_ctx *c = new chicdiff_hip_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->h_sc, sizeof(FitScalars))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_sf, sizeof(double) * kMaxS)) != hipSuccess) {
+        fail(nullptr, CHICDIFF_E_HIP, "context setup: %s", hipGetErrorString(e));
+        delete c;
+        return CHICDIFF_E_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return CHICDIFF_OK;
+}
+
+void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &t : c->timers) {
+        if (t.e0) (void)hipEventDestroy(t.e0);
+        if (t.e1) (void)hipEventDestroy(t.e1);
+    }
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->d_sf) (void)hipFree(c->d_sf);
+    if (c->h_sc) (void)hipHostFree(c->h_sc);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int chicdiff_hip_set_stream(chicdiff_hip_ctx *c, void *s) {
+    if (!c) return CHICDIFF_E_INVALID;
+    c->stream = (hipStream_t)s;  // NULL is HIP's null stream (what torch calls the default stream)
+    return CHICDIFF_OK;
+}
+
+int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *c, chicdiff_allreduce_fn fn, void *user, int32_t world, int32_t rank) {
+    if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn))
+        return fail(c, CHICDIFF_E_INVALID, "set_allreduce: bad arguments");
+    c->allreduce = fn;
+    c->allreduce_user = user;
+    c->world = world;
+    c->rank = rank;
+    return CHICDIFF_OK;
+}
+
+int chicdiff_hip_enable_timing(chicdiff_hip_ctx *c, int32_t on) {
+    if (!c) return CHICDIFF_E_INVALID;
+    c->timing = on != 0;
+    return CHICDIFF_OK;
+}
+
+}  // extern "C"
+
+// ---- timing: one event pair per launch, accumulated per kernel name when the call ends ------
+struct Scope {
+    chicdiff_hip_ctx *c;
+    int idx = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    Scope(chicdiff_hip_ctx *c_, const char *name) : c(c_) {
+        if (!c->timing) return;
+        for (size_t i = 0; i < c->timers.size(); i++)
+            if (c->timers[i].name == name) idx = (int)i;
+        if (idx < 0) {
+            KTimer t;
+            t.name = name;
+            c->timers.push_back(t);
+            idx = (int)c->timers.size() - 1;
+        }
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, c->stream);
+    }
+    ~Scope() {
+        if (!c->timing) return;
+        (void)hipEventRecord(e1, c->stream);
+        c->pending.push_back({idx, e0});
+        c->pending.push_back({idx, e1});
+    }
+};
+static void timing_reset(chicdiff_hip_ctx *c) {
+    for (auto &t : c->timers) {
+        t.ms = 0;
+        t.launches = 0;
+    }
+}
+static void timing_collect(chicdiff_hip_ctx *c) {
+    if (!c->timing) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (size_t i = 0; i + 1 < c->pending.size(); i += 2) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->pending[i].second, c->pending[i + 1].second);
+        c->timers[c->pending[i].first].ms += ms;
+        c->timers[c->pending[i].first].launches++;
+        (void)hipEventDestroy(c->pending[i].second);
+        (void)hipEventDestroy(c->pending[i + 1].second);
+    }
+    c->pending.clear();
+}
+
+extern "C" int32_t chicdiff_hip_kernel_times(chicdiff_hip_ctx *c, chicdiff_kernel_time *out, int32_t cap) {
+    if (!c) return 0;
+    int32_t k = 0;
+    for (auto &t : c->timers) {
+        if (t.launches == 0) continue;
+        if (out && k < cap) {
+            out[k].name = t.name.c_str();
+            out[k].ms = t.ms;
+            out[k].launches = t.launches;
+        }
+        k++;
+    }
+    return k;
+}
+
+// ---- workspace --------------------------------------------------------------------------
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
+    if (c->ws && n <= c->cap_n && S <= c->cap_S) return CHICDIFF_OK;
+    if (c->ws) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->ws));
+        c->ws = nullptr;
+    }
+    const size_t nd = align256(sizeof(double) * (size_t)n), ni = align256(sizeof(int32_t) * (size_t)n);
+    const size_t n_double_arrays = 15 + 1 /*lgm*/, n_int_arrays = 5;
+    const size_t partials = align256(sizeof(double) * ((size_t)kRedBlocks * 72 + 128));
+    const size_t hist = align256(sizeof(double) * (size_t)kMaxS * 2 * kSelBins);
+    const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
+    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + hist + align256(sizeof(FitScalars)) + 256 + nfbytes;
+    hipError_t e = hipMalloc(&c->ws, total);
+    if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "workspace of %zu bytes: %s", total, hipGetErrorString(e));
+    c->ws_bytes = total;
+    char *p = (char *)c->ws;
+    auto takeD = [&](double *&ptr) { ptr = (double *)p; p += nd; };
+    auto takeI = [&](int32_t *&ptr) { ptr = (int32_t *)p; p += ni; };
+    FitWork &w = c->w;
+    takeD(w.baseMean); takeD(w.baseVar); takeD(w.gm0); takeD(w.gm1); takeD(w.rough); takeD(w.binit0); takeD(w.binit1);
+    takeD(w.crow); takeD(w.dispGene); takeD(w.dispFit); takeD(w.dispMAP); takeD(w.disp); takeD(w.beta0); takeD(w.beta1);
+    takeD(w.resid); takeD(c->d_lgm);
+    takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter);
+    w.partials = (double *)p; p += partials;
+    w.hist = (double *)p; p += hist;
+    w.sc = (FitScalars *)p; p += align256(sizeof(FitScalars));
+    w.queue = (unsigned long long *)p; p += 256;
+    c->d_nf_tmp = (double *)p;
+    c->cap_n = n;
+    c->cap_S = S;
+    return CHICDIFF_OK;
+}
+
+static int do_allreduce(chicdiff_hip_ctx *c, double *dev, int64_t count) {
+    if (c->world <= 1) return CHICDIFF_OK;
+    if (c->allreduce(c->allreduce_user, dev, count) != 0) return fail(c, CHICDIFF_E_COMM, "all-reduce callback failed");
+    return CHICDIFF_OK;
+}
+
+static double *sums_of(const FitWork &w) { return w.partials + (size_t)kRedBlocks * 72; }
+
+// exact medians by radix select; results land in w.sc (see sel_finish_kernel)
+static int run_select(chicdiff_hip_ctx *c, SelArgs a) {
+    hipStream_t st = c->stream;
+    {
+        Scope t(c, "select_count");
+        launch_sel_count(a, c->w, st);
+    }
+    int rc = do_allreduce(c, c->w.hist, a.ncol);
+    if (rc) return rc;
+    launch_sel_begin(a, c->w, st);
+    static const int shifts[6] = {52, 40, 28, 16, 4, 0};
+    for (int r = 0; r < 6; r++) {
+        a.shift = shifts[r];
+        {
+            Scope t(c, "select_hist");
+            launch_sel_hist(a, c->w, st);
+        }
+        if ((rc = do_allreduce(c, c->w.hist, (int64_t)a.ncol * 2 * kSelBins))) return rc;
+        Scope t(c, "select_step");
+        launch_sel_step(a, c->w, st);
+    }
+    launch_sel_finish(a, c->w, st);
+    return CHICDIFF_OK;
+}
+
+static int check_counts_group(chicdiff_hip_ctx *c, int64_t n, int32_t S, const int32_t *group, FitDims &d) {
+    if (n < 1 || S < 2 || S > kMaxS) return fail(c, CHICDIFF_E_INVALID, "need n >= 1 and 2 <= S <= %d (got n=%lld, S=%d)", kMaxS, (long long)n, S);
+    d.n = n;
+    d.S = S;
+    d.gmask = 0;
+    d.nA = d.nB = 0;
+    for (int j = 0; j < S; j++) {
+        const int g = group ? group[j] : 0;
+        if (g != 0 && g != 1) return fail(c, CHICDIFF_E_INVALID, "group[%d]=%d: only two-level designs (0/1) or ~1 (all 0) are supported", j, g);
+        if (g) { d.gmask |= (1ull << j); d.nB++; } else d.nA++;
+    }
+    d.p = d.nB > 0 ? 2 : 1;
+    if (d.p == 2 && d.nA == 0) return fail(c, CHICDIFF_E_INVALID, "design has no sample in the reference level");
+    if (S <= d.p) return fail(c, CHICDIFF_E_INVALID, "no residual degrees of freedom (S=%d, p=%d)", S, d.p);
+    return CHICDIFF_OK;
+}
+
+static Opts make_opts(const chicdiff_nbglm_opts *in, int S) {
+    chicdiff_nbglm_opts o;
+    if (in) o = *in; else chicdiff_hip_default_opts(&o);
+    Opts r;
+    r.minDisp = o.minDisp; r.dispTol = o.dispTol; r.kappa0 = o.kappa0; r.betaTol = o.betaTol; r.minmu = o.minmu;
+    r.outlierSD = o.outlierSD; r.dispPriorVarIn = o.dispPriorVar; r.maxit = o.maxit; r.betaMaxit = o.betaMaxit;
+    r.maxDisp = S > 10 ? (double)S : 10.0;
+    return r;
+}
+
+static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const double *d_nf, FitDims d, Opts o,
+                        const chicdiff_nbglm_out *d_out, chicdiff_nbglm_scalars *scalars) {
+    int rc;
+    hipStream_t st = c->stream;
+    FitWork &w = c->w;
+    HIPCHK(c, hipMemsetAsync(w.queue, 0, 256, st));
+    HIPCHK(c, hipMemsetAsync(w.sc, 0, sizeof(FitScalars), st));
+    {
+        Scope t(c, "prep");
+        launch_prep(d_counts, d_nf, d, w, o, st);
+        launch_prep_finish(d, w, st);
+    }
+    if ((rc = do_allreduce(c, w.sc->colsum, kMaxS + 1))) return rc;  // colsum[kMaxS] + nnz are contiguous
+    launch_xim(d, w, st);
+    {
+        Scope t(c, "disp_gene");
+        launch_disp_gene(d_counts, d_nf, d, w, o, st);
+    }
+    // trend: batches of passes, host polls the finished flag between batches
+    launch_trend_init(d, w, o, st);
+    int passes = 0;
+    for (;;) {
+        const int batch = passes == 0 ? 12 : 8;
+        for (int k = 0; k < batch; k++) {
+            {
+                Scope t(c, "trend_pass");
+                launch_trend_pass(d, w, o, st);
+            }
+            if ((rc = do_allreduce(c, sums_of(w), kTrendSums))) return rc;
+            launch_trend_step(d, w, o, st);
+        }
+        passes += batch;
+        HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (c->h_sc->finished) break;
+        if (passes > 11 * 27 + 16) return fail(c, CHICDIFF_E_NUMERIC, "trend state machine did not finish");
+    }
+    int status = 0;
+    if (c->h_sc->failed) status |= CHICDIFF_ST_TREND_FAILED;
+    // MAD of the log residuals
+    launch_dispfit_resid(d, w, o, st);
+    SelArgs sa{};
+    sa.n = d.n;
+    sa.ncol = 1;
+    sa.resid = w.resid;
+    sa.mode = SEL_RESID;
+    if ((rc = run_select(c, sa))) return rc;
+    sa.mode = SEL_ABSDEV;
+    if ((rc = run_select(c, sa))) return rc;
+    launch_prior_var(d, w, o, st);
+    {
+        Scope t(c, "disp_map");
+        launch_disp_map(d_counts, d_nf, d, w, o, st);
+    }
+    static const chicdiff_nbglm_out none{};
+    const chicdiff_nbglm_out &out = d_out ? *d_out : none;
+    if (d.p == 2) {
+        {
+            Scope t(c, "wald_prep");
+            launch_wald_prep(d_counts, d_nf, d, w, o, st);
+        }
+        {
+            Scope t(c, "wald_irls");
+            launch_wald_irls(d_counts, d_nf, d, w, o, st);
+        }
+        Scope t(c, "wald_final");
+        launch_wald_final(d_counts, d_nf, d, w, o, out, st);
+    } else {
+        Scope t(c, "wald_intercept");
+        launch_wald_intercept(d_counts, d_nf, d, w, o, out, st);
+    }
+    launch_dev_sum_finish(d, w, st);
+    if ((rc = do_allreduce(c, sums_of(w), 3))) return rc;
+    // copy the per-row workspace columns the caller asked for
+    const size_t nb = sizeof(double) * (size_t)d.n, ib = sizeof(int32_t) * (size_t)d.n;
+#define CPY(dst, src, bytes) \
+    if (out.dst) HIPCHK(c, hipMemcpyAsync(out.dst, src, bytes, hipMemcpyDeviceToDevice, st))
+    CPY(baseMean, w.baseMean, nb); CPY(baseVar, w.baseVar, nb); CPY(dispGeneEst, w.dispGene, nb);
+    CPY(dispFit, w.dispFit, nb); CPY(dispMAP, w.dispMAP, nb); CPY(dispersion, w.disp, nb);
+    CPY(dispGeneIter, w.geneIter, ib); CPY(dispIter, w.mapIter, ib); CPY(dispOutlier, w.outlier, ib);
+    CPY(allZero, w.allZero, ib);
+#undef CPY
+    double hs[3];
+    HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hs, sums_of(w), sizeof hs, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    if (scalars) {
+        const FitScalars *s = c->h_sc;
+        scalars->trendCoef[0] = s->coefs[0];
+        scalars->trendCoef[1] = s->coefs[1];
+        scalars->varLogDispEsts = s->varLogDispEsts;
+        scalars->dispPriorVar = s->dispPriorVar;
+        scalars->nAllZero = (int64_t)hs[2];
+        scalars->sumDeviance = hs[2] > 0 ? NAN : hs[0];  // sum() without na.rm, chicdiff.R:1647
+        scalars->trendOuterIter = s->outer_it;
+        if (hs[2] > 0) status |= CHICDIFF_ST_ALLZERO_ROWS;
+        if (hs[1] > 0) status |= CHICDIFF_ST_BETA_NONCONV;
+        if (!(o.dispPriorVarIn == o.dispPriorVarIn) && d.S - d.p <= 3) status |= CHICDIFF_ST_PRIORVAR_MC;
+        scalars->status = status;
+    }
+    return CHICDIFF_OK;
+}
+
+extern "C" {
+
+int chicdiff_hip_nbglm_fit_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, const double *d_nf, int64_t n, int32_t S,
+                               const int32_t *group, const chicdiff_nbglm_opts *opts, const chicdiff_nbglm_out *d_out,
+                               chicdiff_nbglm_scalars *scalars) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_counts || !d_nf) return fail(c, CHICDIFF_E_INVALID, "counts / nf pointer is NULL");
+    FitDims d;
+    int rc = check_counts_group(c, n, S, group, d);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, n, S))) return rc;
+    timing_reset(c);
+    rc = fit_dev_impl(c, d_counts, d_nf, d, make_opts(opts, S), d_out, scalars);
+    timing_collect(c);
+    return rc;
+}
+
+int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const double *nf, int64_t n, int32_t S,
+                           const int32_t *group, const chicdiff_nbglm_opts *opts, const chicdiff_nbglm_out *out,
+                           chicdiff_nbglm_scalars *scalars) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!counts || !nf) return fail(c, CHICDIFF_E_INVALID, "counts / nf pointer is NULL");
+    if (n < 1 || S < 2 || S > kMaxS) return fail(c, CHICDIFF_E_INVALID, "need n >= 1 and 2 <= S <= %d", kMaxS);
+    for (int64_t k = 0; k < n * S; k++)
+        if (counts[k] < 0) return fail(c, CHICDIFF_E_INVALID, "counts[%lld] is negative or NA_integer_", (long long)k);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t cb = sizeof(int32_t) * (size_t)n * S, fb = sizeof(double) * (size_t)n * S;
+    const size_t nd = (sizeof(double) * (size_t)n + 255) & ~(size_t)255;
+    char *buf = nullptr;
+    HIPCHK(c, hipMalloc((void **)&buf, ((cb + 255) & ~(size_t)255) + fb + 256 + nd * 20));
+    int32_t *d_counts = (int32_t *)buf;
+    double *d_nf = (double *)(buf + ((cb + 255) & ~(size_t)255));
+    char *po = (char *)d_nf + ((fb + 255) & ~(size_t)255);
+    chicdiff_nbglm_out dout{};
+    static const chicdiff_nbglm_out none{};
+    const chicdiff_nbglm_out &ho = out ? *out : none;
+    double *const *hd[] = {&ho.baseMean, &ho.baseVar, &ho.dispGeneEst, &ho.dispFit, &ho.dispMAP, &ho.dispersion, &ho.log2FoldChange,
+                           &ho.lfcSE, &ho.stat, &ho.pvalue, &ho.intercept, &ho.interceptSE, &ho.deviance, &ho.maxCooks};
+    double **dd[] = {&dout.baseMean, &dout.baseVar, &dout.dispGeneEst, &dout.dispFit, &dout.dispMAP, &dout.dispersion,
+                     &dout.log2FoldChange, &dout.lfcSE, &dout.stat, &dout.pvalue, &dout.intercept, &dout.interceptSE,
+                     &dout.deviance, &dout.maxCooks};
+    int32_t *const *hi[] = {&ho.dispGeneIter, &ho.dispIter, &ho.dispOutlier, &ho.betaConv, &ho.betaIter, &ho.allZero};
+    int32_t **di[] = {&dout.dispGeneIter, &dout.dispIter, &dout.dispOutlier, &dout.betaConv, &dout.betaIter, &dout.allZero};
+    for (int k = 0; k < 14; k++) { if (*hd[k]) *dd[k] = (double *)po; po += nd; }
+    for (int k = 0; k < 6; k++) { if (*hi[k]) *di[k] = (int32_t *)po; po += nd; }
+    int rc = CHICDIFF_OK;
+    hipError_t e;
+    if ((e = hipMemcpyAsync(d_counts, counts, cb, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_nf, nf, fb, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+        rc = fail(c, CHICDIFF_E_HIP, "H2D copy: %s", hipGetErrorString(e));
+    if (!rc) rc = chicdiff_hip_nbglm_fit_dev(c, d_counts, d_nf, n, S, group, opts, &dout, scalars);
+    if (!rc) {
+        for (int k = 0; k < 14 && !rc; k++)
+            if (*hd[k] && (e = hipMemcpy(*hd[k], *dd[k], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess)
+                rc = fail(c, CHICDIFF_E_HIP, "D2H copy: %s", hipGetErrorString(e));
+        for (int k = 0; k < 6 && !rc; k++)
+            if (*hi[k] && (e = hipMemcpy(*hi[k], *di[k], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess)
+                rc = fail(c, CHICDIFF_E_HIP, "D2H copy: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(buf);
+    return rc;
+}
+
+int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S, double *sf_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_counts || !sf_host || n < 1 || S < 1 || S > kMaxS) return fail(c, CHICDIFF_E_INVALID, "size_factors: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_workspace(c, n, S);
+    if (rc) return rc;
+    timing_reset(c);
+    {
+        Scope t(c, "row_lgm");
+        launch_row_lgm(d_counts, n, S, c->d_lgm, c->stream);
+    }
+    SelArgs sa{};
+    sa.mode = SEL_SIZEFACTOR;
+    sa.ncol = S;
+    sa.n = n;
+    sa.counts = d_counts;
+    sa.lgm = c->d_lgm;
+    sa.S = S;
+    if ((rc = run_select(c, sa))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_sc, c->w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    for (int j = 0; j < S; j++) {
+        if (c->h_sc->sel_count[j] <= 0)
+            return fail(c, CHICDIFF_E_NUMERIC, "every gene contains at least one zero, cannot compute log geometric means");
+        sf_host[j] = c->h_sc->sel_value[2 * j];
+    }
+    return CHICDIFF_OK;
+}
+
+int chicdiff_hip_offsets_dev(chicdiff_hip_ctx *c, const double *d_fullMean, const double *sf_host, int64_t n, int32_t S,
+                             double theta, double *d_nf_out) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_fullMean || !sf_host || !d_nf_out || n < 1 || S < 1 || S > kMaxS) return fail(c, CHICDIFF_E_INVALID, "offsets: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
+    const int mix = theta == theta;
+    {
+        Scope t(c, "offsets");
+        launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, d_nf_out, c->stream);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // sf_host may be a temporary
+    timing_collect(c);
+    return CHICDIFF_OK;
+}
+
+int chicdiff_hip_window_sums_dev(chicdiff_hip_ctx *c, const int32_t *d_fragN, const double *d_fragFM, int64_t nfrag,
+                                 int32_t S, const int64_t *d_region_ptr, int64_t n, int32_t *d_N, double *d_FM) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_region_ptr || n < 1 || S < 1 || (d_fragN && !d_N) || (d_fragFM && !d_FM))
+        return fail(c, CHICDIFF_E_INVALID, "window_sums: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    {
+        Scope t(c, "window_sums");
+        launch_window_sums(d_fragN, d_fragFM, nfrag, S, d_region_ptr, n, d_N, d_FM, c->stream);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return CHICDIFF_OK;
+}
+
+int chicdiff_hip_count_join_dev(chicdiff_hip_ctx *c, const int32_t *d_ru_bait, const int32_t *d_ru_oe, int64_t nru,
+                                const int64_t *d_keys, const int32_t *d_vals, int64_t nkeys, int32_t *d_out) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_ru_bait || !d_ru_oe || !d_out || nru < 0 || nkeys < 0 || (nkeys > 0 && (!d_keys || !d_vals)))
+        return fail(c, CHICDIFF_E_INVALID, "count_join: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    if (nru > 0) {
+        Scope t(c, "count_join");
+        launch_count_join(d_ru_bait, d_ru_oe, nru, d_keys, d_vals, nkeys, d_out, c->stream);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return CHICDIFF_OK;
+}
+
+int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, const double *d_fullMean, const double *sf_host,
+                                int64_t n, int32_t S, const double *thetas, int32_t ntheta, const chicdiff_nbglm_opts *opts,
+                                double *deviances_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_counts || !d_fullMean || !sf_host || !thetas || !deviances_host || ntheta < 1)
+        return fail(c, CHICDIFF_E_INVALID, "theta_grid: bad arguments");
+    FitDims d;
+    int rc = check_counts_group(c, n, S, nullptr, d);  // design ~ 1  ("sic!", chicdiff.R:1629-1631)
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, n, S))) return rc;
+    timing_reset(c);
+    HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
+    const Opts o = make_opts(opts, S);
+    for (int t = 0; t < ntheta; t++) {
+        {
+            Scope s(c, "offsets");
+            launch_offsets(d_fullMean, c->d_sf, n, S, thetas[t], 1, c->d_nf_tmp, c->stream);
+        }
+        chicdiff_nbglm_scalars sc;
+        if ((rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, o, nullptr, &sc))) return rc;
+        deviances_host[t] = sc.sumDeviance;
+    }
+    timing_collect(c);
+    return CHICDIFF_OK;
+}
+
+}  // extern "C"
+
+// small extra export used by the parity tests: p = 2*pnorm(-|stat|) on device (Cody, as R)
+extern "C" int chicdiff_hip_wald_pvalues_dev(chicdiff_hip_ctx *c, const double *d_stat, int64_t n, double *d_p) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_stat || !d_p || n < 0) return fail(c, CHICDIFF_E_INVALID, "wald_pvalues: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > 0) launch_pvalues(d_stat, n, d_p, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CHICDIFF_OK;
+}

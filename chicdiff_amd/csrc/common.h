@@ -1,0 +1,119 @@
+// common.h — shared declarations of the HIP implementation behind include/chicdiff_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/chicdiff_hip.h"
+
+namespace cd {
+
+constexpr int kMaxS = 64;          // samples per fit (group mask is one 64-bit word)
+constexpr int kSelBits = 12;       // radix-select digit width
+constexpr int kSelBins = 1 << kSelBits;
+constexpr int kRedBlocks = 1024;   // fixed grid of the reduction passes (deterministic two-stage sums)
+constexpr int kTrendSums = 8;      // dev, sw, swx, swxx, swy, swxy, count, invalid
+
+// Device-resident scalars of one fit; the host reads the struct back once, at the end.
+struct FitScalars {
+    double colsum[kMaxS];  // column sums of nf over non-all-zero rows (then all-reduced)
+    double nnz;            // number of non-all-zero rows (double: goes through the f64 all-reduce)
+    double xim;            // mean_j 1/colMeans(nf)_j                  (DESeq2 momentsDispEstimate)
+    // trend state machine (parametricDispersionFit + glm.fit), see trend_step_kernel
+    double coefs[2];       // outer-loop coefficients (define the `good` set)
+    double b[2];           // inner IRLS iterate
+    double devold;
+    int32_t inner_it, outer_it, phase, finished, failed, conv, _pad0, _pad1;
+    double nfit;           // rows with dispGeneEst > 100*minDisp
+    // MAD / prior
+    double med, mad, varLogDispEsts, dispPriorVar;
+    double nres;           // rows with dispGeneEst >= 100*minDisp
+    double sumDeviance;
+    double nonconv;        // rows whose IRLS hit betaMaxit
+    // radix-select state: up to kMaxS columns x 2 ranks
+    uint64_t sel_prefix[kMaxS * 2];
+    double sel_rank[kMaxS * 2];  // remaining 0-based rank inside the current prefix
+    double sel_count[kMaxS];     // population per column
+    double sel_value[kMaxS * 2]; // selected order statistics
+};
+
+struct FitDims {
+    int64_t n;
+    int32_t S, p, nA, nB;
+    uint64_t gmask;  // bit j set = sample j in group B
+};
+
+// workspace pointers of one fit (all device memory, length n unless noted)
+struct FitWork {
+    double *baseMean, *baseVar, *gm0, *gm1, *rough, *binit0, *binit1, *crow;
+    double *dispGene, *dispFit, *dispMAP, *disp, *beta0, *beta1, *resid;
+    int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter;
+    double *partials;             // kRedBlocks x 72 doubles
+    double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
+    unsigned long long *queue;    // work-queue heads
+    FitScalars *sc;
+};
+
+struct Opts {
+    double minDisp, dispTol, kappa0, betaTol, minmu, outlierSD, dispPriorVarIn, maxDisp;
+    int32_t maxit, betaMaxit;
+};
+
+// ---- launchers (defined in the .hip files; all enqueue on `st` and never synchronise) -------
+void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_prep_finish(FitDims d, FitWork w, hipStream_t st);          // partials -> colsum,nnz
+void launch_xim(FitDims d, FitWork w, hipStream_t st);                  // colsum -> xim
+void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_disp_map(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_trend_init(FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st);   // -> partials -> sums in w.partials[0..8)
+void launch_trend_step(FitDims d, FitWork w, Opts o, hipStream_t st);   // consumes sums, advances the state machine
+void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
+                       const chicdiff_nbglm_out &out, hipStream_t st);
+void launch_wald_intercept(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
+                           const chicdiff_nbglm_out &out, hipStream_t st);
+void launch_dev_sum_finish(FitDims d, FitWork w, hipStream_t st);
+
+// radix select over keys produced on the fly; `mode` picks the key generator
+enum SelMode { SEL_RESID = 0, SEL_ABSDEV = 1, SEL_SIZEFACTOR = 2 };
+struct SelArgs {
+    int mode;
+    int ncol;               // columns selected simultaneously (1, or S for size factors)
+    int64_t n;
+    const double *resid;    // SEL_RESID / SEL_ABSDEV: residuals (NaN = excluded)
+    const int32_t *counts;  // SEL_SIZEFACTOR
+    const double *lgm;      // SEL_SIZEFACTOR: row log geometric means (-inf/NaN = excluded)
+    int S;
+    int shift;              // bit position of the current digit
+};
+void launch_sel_count(SelArgs a, FitWork w, hipStream_t st);    // population per column -> partials -> hist[0..ncol)
+void launch_sel_begin(SelArgs a, FitWork w, hipStream_t st);    // ranks from populations
+void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st);     // digit histograms for the live prefixes
+void launch_sel_step(SelArgs a, FitWork w, hipStream_t st);     // pick bins, extend prefixes
+void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st);   // prefixes -> values; median into sc
+
+void launch_row_lgm(const int32_t *counts, int64_t n, int S, double *lgm, hipStream_t st);
+void launch_offsets(const double *fullMean, const double *sf_dev, int64_t n, int S, double theta, int mix,
+                    double *out, hipStream_t st);
+void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfrag, int S, const int64_t *rptr,
+                        int64_t n, int32_t *N, double *FM, hipStream_t st);
+void launch_count_join(const int32_t *bait, const int32_t *oe, int64_t nru, const int64_t *keys,
+                       const int32_t *vals, int64_t nkeys, int32_t *out, hipStream_t st);
+void launch_pvalues(const double *stat, int64_t n, double *p, hipStream_t st);
+
+// order-preserving map double -> uint64 (NaN never passed in)
+__host__ __device__ inline uint64_t key_of(double x) {
+    union { double d; uint64_t u; } c;
+    c.d = x;
+    return (c.u & 0x8000000000000000ull) ? ~c.u : (c.u | 0x8000000000000000ull);
+}
+__host__ __device__ inline double value_of(uint64_t k) {
+    union { double d; uint64_t u; } c;
+    c.u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return c.d;
+}
+
+}  // namespace cd

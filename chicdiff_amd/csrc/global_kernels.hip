@@ -1,0 +1,462 @@
+// global_kernels.hip — the fit's global statistics and the HBM-bound Chicdiff-side kernels.
+//
+//  * dispersion trend  alpha(mu) = a0 + a1/mu  — DESeq2 parametricDispersionFit + R glm.fit for
+//    Gamma(link="identity"): one fused pass per IRLS step (deviance of
+//    the current iterate + weighted-LS sums for the next), two-stage deterministic reduction,
+//    and a one-thread state machine so the host never has to read the iterate back;
+//  * exact medians (size factors, chicdiff.R:1561-1562 / A1; MAD of log residuals, A3) by a
+//    12-bit radix select over order-preserving 64-bit keys — every step is a SUM, so row
+//    sharding only needs sum-all-reduces of the histograms;
+//  * offsets (chicdiff.R:1583-1589, 1635-1638), window sums (:1540-1547), count join (:843-858).
+#include "common.h"
+#include "devmath.h"
+
+namespace cd {
+
+// ------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void block_reduce_store(double (&v)[K], double *out) {
+    __shared__ double red[K][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (lane == 0) red[k][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) out[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// sums[k] = sum_b partials[b*K + k], fixed order (deterministic)
+__global__ void reduce_partials_kernel(const double *partials, int nblk, int K, double *sums) {
+    __shared__ double red[256];
+    for (int k = 0; k < K; k++) {
+        double acc = 0;
+        for (int b = threadIdx.x; b < nblk; b += 256) acc += partials[(int64_t)b * K + k];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sums[k] = red[0];
+        __syncthreads();
+    }
+}
+
+static inline double *sums_of(const FitWork &w) { return w.partials + (size_t)kRedBlocks * 72; }
+
+// ------------------------------------------------------------------------------------------
+// trend
+enum { TR_INNER_START = 0, TR_INNER_ITER = 1 };
+
+__global__ void trend_init_kernel(FitWork w) {
+    FitScalars *sc = w.sc;
+    sc->coefs[0] = 0.1;
+    sc->coefs[1] = 1.0;
+    sc->b[0] = 0.1;
+    sc->b[1] = 1.0;
+    sc->devold = 0;
+    sc->inner_it = 0;
+    sc->outer_it = 0;
+    sc->phase = TR_INNER_START;
+    sc->finished = 0;
+    sc->failed = 0;
+    sc->conv = 0;
+}
+
+__global__ __launch_bounds__(256) void trend_pass_kernel(FitDims d, FitWork w, double minDisp) {
+    const FitScalars *sc = w.sc;
+    if (sc->finished) return;
+    const double c0 = sc->coefs[0], c1 = sc->coefs[1], b0 = sc->b[0], b1 = sc->b[1];
+    double v[kTrendSums] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+        if (w.allZero[i]) continue;
+        const double y = w.dispGene[i];
+        if (!(y > 100 * minDisp)) continue;
+        const double bm = w.baseMean[i];
+        const double r = y / (c0 + c1 / bm);
+        if (!(r > 1e-4 && r < 15)) continue;
+        const double x = 1.0 / bm;
+        const double mu = b0 + b1 * x;
+        if (!(mu > 0) || !isfinite(mu)) {
+            v[7] += 1;
+            continue;
+        }
+        v[0] += -2.0 * (log(y / mu) - (y - mu) / mu);
+        const double wt = 1.0 / (mu * mu);
+        v[1] += wt;
+        v[2] += wt * x;
+        v[3] += wt * x * x;
+        v[4] += wt * y;
+        v[5] += wt * x * y;
+        v[6] += 1;
+    }
+    block_reduce_store<kTrendSums>(v, w.partials + (size_t)blockIdx.x * kTrendSums);
+}
+
+// One thread: R's glm.fit iteration bookkeeping + parametricDispersionFit's outer loop.
+__global__ void trend_step_kernel(FitWork w) {
+    FitScalars *sc = w.sc;
+    if (sc->finished) return;
+    const double *s = w.partials + (size_t)kRedBlocks * 72;
+    const double dev = s[0], sw = s[1], swx = s[2], swxx = s[3], swy = s[4], swxy = s[5], cnt = s[6], bad = s[7];
+    bool inner_done = false, conv = false;
+    if (bad > 0 || cnt < 2) {  // invalid mu (R would step-halve; DESeq2 ends in "fit failed") or no data
+        sc->failed = 1;
+        sc->finished = 1;
+        return;
+    }
+    if (sc->phase == TR_INNER_START) {
+        sc->devold = dev;
+        sc->inner_it = 0;
+        sc->phase = TR_INNER_ITER;
+    } else {
+        if (fabs(dev - sc->devold) / (fabs(dev) + 0.1) < 1e-8) {
+            inner_done = true;
+            conv = true;
+        } else {
+            sc->devold = dev;
+            if (sc->inner_it >= 25) inner_done = true;  // glm.fit maxit, not converged
+        }
+    }
+    if (!inner_done) {
+        const double det = sw * swxx - swx * swx;
+        const double nb0 = (swxx * swy - swx * swxy) / det, nb1 = (sw * swxy - swx * swy) / det;
+        if (!isfinite(nb0) || !isfinite(nb1)) {
+            sc->failed = 1;
+            sc->finished = 1;
+            return;
+        }
+        sc->b[0] = nb0;
+        sc->b[1] = nb1;
+        sc->inner_it++;
+        return;
+    }
+    // inner loop over: parametricDispersionFit bookkeeping
+    const double o0 = sc->coefs[0], o1 = sc->coefs[1];
+    sc->coefs[0] = sc->b[0];
+    sc->coefs[1] = sc->b[1];
+    if (!(sc->coefs[0] > 0 && sc->coefs[1] > 0)) {
+        sc->failed = 1;
+        sc->finished = 1;
+        return;
+    }
+    const double l0 = log(sc->coefs[0] / o0), l1 = log(sc->coefs[1] / o1);
+    if ((l0 * l0 + l1 * l1 < 1e-6) && conv) {
+        sc->finished = 1;
+        sc->conv = 1;
+        return;
+    }
+    sc->outer_it++;
+    if (sc->outer_it > 10) {
+        sc->failed = 2;
+        sc->finished = 1;
+        return;
+    }
+    sc->phase = TR_INNER_START;  // next glm() call starts from the new coefs, on the new `good` set
+}
+
+void launch_trend_init(FitDims, FitWork w, Opts, hipStream_t st) { trend_init_kernel<<<1, 1, 0, st>>>(w); }
+void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st) {
+    trend_pass_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp);
+    reduce_partials_kernel<<<1, 256, 0, st>>>(w.partials, kRedBlocks, kTrendSums, sums_of(w));
+}
+void launch_trend_step(FitDims, FitWork w, Opts, hipStream_t st) { trend_step_kernel<<<1, 1, 0, st>>>(w); }
+
+// residuals of log gene-wise estimates around the trend (rows with dispGeneEst >= 100*minDisp)
+__global__ __launch_bounds__(256) void resid_kernel(FitDims d, FitWork w, double minDisp) {
+    const double c0 = w.sc->coefs[0], c1 = w.sc->coefs[1];
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+        double r = NAN;
+        if (!w.allZero[i]) {
+            const double y = w.dispGene[i];
+            if (y >= 100 * minDisp) r = log(y) - log(c0 + c1 / w.baseMean[i]);
+        }
+        w.resid[i] = r;
+    }
+}
+void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st) {
+    resid_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp);
+}
+
+// estimateDispersionsPriorVar, closed-form branch (A4)
+__global__ void prior_var_kernel(FitDims d, FitWork w, double prior_in) {
+    FitScalars *sc = w.sc;
+    const double v = sc->mad * sc->mad;
+    sc->varLogDispEsts = v;
+    if (prior_in == prior_in) {
+        sc->dispPriorVar = prior_in;
+    } else {
+        sc->dispPriorVar = fmax(v - trigamma_pos((d.S - d.p) / 2.0), 0.25);
+    }
+}
+void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st) {
+    prior_var_kernel<<<1, 1, 0, st>>>(d, w, o.dispPriorVarIn);
+}
+
+// ------------------------------------------------------------------------------------------
+// radix select
+__device__ __forceinline__ bool sel_key(const SelArgs &a, const FitScalars *sc, int col, int64_t i, uint64_t &key) {
+    double x;
+    if (a.mode == SEL_SIZEFACTOR) {
+        const double lg = a.lgm[i];
+        const int32_t k = a.counts[(int64_t)col * a.n + i];
+        if (!isfinite(lg) || k <= 0) return false;
+        x = log((double)k) - lg;
+    } else {
+        x = a.resid[i];
+        if (x != x) return false;
+        if (a.mode == SEL_ABSDEV) x = fabs(x - sc->med);
+    }
+    key = key_of(x);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void sel_count_kernel(SelArgs a, FitWork w) {
+    const int col = blockIdx.y;
+    double v[1] = {0};
+    uint64_t key;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256)
+        if (sel_key(a, w.sc, col, i, key)) v[0] += 1;
+    block_reduce_store<1>(v, w.partials + ((size_t)col * gridDim.x + blockIdx.x));
+}
+__global__ void sel_count_finish_kernel(FitWork w, int nblk, int ncol) {
+    const int c = threadIdx.x;
+    if (c >= ncol) return;
+    double s = 0;
+    for (int b = 0; b < nblk; b++) s += w.partials[(size_t)c * nblk + b];
+    w.hist[c] = s;  // rides the all-reduce from here
+}
+__global__ void sel_begin_kernel(FitWork w, int ncol) {
+    const int c = threadIdx.x;
+    if (c >= ncol) return;
+    FitScalars *sc = w.sc;
+    const double m = w.hist[c];
+    sc->sel_count[c] = m;
+    const int64_t mi = (int64_t)m;
+    sc->sel_rank[2 * c] = (double)((mi - 1) / 2);
+    sc->sel_rank[2 * c + 1] = (double)(mi / 2);
+    sc->sel_prefix[2 * c] = 0;
+    sc->sel_prefix[2 * c + 1] = 0;
+}
+
+// histograms of the current digit for the two live prefixes of column blockIdx.y
+__global__ __launch_bounds__(256) void sel_hist_kernel(SelArgs a, FitWork w, int bits) {
+    __shared__ unsigned int h[2][kSelBins];
+    const int col = blockIdx.y;
+    const FitScalars *sc = w.sc;
+    for (int k = threadIdx.x; k < 2 * kSelBins; k += 256) (&h[0][0])[k] = 0;
+    __syncthreads();
+    const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
+    const int hi = a.shift + bits;  // bits above `hi` are fixed by the prefix
+    const bool same = (p0 == p1);
+    const uint64_t mask = (1ull << bits) - 1ull;
+    uint64_t key;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        if (!sel_key(a, sc, col, i, key)) continue;
+        const uint64_t top = (hi >= 64) ? 0ull : (key >> hi);
+        const unsigned dig = (unsigned)((key >> a.shift) & mask);
+        if (top == ((hi >= 64) ? 0ull : (p0 >> hi))) atomicAdd(&h[0][dig], 1u);
+        else if (!same && top == (p1 >> hi)) atomicAdd(&h[1][dig], 1u);
+    }
+    __syncthreads();
+    double *g = w.hist + (size_t)col * 2 * kSelBins;
+    for (int k = threadIdx.x; k < 2 * kSelBins; k += 256) {
+        const unsigned c = (&h[0][0])[k];
+        if (c) atomicAdd(&g[k], (double)c);
+    }
+}
+
+// pick the bin holding the wanted rank; one block per column, both rank slots in turn
+__global__ __launch_bounds__(256) void sel_step_kernel(SelArgs a, FitWork w, int bits) {
+    __shared__ double part[256];
+    const int col = blockIdx.x;
+    FitScalars *sc = w.sc;
+    const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
+    const int nb = 1 << bits, per = (nb + 255) / 256;
+    for (int slot = 0; slot < 2; slot++) {
+        const int hslot = (slot == 1 && p0 != p1) ? 1 : 0;
+        const double *g = w.hist + ((size_t)col * 2 + hslot) * kSelBins;
+        double acc = 0;
+        for (int k = 0; k < per; k++) {
+            const int b = threadIdx.x * per + k;
+            if (b < nb) acc += g[b];
+        }
+        __syncthreads();
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double rank = sc->sel_rank[2 * col + slot];
+            double cum = 0;
+            int t = 0;
+            for (; t < 255; t++) {
+                if (cum + part[t] > rank) break;
+                cum += part[t];
+            }
+            int b = t * per;
+            for (; b < nb - 1 && b < (t + 1) * per - 1; b++) {
+                if (cum + g[b] > rank) break;
+                cum += g[b];
+            }
+            const uint64_t mine = (slot == 0) ? p0 : p1;
+            sc->sel_prefix[2 * col + slot] = mine | ((uint64_t)b << a.shift);
+            sc->sel_rank[2 * col + slot] = rank - cum;
+        }
+    }
+}
+
+__global__ void sel_finish_kernel(SelArgs a, FitWork w) {
+    const int c = threadIdx.x;
+    if (c >= a.ncol) return;
+    FitScalars *sc = w.sc;
+    const double lo = value_of(sc->sel_prefix[2 * c]), hi = value_of(sc->sel_prefix[2 * c + 1]);
+    const double med = (sc->sel_count[c] > 0) ? (lo + hi) / 2.0 : NAN;
+    sc->sel_value[2 * c] = lo;
+    sc->sel_value[2 * c + 1] = hi;
+    if (a.mode == SEL_RESID) {
+        sc->med = med;
+        sc->nres = sc->sel_count[c];
+    } else if (a.mode == SEL_ABSDEV) {
+        sc->mad = 1.4826 * med;
+    } else {
+        sc->sel_value[2 * c] = exp(med);  // size factor of column c
+    }
+}
+
+static int sel_blocks(int64_t n) {
+    int64_t b = (n + 256 * 8 - 1) / (256 * 8);
+    if (b < 1) b = 1;
+    if (b > 512) b = 512;
+    return (int)b;
+}
+void launch_sel_count(SelArgs a, FitWork w, hipStream_t st) {
+    const int nb = sel_blocks(a.n);
+    sel_count_kernel<<<dim3(nb, a.ncol), 256, 0, st>>>(a, w);
+    sel_count_finish_kernel<<<1, 64, 0, st>>>(w, nb, a.ncol);
+}
+void launch_sel_begin(SelArgs a, FitWork w, hipStream_t st) { sel_begin_kernel<<<1, 64, 0, st>>>(w, a.ncol); }
+void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st) {
+    const int bits = a.shift == 0 ? 4 : kSelBits;
+    (void)hipMemsetAsync(w.hist, 0, sizeof(double) * (size_t)a.ncol * 2 * kSelBins, st);
+    sel_hist_kernel<<<dim3(sel_blocks(a.n), a.ncol), 256, 0, st>>>(a, w, bits);
+}
+void launch_sel_step(SelArgs a, FitWork w, hipStream_t st) {
+    const int bits = a.shift == 0 ? 4 : kSelBits;
+    sel_step_kernel<<<a.ncol, 256, 0, st>>>(a, w, bits);
+}
+void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st) { sel_finish_kernel<<<1, 64, 0, st>>>(a, w); }
+
+// ------------------------------------------------------------------------------------------
+// a5 helper: row log geometric means, loggeomeans <- rowMeans(log(counts))
+__global__ __launch_bounds__(256) void row_lgm_kernel(const int32_t *__restrict__ counts, int64_t n, int S,
+                                                      double *__restrict__ lgm) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double s = 0;
+        for (int j = 0; j < S; j++) s += log((double)counts[(int64_t)j * n + i]);  // log(0) = -inf
+        lgm[i] = s / S;
+    }
+}
+void launch_row_lgm(const int32_t *counts, int64_t n, int S, double *lgm, hipStream_t st) {
+    row_lgm_kernel<<<kRedBlocks, 256, 0, st>>>(counts, n, S, lgm);
+}
+
+// a4: offsets.  One thread per row; the row's S values are re-read from L1/L2, so HBM sees
+// one read of FullMean and one write of the result.
+__global__ __launch_bounds__(256) void offsets_kernel(const double *__restrict__ fm, const double *__restrict__ sf,
+                                                      int64_t n, int S, double theta, int mix,
+                                                      double *__restrict__ out) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double sl = 0;
+        for (int j = 0; j < S; j++) sl += log(fm[(int64_t)j * n + i]);
+        const double gmean = exp(sl / S);
+        bool anyna = false;
+        for (int j = 0; j < S; j++) {
+            const double m3 = fm[(int64_t)j * n + i] / gmean;
+            anyna |= (m3 != m3);
+        }
+        double g2 = 1.0;
+        if (mix) {
+            double sl2 = 0;
+            for (int j = 0; j < S; j++) {
+                const double m3 = anyna ? sf[j] : fm[(int64_t)j * n + i] / gmean;
+                sl2 += log(m3 * (1 - theta) + sf[j] * theta);
+            }
+            g2 = exp(sl2 / S);
+        }
+        for (int j = 0; j < S; j++) {
+            double m3 = anyna ? sf[j] : fm[(int64_t)j * n + i] / gmean;
+            if (mix) m3 = (m3 * (1 - theta) + sf[j] * theta) / g2;
+            out[(int64_t)j * n + i] = m3;
+        }
+    }
+}
+void launch_offsets(const double *fm, const double *sf_dev, int64_t n, int S, double theta, int mix, double *out,
+                    hipStream_t st) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    offsets_kernel<<<(unsigned)blocks, 256, 0, st>>>(fm, sf_dev, n, S, theta, mix, out);
+}
+
+// a2: window sums, one thread per (region, sample)
+__global__ __launch_bounds__(256) void window_sums_kernel(const int32_t *__restrict__ fragN,
+                                                          const double *__restrict__ fragFM, int64_t nfrag, int S,
+                                                          const int64_t *__restrict__ rptr, int64_t n,
+                                                          int32_t *__restrict__ N, double *__restrict__ FM) {
+    const int j = blockIdx.y;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t lo = rptr[i], hi = rptr[i + 1];
+        if (fragN) {
+            int32_t s = 0;
+            for (int64_t f = lo; f < hi; f++) s += fragN[(int64_t)j * nfrag + f];
+            N[(int64_t)j * n + i] = s;
+        }
+        if (fragFM) {
+            double s = 0;
+            for (int64_t f = lo; f < hi; f++) s += fragFM[(int64_t)j * nfrag + f];
+            FM[(int64_t)j * n + i] = s;
+        }
+    }
+}
+void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfrag, int S, const int64_t *rptr,
+                        int64_t n, int32_t *N, double *FM, hipStream_t st) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    window_sums_kernel<<<dim3((unsigned)blocks, S), 256, 0, st>>>(fragN, fragFM, nfrag, S, rptr, n, N, FM);
+}
+
+// a1: count join by binary search in the sample's sorted key table
+__global__ __launch_bounds__(256) void count_join_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
+                                                         int64_t nru, const int64_t *__restrict__ keys,
+                                                         const int32_t *__restrict__ vals, int64_t nkeys,
+                                                         int32_t *__restrict__ out) {
+    for (int64_t r = blockIdx.x * 256 + threadIdx.x; r < nru; r += (int64_t)gridDim.x * 256) {
+        const int64_t key = ((int64_t)bait[r] << 32) | (uint32_t)oe[r];
+        int64_t lo = 0, hi = nkeys;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        out[r] = (lo < nkeys && keys[lo] == key) ? vals[lo] : 0;
+    }
+}
+void launch_count_join(const int32_t *bait, const int32_t *oe, int64_t nru, const int64_t *keys, const int32_t *vals,
+                       int64_t nkeys, int32_t *out, hipStream_t st) {
+    int64_t blocks = (nru + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    count_join_kernel<<<(unsigned)blocks, 256, 0, st>>>(bait, oe, nru, keys, vals, nkeys, out);
+}
+
+__global__ __launch_bounds__(256) void pvalue_kernel(const double *__restrict__ stat, int64_t n, double *__restrict__ p) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = pnorm_two_sided(stat[i]);
+}
+void launch_pvalues(const double *stat, int64_t n, double *p, hipStream_t st) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    pvalue_kernel<<<(unsigned)blocks, 256, 0, st>>>(stat, n, p);
+}
+
+}  // namespace cd

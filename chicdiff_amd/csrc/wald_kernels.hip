@@ -1,0 +1,402 @@
+// wald_kernels.hip — NB-GLM ridge IRLS, Wald statistics, deviance and Cook's distances.
+//
+// Replaces DESeq2's nbinomWaldTest -> fitNbinomGLMs (R) -> fitBeta (C++), reached from
+// chicdiff.R:1574, :1603, :1644, :1674.  For the two designs Chicdiff
+// builds (~condition with two levels; ~1) the (S+2)x2 QR solve of fitBeta's ridge-augmented
+// system collapses to a closed-form 2x2 solve (det(X'WX) = sum_A w * sum_B w), so there is no
+// dense contraction and no MFMA: three kernels,
+//   wald_prep   (row per thread) : beta start = LS of log(q+0.1); the mu-independent part of the
+//                                   NB log-likelihood, so the IRLS ticks need one log1p/sample;
+//   wald_irls   (row per lane + queue refill, as disp_fit_kernel) : IRLS ticks;
+//   wald_final  (row per thread) : sandwich SE, stat, p (Cody), deviance via the saddle-point
+//                                   dnbinom R uses, hat diagonals -> max Cook's distance.
+#include "common.h"
+#include "devmath.h"
+
+namespace cd {
+
+constexpr double kLog2e = 1.4426950408889634074;
+
+__global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restrict__ counts,
+                                                        const double *__restrict__ nf, FitDims d, FitWork w) {
+    const int64_t n = d.n;
+    const int S = d.S;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (w.allZero[i]) continue;
+        const double size = 1.0 / w.disp[i];
+        const double lg_size = lgamma_pos(size);
+        double lA = 0, lB = 0, c = 0;
+        for (int j = 0; j < S; j++) {
+            const double y = (double)counts[(int64_t)j * n + i];
+            const double l = log(y / nf[(int64_t)j * n + i] + 0.1);
+            if ((d.gmask >> j) & 1) lB += l; else lA += l;
+            if (y > 0) c += lgamma_pos(y + size) - lg_size - lgamma_pos(y + 1.0);
+        }
+        lA /= d.nA;
+        lB /= d.nB;
+        w.binit0[i] = lA;
+        w.binit1[i] = lB - lA;
+        w.crow[i] = c;
+    }
+}
+
+struct WaldArgs {
+    const int32_t *counts;
+    const double *nf;
+    FitDims d;
+    FitWork w;
+    Opts o;
+};
+
+// IRLS.  Tick k evaluates at beta_k: deviance(beta_k) for the convergence test and the
+// weighted sums that give beta_{k+1}.  DESeq2's loop index t equals k-1.
+__global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = A.d.S;
+    const int64_t n = A.d.n;
+    double *s_nf = smem + (size_t)wave * S * 96;
+    int *s_y = reinterpret_cast<int *>(s_nf + S * 64);
+    const uint64_t gmask = A.d.gmask;
+    const Opts o = A.o;
+    const double lambda = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
+    unsigned long long *queue = A.w.queue + 2;
+
+    bool need = true, done = false, queue_empty = false;
+    int64_t row = -1;
+    int k = 0;
+    double b0 = 0, b1 = 0, alpha = 0, size = 0, crow = 0, dev_old = 0, la = 0;
+
+    for (;;) {
+        for (int attempt = 0; attempt < 4; attempt++) {
+            const unsigned long long needmask = __ballot(need && !done);
+            if (!needmask) break;
+            if (queue_empty) {
+                if (need) done = true;
+                break;
+            }
+            const int cnt = __popcll(needmask);
+            const int leader = __ffsll((long long)needmask) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(queue, (unsigned long long)cnt);
+            base = __shfl(base, leader);
+            if (base + cnt >= (unsigned long long)n) queue_empty = true;
+            if (need && !done) {
+                const int rank = __popcll(needmask & ((1ull << lane) - 1ull));
+                const int64_t r = (int64_t)base + rank;
+                if (r >= n) {
+                    done = true;
+                } else if (A.w.allZero[r]) {
+                    A.w.beta0[r] = NAN;
+                    A.w.beta1[r] = NAN;
+                    A.w.betaIter[r] = 0;
+                } else {
+                    row = r;
+                    for (int j = 0; j < S; j++) {
+                        s_nf[j * 64 + lane] = A.nf[(int64_t)j * n + r];
+                        s_y[j * 64 + lane] = A.counts[(int64_t)j * n + r];
+                    }
+                    alpha = A.w.disp[r];
+                    size = 1.0 / alpha;
+                    la = log(alpha);
+                    crow = A.w.crow[r];
+                    b0 = A.w.binit0[r];
+                    b1 = A.w.binit1[r];
+                    k = 0;
+                    dev_old = 0;
+                    need = false;
+                }
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+        if (!need && !done) {  // lanes without a row sit this tick out; the wave as a whole goes on
+
+            const double E0 = exp(b0), E1 = exp(b0 + b1);
+            double wA = 0, wB = 0, zA = 0, zB = 0, D = 0;
+            for (int j = 0; j < S; j++) {
+                const double nfj = s_nf[j * 64 + lane];
+                const double y = (double)s_y[j * 64 + lane];
+                const bool g = (gmask >> j) & 1;
+                const double raw = nfj * (g ? E1 : E0);
+                const bool floored = raw < o.minmu;
+                const double mu = floored ? o.minmu : raw;
+                const double ma = alpha * mu;
+                const double rt = rcp(1.0 + ma);
+                const double wj = mu * rt;
+                const double eta = floored ? log(mu / nfj) : (g ? b0 + b1 : b0);
+                const double z = eta + (y - mu) / mu;
+                if (g) { wB += wj; zB += wj * z; } else { wA += wj; zA += wj * z; }
+                // -log dnbinom's mu-dependent part: (size+y) log1p(alpha mu) - y log(alpha mu)
+                double dj = (size + y) * log1p(ma);
+                if (y > 0) dj -= y * (la + log(mu));
+                D += dj;
+            }
+            bool stop = false;
+            int iter_out = k;
+            if (k >= 1) {
+                const double dev = 2.0 * (D - crow);
+                const double conv_test = fabs(dev - dev_old) / (fabs(dev) + 0.1);
+                if (conv_test != conv_test) {
+                    stop = true;
+                    iter_out = o.betaMaxit;
+                } else if (k >= 2 && conv_test < o.betaTol) {
+                    stop = true;
+                } else if (k >= o.betaMaxit) {
+                    stop = true;
+                }
+                dev_old = dev;
+            }
+            if (!stop) {
+                const double m00 = wA + wB + lambda, m01 = wB, m11 = wB + lambda;
+                const double r0 = zA + zB, r1 = zB;
+                const double det = m00 * m11 - m01 * m01;
+                b0 = (m11 * r0 - m01 * r1) / det;
+                b1 = (m00 * r1 - m01 * r0) / det;
+                k++;
+                if (fabs(b0) > 30.0 || fabs(b1) > 30.0) {
+                    stop = true;
+                    iter_out = o.betaMaxit;
+                }
+            }
+            if (stop) {
+                A.w.beta0[row] = b0;
+                A.w.beta1[row] = b1;
+                A.w.betaIter[row] = iter_out;
+                need = true;
+            }
+        }
+    }
+}
+
+// trimmed mean of v[0..n) dropping `lo` values at each end (R mean(x, trim)); destroys v
+__device__ __forceinline__ double trimmed_mean(double *v, int n, int lo) {
+    for (int t = 0; t < lo; t++) {
+        int imin = 0, imax = 0;
+        for (int k = 1; k < n; k++) {
+            if (v[k] < v[imin]) imin = k;
+            if (v[k] >= v[imax]) imax = k;
+        }
+        if (imin == imax) imax = (imin + 1) % n;
+        // remove the two (order of removal keeps indices valid)
+        const int a = imin > imax ? imin : imax, b = imin > imax ? imax : imin;
+        v[a] = v[n - 1];
+        v[b] = v[n - 2];
+        n -= 2;
+    }
+    double s = 0;
+    for (int k = 0; k < n; k++) s += v[k];
+    return s / n;
+}
+__device__ __forceinline__ int trim_lo(int n) {
+    // trimratio c(1/3, 1/4, 1/8) on bins (0,3.5], (3.5,23.5], (23.5,Inf)
+    const double tr = n <= 3 ? 1.0 / 3 : (n <= 23 ? 1.0 / 4 : 1.0 / 8);
+    return (int)floor(n * tr);
+}
+__device__ __forceinline__ double trim_scale(int n) { return n <= 3 ? 2.04 : (n <= 23 ? 1.86 : 1.51); }
+
+__global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restrict__ counts,
+                                                         const double *__restrict__ nf, FitDims d, FitWork w, Opts o,
+                                                         chicdiff_nbglm_out out) {
+    const int64_t n = d.n;
+    const int S = d.S;
+    const double lambda = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
+    double v[3] = {0, 0, 0};  // sum deviance, non-converged rows, all-zero rows
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const bool az = w.allZero[i];
+        double B0 = NAN, B1 = NAN, s0 = NAN, s1 = NAN, st = NAN, pv = NAN, dv = NAN, mc = NAN;
+        int bconv = 0, biter = 0;
+        if (!az) {
+            const double alpha = w.disp[i], size = 1.0 / alpha;
+            const double b0 = w.beta0[i], b1 = w.beta1[i];
+            biter = w.betaIter[i];
+            bconv = biter < o.betaMaxit;
+            const double E0 = exp(b0), E1 = exp(b0 + b1);
+            double wA = 0, wB = 0, ll = 0;
+            for (int j = 0; j < S; j++) {
+                const bool g = (d.gmask >> j) & 1;
+                const double y = (double)counts[(int64_t)j * n + i];
+                const double muf = nf[(int64_t)j * n + i] * (g ? E1 : E0);  // no floor for the likelihood
+                const double mu = fmax(muf, o.minmu);
+                const double wj = mu / (1.0 + alpha * mu);
+                if (g) wB += wj; else wA += wj;
+                ll += dnbinom_mu_log(y, size, muf);
+            }
+            const double m00 = wA + wB + lambda, m01 = wB, m11 = wB + lambda, det = m00 * m11 - m01 * m01;
+            const double i00 = m11 / det, i01 = -m01 / det, i11 = m00 / det;
+            const double a00 = wA + wB, a01 = wB, a11 = wB;
+            const double t00 = i00 * a00 + i01 * a01, t01 = i00 * a01 + i01 * a11;
+            const double t10 = i01 * a00 + i11 * a01, t11 = i01 * a01 + i11 * a11;
+            const double v0 = t00 * i00 + t01 * i01, v1 = t10 * i01 + t11 * i11;
+            B0 = kLog2e * b0;
+            B1 = kLog2e * b1;
+            s0 = kLog2e * sqrt(fmax(v0, 0.0));
+            s1 = kLog2e * sqrt(fmax(v1, 0.0));
+            st = B1 / s1;
+            pv = pnorm_two_sided(st);
+            dv = -2.0 * ll;
+            if (!bconv || !(v0 > 0) || !(v1 > 0)) v[1] += 1;
+            if (out.maxCooks && (d.nA >= 3 || d.nB >= 3)) {
+                // robustMethodOfMomentsDisp: max over cells (>=3 samples) of the scaled trimmed variance
+                double tmp[kMaxS];
+                double vmax = -INFINITY, m = 0;
+                for (int j = 0; j < S; j++) m += (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i];
+                m /= S;
+                for (int c = 0; c < 2; c++) {
+                    const int nc = c ? d.nB : d.nA;
+                    if (nc < 3) continue;
+                    int kk = 0;
+                    for (int j = 0; j < S; j++)
+                        if ((int)((d.gmask >> j) & 1) == c) tmp[kk++] = (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i];
+                    const double cm = trimmed_mean(tmp, nc, trim_lo(nc));
+                    kk = 0;
+                    for (int j = 0; j < S; j++)
+                        if ((int)((d.gmask >> j) & 1) == c) {
+                            const double dd = (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i] - cm;
+                            tmp[kk++] = dd * dd;
+                        }
+                    const double vv = trim_scale(nc) * trimmed_mean(tmp, nc, trim_lo(nc));
+                    if (vv > vmax) vmax = vv;
+                }
+                const double arob = fmax((vmax - m) / (m * m), 0.04);
+                mc = -INFINITY;
+                for (int j = 0; j < S; j++) {
+                    const bool g = (d.gmask >> j) & 1;
+                    if ((g ? d.nB : d.nA) < 3) continue;
+                    const double y = (double)counts[(int64_t)j * n + i];
+                    const double muf = nf[(int64_t)j * n + i] * (g ? E1 : E0);
+                    const double mu = fmax(muf, o.minmu);
+                    const double wj = mu / (1.0 + alpha * mu);
+                    const double h = wj * (g ? (i00 + 2 * i01 + i11) : i00);
+                    const double V = muf + arob * muf * muf;
+                    const double ck = (y - muf) * (y - muf) / V / 2.0 * h / ((1 - h) * (1 - h));
+                    if (ck > mc) mc = ck;
+                }
+            }
+            v[0] += dv;
+        } else {
+            v[2] += 1;
+        }
+        if (out.log2FoldChange) out.log2FoldChange[i] = B1;
+        if (out.lfcSE) out.lfcSE[i] = s1;
+        if (out.stat) out.stat[i] = st;
+        if (out.pvalue) out.pvalue[i] = pv;
+        if (out.intercept) out.intercept[i] = B0;
+        if (out.interceptSE) out.interceptSE[i] = s0;
+        if (out.deviance) out.deviance[i] = dv;
+        if (out.maxCooks) out.maxCooks[i] = mc;
+        if (out.betaConv) out.betaConv[i] = bconv;
+        if (out.betaIter) out.betaIter[i] = biter;
+    }
+    // block partials: 3 values
+    __shared__ double red[3][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < 3; k++) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (lane == 0) red[k][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        w.partials[(size_t)blockIdx.x * 3 + threadIdx.x] =
+            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// design ~1: fitNbinomGLMs' intercept-only shortcut (no IRLS)
+__global__ __launch_bounds__(256) void wald_intercept_kernel(const int32_t *__restrict__ counts,
+                                                             const double *__restrict__ nf, FitDims d, FitWork w,
+                                                             chicdiff_nbglm_out out) {
+    const int64_t n = d.n;
+    const int S = d.S;
+    double v[3] = {0, 0, 0};
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double B0 = NAN, s0 = NAN, st = NAN, pv = NAN, dv = NAN;
+        const bool az = w.allZero[i];
+        if (!az) {
+            const double alpha = w.disp[i], size = 1.0 / alpha;
+            double bm = 0;
+            for (int j = 0; j < S; j++) bm += (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i];
+            bm /= S;
+            B0 = log2(bm);
+            const double e = exp2(B0);
+            double ll = 0, xtwx = 0;
+            for (int j = 0; j < S; j++) {
+                const double mu = nf[(int64_t)j * n + i] * e;
+                ll += dnbinom_mu_log((double)counts[(int64_t)j * n + i], size, mu);
+                xtwx += 1.0 / (1.0 / mu + alpha);
+            }
+            s0 = kLog2e * sqrt(1.0 / xtwx);
+            st = B0 / s0;
+            pv = pnorm_two_sided(st);
+            dv = -2.0 * ll;
+            v[0] += dv;
+        } else {
+            v[2] += 1;
+        }
+        if (out.log2FoldChange) out.log2FoldChange[i] = NAN;
+        if (out.lfcSE) out.lfcSE[i] = NAN;
+        if (out.stat) out.stat[i] = st;
+        if (out.pvalue) out.pvalue[i] = pv;
+        if (out.intercept) out.intercept[i] = B0;
+        if (out.interceptSE) out.interceptSE[i] = s0;
+        if (out.deviance) out.deviance[i] = dv;
+        if (out.maxCooks) out.maxCooks[i] = NAN;
+        if (out.betaConv) out.betaConv[i] = az ? 0 : 1;
+        if (out.betaIter) out.betaIter[i] = az ? 0 : 1;
+    }
+    __shared__ double red[3][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < 3; k++) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (lane == 0) red[k][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        w.partials[(size_t)blockIdx.x * 3 + threadIdx.x] =
+            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// partials (kRedBlocks x 3) -> sums[0..3): deviance sum, non-converged rows, all-zero rows
+__global__ void dev_sum_kernel(FitWork w) {
+    __shared__ double red[256];
+    double *sums = w.partials + (size_t)kRedBlocks * 72;
+    for (int k = 0; k < 3; k++) {
+        double acc = 0;
+        for (int b = threadIdx.x; b < kRedBlocks; b += 256) acc += w.partials[(size_t)b * 3 + k];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sums[k] = red[0];
+        __syncthreads();
+    }
+}
+
+void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts, hipStream_t st) {
+    wald_prep_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
+}
+void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
+    WaldArgs A{counts, nf, d, w, o};
+    const size_t lds_per_wave = (size_t)d.S * 64 * 12;
+    int threads = 256;
+    while (threads > 64 && lds_per_wave * (threads / 64) > 40 * 1024) threads >>= 1;
+    const size_t lds = lds_per_wave * (threads / 64);
+    int64_t blocks = ((d.n + 63) / 64 + threads / 64 - 1) / (threads / 64);
+    const int64_t per_cu = (int64_t)(160 * 1024 / lds) < 8 ? (int64_t)(160 * 1024 / lds) : 8;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    if (blocks < 1) blocks = 1;
+    wald_irls_kernel<<<(unsigned)blocks, threads, lds, st>>>(A);
+}
+void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
+                       const chicdiff_nbglm_out &out, hipStream_t st) {
+    wald_final_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w, o, out);
+}
+void launch_wald_intercept(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts,
+                           const chicdiff_nbglm_out &out, hipStream_t st) {
+    wald_intercept_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w, out);
+}
+void launch_dev_sum_finish(FitDims, FitWork w, hipStream_t st) { dev_sum_kernel<<<1, 256, 0, st>>>(w); }
+
+}  // namespace cd

@@ -1,0 +1,285 @@
+"""ctypes binding of the C ABI in ``include/chicdiff_hip.h`` (``chicdiff_amd/lib/libchicdiff_hip.so``).
+
+This is the product path: there is NO CPU fallback.  If the shared library has not been
+built, or no MI355X is visible, construction raises — it never routes to ``oracle/``.
+PyTorch is used only as plumbing: device buffers (``torch.Tensor``), the current HIP stream,
+and ``torch.distributed`` for the sum-all-reduce hook.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libchicdiff_hip.so")
+
+ST_TREND_FAILED, ST_PRIORVAR_MC, ST_BETA_NONCONV, ST_ALLZERO_ROWS = 1, 2, 4, 8
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
+# every symbol include/chicdiff_hip.h declares (tests check the library exports each)
+EXPORTS = [
+    "chicdiff_hip_create", "chicdiff_hip_destroy", "chicdiff_hip_last_error", "chicdiff_hip_set_stream",
+    "chicdiff_hip_set_allreduce", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
+    "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
+    "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_theta_grid_dev",
+    "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
+]
+
+
+class Opts(C.Structure):
+    _fields_ = [("minDisp", C.c_double), ("dispTol", C.c_double), ("kappa0", C.c_double),
+                ("maxit", C.c_int32), ("betaMaxit", C.c_int32), ("betaTol", C.c_double),
+                ("minmu", C.c_double), ("outlierSD", C.c_double), ("dispPriorVar", C.c_double)]
+
+
+OUT_DOUBLE = ["baseMean", "baseVar", "dispGeneEst", "dispFit", "dispMAP", "dispersion", "log2FoldChange",
+              "lfcSE", "stat", "pvalue", "intercept", "interceptSE", "deviance", "maxCooks"]
+OUT_INT = ["dispGeneIter", "dispIter", "dispOutlier", "betaConv", "betaIter", "allZero"]
+
+
+class Out(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in OUT_DOUBLE + OUT_INT]
+
+
+class Scalars(C.Structure):
+    _fields_ = [("trendCoef", C.c_double * 2), ("varLogDispEsts", C.c_double), ("dispPriorVar", C.c_double),
+                ("sumDeviance", C.c_double), ("nAllZero", C.c_int64), ("trendOuterIter", C.c_int32),
+                ("status", C.c_int32)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_int32)]
+
+
+class ChicdiffHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load the HIP library; raise (never fall back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ChicdiffHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    L.chicdiff_hip_create.argtypes = [C.POINTER(vp), i32]
+    L.chicdiff_hip_destroy.argtypes = [vp]
+    L.chicdiff_hip_destroy.restype = None
+    L.chicdiff_hip_last_error.argtypes = [vp]
+    L.chicdiff_hip_last_error.restype = C.c_char_p
+    L.chicdiff_hip_set_stream.argtypes = [vp, vp]
+    L.chicdiff_hip_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32, i32]
+    L.chicdiff_hip_default_opts.argtypes = [C.POINTER(Opts)]
+    L.chicdiff_hip_default_opts.restype = None
+    L.chicdiff_hip_size_factors_dev.argtypes = [vp, vp, i64, i32, C.POINTER(dbl)]
+    L.chicdiff_hip_offsets_dev.argtypes = [vp, vp, C.POINTER(dbl), i64, i32, dbl, vp]
+    L.chicdiff_hip_window_sums_dev.argtypes = [vp, vp, vp, i64, i32, vp, i64, vp, vp]
+    L.chicdiff_hip_count_join_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp]
+    L.chicdiff_hip_nbglm_fit_dev.argtypes = [vp, vp, vp, i64, i32, C.POINTER(i32), C.POINTER(Opts), C.POINTER(Out),
+                                             C.POINTER(Scalars)]
+    L.chicdiff_hip_nbglm_fit.argtypes = L.chicdiff_hip_nbglm_fit_dev.argtypes
+    L.chicdiff_hip_theta_grid_dev.argtypes = [vp, vp, vp, C.POINTER(dbl), i64, i32, C.POINTER(dbl), i32,
+                                              C.POINTER(Opts), C.POINTER(dbl)]
+    L.chicdiff_hip_wald_pvalues_dev.argtypes = [vp, vp, i64, vp]
+    L.chicdiff_hip_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
+    L.chicdiff_hip_kernel_times.restype = i32
+    L.chicdiff_hip_enable_timing.argtypes = [vp, i32]
+    _lib = L
+    return L
+
+
+def default_opts(**kw) -> Opts:
+    o = Opts()
+    load_library().chicdiff_hip_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _scalars_dict(s: Scalars) -> dict:
+    return dict(trendCoef=np.array(s.trendCoef[:]), varLogDispEsts=s.varLogDispEsts, dispPriorVar=s.dispPriorVar,
+                sumDeviance=s.sumDeviance, nAllZero=s.nAllZero, trendOuterIter=s.trendOuterIter, status=s.status)
+
+
+class HipContext:
+    """One context per process/GPU.  Device buffers are torch tensors on ``cuda:<device>``
+    (torch's name for a ROCm device), laid out sample-major: a tensor of shape (S, n),
+    contiguous, is the C ABI's column-major n x S matrix."""
+
+    def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        import torch
+
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise ChicdiffHipError("no MI355X visible to PyTorch-ROCm: the HIP path cannot run (there is no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        rc = self.lib.chicdiff_hip_create(C.byref(h), device)
+        if rc:
+            raise ChicdiffHipError(self.lib.chicdiff_hip_last_error(None).decode())
+        self.h = h
+        self._cb = None
+        self._comm_tensors = {}
+        if use_torch_stream:
+            self.use_stream(torch.cuda.current_stream(self.device))
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.chicdiff_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise ChicdiffHipError(f"[{rc}] " + self.lib.chicdiff_hip_last_error(self.h).decode())
+
+    def use_stream(self, stream):
+        self._check(self.lib.chicdiff_hip_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def enable_timing(self, on=True):
+        self.lib.chicdiff_hip_enable_timing(self.h, int(on))
+
+    def kernel_times(self) -> dict:
+        buf = (KernelTime * 32)()
+        k = self.lib.chicdiff_hip_kernel_times(self.h, buf, 32)
+        return {buf[i].name.decode(): (buf[i].ms, buf[i].launches) for i in range(min(k, 32))}
+
+    def set_process_group(self, group=None):
+        """Route the library's sum-all-reduces through torch.distributed (backend nccl = RCCL)."""
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        torch = self.torch
+
+        class _Raw:  # expose a raw device pointer to torch through __cuda_array_interface__
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        def cb(_user, dev_ptr, count):
+            try:
+                t = torch.as_tensor(_Raw(int(dev_ptr), int(count)), device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                self._cb_error = e
+                return 1
+
+        self._cb = ALLREDUCE_FN(cb)
+        self._check(self.lib.chicdiff_hip_set_allreduce(self.h, self._cb, None, world, rank))
+
+    def to_device(self, a, dtype):
+        """(n, S) host array -> (S, n) contiguous device tensor (sample-major)."""
+        t = self.torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=dtype).T))
+        return t.to(self.device)
+
+    # -- a5 ---------------------------------------------------------------------------------
+    def size_factors(self, d_counts) -> np.ndarray:
+        S, n = d_counts.shape
+        sf = (C.c_double * S)()
+        self._check(self.lib.chicdiff_hip_size_factors_dev(self.h, d_counts.data_ptr(), n, S, sf))
+        return np.array(sf[:])
+
+    # -- a4 ---------------------------------------------------------------------------------
+    def offsets(self, d_fullmean, size_factors, theta=None, out=None):
+        S, n = d_fullmean.shape
+        sf = (C.c_double * S)(*[float(x) for x in size_factors])
+        if out is None:
+            out = self.torch.empty_like(d_fullmean)
+        th = float("nan") if theta is None else float(theta)
+        self._check(self.lib.chicdiff_hip_offsets_dev(self.h, d_fullmean.data_ptr(), sf, n, S, th, out.data_ptr()))
+        return out
+
+    # -- a2 ---------------------------------------------------------------------------------
+    def window_sums(self, d_fragN, d_fragFM, d_region_ptr):
+        torch = self.torch
+        ref = d_fragN if d_fragN is not None else d_fragFM
+        S, nfrag = ref.shape
+        n = d_region_ptr.numel() - 1
+        N = torch.empty((S, n), dtype=torch.int32, device=self.device) if d_fragN is not None else None
+        FM = torch.empty((S, n), dtype=torch.float64, device=self.device) if d_fragFM is not None else None
+        self._check(self.lib.chicdiff_hip_window_sums_dev(
+            self.h, d_fragN.data_ptr() if d_fragN is not None else None,
+            d_fragFM.data_ptr() if d_fragFM is not None else None, nfrag, S, d_region_ptr.data_ptr(), n,
+            N.data_ptr() if N is not None else None, FM.data_ptr() if FM is not None else None))
+        return N, FM
+
+    # -- a1 ---------------------------------------------------------------------------------
+    def count_join(self, d_bait, d_oe, d_keys, d_vals):
+        out = self.torch.empty_like(d_bait)
+        self._check(self.lib.chicdiff_hip_count_join_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), d_bait.numel(),
+                                                         d_keys.data_ptr(), d_vals.data_ptr(), d_keys.numel(),
+                                                         out.data_ptr()))
+        return out
+
+    # -- a6 + a7 ----------------------------------------------------------------------------
+    def nbglm_fit(self, d_counts, d_nf, group, want=None, opts: Opts | None = None, outputs: dict | None = None):
+        """estimateDispersions + nbinomWaldTest on device-resident (S, n) tensors.
+
+        Returns (outputs, scalars): ``outputs`` maps the requested column names to device
+        tensors of length n (pass ``outputs`` to reuse buffers)."""
+        torch = self.torch
+        S, n = d_counts.shape
+        assert d_nf.shape == (S, n) and d_counts.dtype == torch.int32 and d_nf.dtype == torch.float64
+        assert d_counts.is_contiguous() and d_nf.is_contiguous()
+        want = list(want) if want is not None else ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue"]
+        out = Out()
+        bufs = outputs if outputs is not None else {}
+        for k in want:
+            if k not in bufs:
+                bufs[k] = torch.empty(n, dtype=torch.float64 if k in OUT_DOUBLE else torch.int32, device=self.device)
+            setattr(out, k, bufs[k].data_ptr())
+        g = (C.c_int32 * S)(*[int(x) for x in group])
+        sc = Scalars()
+        self._check(self.lib.chicdiff_hip_nbglm_fit_dev(self.h, d_counts.data_ptr(), d_nf.data_ptr(), n, S, g,
+                                                        C.byref(opts) if opts is not None else None, C.byref(out),
+                                                        C.byref(sc)))
+        return bufs, _scalars_dict(sc)
+
+    def nbglm_fit_host(self, counts, nf, group, want=None, opts: Opts | None = None):
+        """Host-buffer entry point (what the R .Call shim uses): numpy (n, S) in, numpy out."""
+        k = np.asfortranarray(np.asarray(counts, dtype=np.int32))
+        f = np.asfortranarray(np.asarray(nf, dtype=np.float64))
+        n, S = k.shape
+        want = list(want) if want is not None else OUT_DOUBLE + OUT_INT
+        out = Out()
+        res = {}
+        for name in want:
+            res[name] = np.empty(n, dtype=np.float64 if name in OUT_DOUBLE else np.int32)
+            setattr(out, name, res[name].ctypes.data)
+        g = (C.c_int32 * S)(*[int(x) for x in group])
+        sc = Scalars()
+        self._check(self.lib.chicdiff_hip_nbglm_fit(self.h, k.ctypes.data, f.ctypes.data, n, S, g,
+                                                    C.byref(opts) if opts is not None else None, C.byref(out), C.byref(sc)))
+        return res, _scalars_dict(sc)
+
+    # -- a8 ---------------------------------------------------------------------------------
+    def theta_grid(self, d_counts, d_fullmean, size_factors, thetas, opts: Opts | None = None) -> np.ndarray:
+        S, n = d_counts.shape
+        sf = (C.c_double * S)(*[float(x) for x in size_factors])
+        th = (C.c_double * len(thetas))(*[float(x) for x in thetas])
+        dev = (C.c_double * len(thetas))()
+        self._check(self.lib.chicdiff_hip_theta_grid_dev(self.h, d_counts.data_ptr(), d_fullmean.data_ptr(), sf, n, S, th,
+                                                         len(thetas), C.byref(opts) if opts is not None else None, dev))
+        return np.array(dev[:])
+
+    def wald_pvalues(self, d_stat):
+        out = self.torch.empty_like(d_stat)
+        self._check(self.lib.chicdiff_hip_wald_pvalues_dev(self.h, d_stat.data_ptr(), d_stat.numel(), out.data_ptr()))
+        return out

@@ -1,0 +1,163 @@
+/*
+ * chicdiff_hip.h — C ABI of the MI355X-native differential-testing core of Chicdiff.
+ *
+ * The reference (pure R, /root/reference/Chicdiff/R/chicdiff.R) has no FFI: the seam it
+ * offers is the exported R function DESeq2Wrap() (chicdiff.R:1494) and, below it, the DESeq2
+ * calls at chicdiff.R:1557-1674.  Each entry point here replaces one of those call groups and
+ * is what an R `.Call` shim (r/src/chicdiff_hip_shim.c) binds.  No R, no
+ * torch, no C++ types cross this boundary: plain pointers, sizes and a status code.
+ *
+ * Conventions
+ *   - matrices are n x S column-major (= sample-major; element (i, j) at [j*n + i]): exactly
+ *     R's INTEGER(mat)/REAL(mat) for the matrices built at chicdiff.R:1551-1553 and :1583,
+ *     and the coalesced layout for one-row-per-lane kernels.
+ *   - `_dev` entry points take DEVICE pointers (HBM-resident inputs/outputs, the benchmarked
+ *     form); the others take caller-owned HOST buffers and stage them (what R passes).
+ *   - every function returns 0 on success, a CHICDIFF_E_* code otherwise;
+ *     chicdiff_hip_last_error() gives the message.  Nothing throws, aborts or calls exit.
+ *   - NA: counts must not be NA_integer_ (INT_MIN) -> CHICDIFF_E_INVALID; NaN/NA_real_ in
+ *     FullMean is meaningful (row falls back to size factors, chicdiff.R:1588-1589).
+ *   - threading: call from one host thread per context; work is enqueued on the context's
+ *     stream (chicdiff_hip_set_stream) and the call returns after the results are complete.
+ */
+#ifndef CHICDIFF_HIP_H
+#define CHICDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHICDIFF_OK 0
+#define CHICDIFF_E_INVALID 1   /* bad argument (shape, NA count, unsupported design)          */
+#define CHICDIFF_E_HIP 2       /* HIP runtime error (message has hipGetErrorString)           */
+#define CHICDIFF_E_NOMEM 3
+#define CHICDIFF_E_COMM 4      /* all-reduce callback failed                                  */
+#define CHICDIFF_E_NUMERIC 5   /* e.g. every row has a zero (size factors undefined)          */
+
+/* status bits reported in chicdiff_nbglm_scalars.status (fit completed, with caveats) */
+#define CHICDIFF_ST_TREND_FAILED 1 /* parametric trend failed; DESeq2 would switch to locfit   */
+#define CHICDIFF_ST_PRIORVAR_MC 2  /* m-p<=3 and no dispPriorVar given: closed form used        */
+#define CHICDIFF_ST_BETA_NONCONV 4 /* some rows hit betaMaxit (DESeq2 would call optim)        */
+#define CHICDIFF_ST_ALLZERO_ROWS 8 /* some rows are all zero: their outputs are NaN (R: NA)    */
+
+typedef struct chicdiff_hip_ctx chicdiff_hip_ctx;
+
+/* Sum-all-reduce `count` doubles at DEVICE pointer `dev_buf`, in place, ordered on the
+ * context's stream, across the ranks sharing the fit.  Return 0 on success.  Replaces nothing
+ * in the reference (single process); it is the hook for row sharding. */
+typedef int (*chicdiff_allreduce_fn)(void *user, void *dev_buf, int64_t count);
+
+int chicdiff_hip_create(chicdiff_hip_ctx **ctx, int32_t device);
+void chicdiff_hip_destroy(chicdiff_hip_ctx *ctx);
+const char *chicdiff_hip_last_error(const chicdiff_hip_ctx *ctx); /* ctx may be NULL: last create() error */
+/* hipStream_t to enqueue on (NULL = HIP's null stream).  Until this is called the context
+ * uses a private non-blocking stream. */
+int chicdiff_hip_set_stream(chicdiff_hip_ctx *ctx, void *hip_stream);
+/* world_size > 1 turns every global statistic (size-factor medians, nf column means, trend
+ * sums, MAD medians, deviance sums) into local partials + one callback. */
+int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, void *user,
+                               int32_t world_size, int32_t rank);
+
+/* DESeq2 defaults that Chicdiff never overrides (chicdiff.R:1573-1574 pass no arguments). */
+typedef struct {
+    double minDisp;      /* 1e-8 */
+    double dispTol;      /* 1e-6 */
+    double kappa0;       /* 1.0  */
+    int32_t maxit;       /* 100  dispersion line search */
+    int32_t betaMaxit;   /* 100  Wald IRLS              */
+    double betaTol;      /* 1e-8 */
+    double minmu;        /* 0.5  */
+    double outlierSD;    /* 2.0  */
+    double dispPriorVar; /* NaN = estimate; DESeq2's estimateDispersionsMAP(dispPriorVar=) */
+} chicdiff_nbglm_opts;
+void chicdiff_hip_default_opts(chicdiff_nbglm_opts *opts);
+
+/* Per-row outputs, length n each; any pointer may be NULL (not wanted).  Host or device
+ * pointers according to the entry point used. */
+typedef struct {
+    double *baseMean;       /* mcols(dds)$baseMean                                   */
+    double *baseVar;
+    double *dispGeneEst;    /* mcols(dds)$dispGeneEst                                */
+    double *dispFit;        /* mcols(dds)$dispFit                                    */
+    double *dispMAP;
+    double *dispersion;     /* dispersions(dds)                                      */
+    double *log2FoldChange; /* results(dds)$log2FoldChange (NaN for design ~1)       */
+    double *lfcSE;
+    double *stat;
+    double *pvalue;         /* before Cook's cutoff / independent filtering          */
+    double *intercept;      /* log2 scale                                            */
+    double *interceptSE;
+    double *deviance;       /* mcols(dds)$deviance = -2 logLik                       */
+    double *maxCooks;       /* NaN unless a group has >= 3 samples                   */
+    int32_t *dispGeneIter, *dispIter, *dispOutlier, *betaConv, *betaIter, *allZero;
+} chicdiff_nbglm_out;
+
+typedef struct {
+    double trendCoef[2];    /* asymptDisp, extraPois: attr(dispersionFunction, "coefficients") */
+    double varLogDispEsts;
+    double dispPriorVar;
+    double sumDeviance;     /* sum(mcols(dds)$deviance) as chicdiff.R:1647 (NaN if any all-zero row) */
+    int64_t nAllZero;
+    int32_t trendOuterIter;
+    int32_t status;         /* CHICDIFF_ST_* bits */
+} chicdiff_nbglm_scalars;
+
+/* a5 — estimateSizeFactors (chicdiff.R:1561-1562): median-of-ratios, S doubles to HOST sf. */
+int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts, int64_t n, int32_t S,
+                                  double *sf_host);
+
+/* a4 — offsets (chicdiff.R:1583-1589 M3; :1614-1615 nsf; :1635-1638 / :1666-1669 theta mix).
+ * theta = NaN returns normFactorsM3 (norm="fullmean"); otherwise sc(theta). */
+int chicdiff_hip_offsets_dev(chicdiff_hip_ctx *ctx, const double *d_fullMean, const double *sf_host,
+                             int64_t n, int32_t S, double theta, double *d_nf_out);
+
+/* a2 — window sums (chicdiff.R:1540-1556).  Fragments of region i are rows
+ * [region_ptr[i], region_ptr[i+1]) of the nfrag x S fragment matrices (ascending otherEndID,
+ * the order setkey(fragData, otherEndID) at :1526 produces).  Either input may be NULL. */
+int chicdiff_hip_window_sums_dev(chicdiff_hip_ctx *ctx, const int32_t *d_fragN, const double *d_fragFullMean,
+                                 int64_t nfrag, int32_t S, const int64_t *d_region_ptr, int64_t n,
+                                 int32_t *d_N, double *d_FullMean);
+
+/* a1 — count join (chicdiff.R:843-858): out[r] = N of (bait[r], oe[r]) in the sample's sorted
+ * key table (key = baitID<<32 | otherEndID, ascending, unique), 0 when absent. */
+int chicdiff_hip_count_join_dev(chicdiff_hip_ctx *ctx, const int32_t *d_ru_bait, const int32_t *d_ru_oe,
+                                int64_t nru, const int64_t *d_keys, const int32_t *d_vals, int64_t nkeys,
+                                int32_t *d_out);
+
+/* a6 + a7 — estimateDispersions + nbinomWaldTest (chicdiff.R:1573-1574, 1602-1603, 1643-1644,
+ * 1673-1674) for design ~condition (group[j] in {0,1}, both present) or ~1 (all group[j]==0).
+ * d_nf = normalizationFactors (n x S).  `group` is a HOST array of S ints. */
+int chicdiff_hip_nbglm_fit_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts, const double *d_nf, int64_t n,
+                               int32_t S, const int32_t *group, const chicdiff_nbglm_opts *opts,
+                               const chicdiff_nbglm_out *d_out, chicdiff_nbglm_scalars *scalars);
+
+/* Same, HOST buffers in and out (what the R .Call shim passes: INTEGER(counts), REAL(nf)). */
+int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *ctx, const int32_t *counts, const double *nf, int64_t n, int32_t S,
+                           const int32_t *group, const chicdiff_nbglm_opts *opts, const chicdiff_nbglm_out *out,
+                           chicdiff_nbglm_scalars *scalars);
+
+/* a8 — theta grid (chicdiff.R:1619-1662): for each theta, sc(theta) -> design ~1 fit ->
+ * deviances[t] = sum(deviance).  d_fullMean n x S, sf_host the null size factors. */
+int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts, const double *d_fullMean,
+                                const double *sf_host, int64_t n, int32_t S, const double *thetas,
+                                int32_t ntheta, const chicdiff_nbglm_opts *opts, double *deviances_host);
+
+/* Wald p-values alone: p[i] = 2*pnorm(-|stat[i]|) (Cody's algorithm, the one R's pnorm uses). */
+int chicdiff_hip_wald_pvalues_dev(chicdiff_hip_ctx *ctx, const double *d_stat, int64_t n, double *d_p);
+
+/* Timing of the last *_dev call's kernels, measured with HIP events on the context's stream:
+ * fills up to `cap` (name, milliseconds, launches) records; returns the number available. */
+typedef struct {
+    const char *name;
+    double ms;
+    int32_t launches;
+} chicdiff_kernel_time;
+int32_t chicdiff_hip_kernel_times(chicdiff_hip_ctx *ctx, chicdiff_kernel_time *out, int32_t cap);
+int chicdiff_hip_enable_timing(chicdiff_hip_ctx *ctx, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
