@@ -15,6 +15,8 @@
 //   * iteration counts are heavy-tailed (median ~7, 1.7 % of rows run 100 + 40 grid points),
 //     so a finished lane immediately pulls the next row from a global queue (one atomic per
 //     wave per refill) instead of idling until its 63 neighbours finish.
+#include <stdlib.h>
+
 #include "common.h"
 #include "devmath.h"
 
@@ -98,6 +100,7 @@ void launch_prep_finish(FitDims d, FitWork w, hipStream_t st) { colsum_finish_ke
 void launch_xim(FitDims d, FitWork w, hipStream_t st) { xim_kernel<<<1, 64, 0, st>>>(d, w); }
 
 // ------------------------------------------------------------------------------------------
+constexpr int kChunk = 256;  // rows a wave takes from the global queue per atomic
 enum Phase : int { PH_NEED = 0, PH_INIT = 1, PH_SEARCH = 2, PH_GRID1 = 3, PH_GRID2 = 4, PH_DONE = 5 };
 
 struct DispArgs {
@@ -109,40 +112,83 @@ struct DispArgs {
 };
 
 // log posterior of a = log(alpha) and its derivative for one row held in LDS (A2.6).
-// mu_j = max(nf_j * groupmean_g, minmu) is rebuilt on the fly; log(mu + 1/alpha) is folded
-// into log(1 + mu*alpha) - a so each sample costs one log besides the lgamma/digamma pair.
-__device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, int lane, int S, uint64_t gmask,
+//
+// With r = 1/alpha, the per-sample terms of DESeq2's log_posterior / dlog_posterior are
+//   lgamma(y+r) - lgamma(r) - y log(mu+r) - r log(1+mu alpha)            (value)
+//   digamma(r) - digamma(y+r) + log(1+mu alpha) - mu alpha/(1+mu alpha) + y/(mu+r)   (derivative)
+// and are evaluated here as
+//   * log(mu+r) = log(1+mu alpha) - a, so one log L covers both logs;
+//   * y is an integer count: lgamma(y+r)-lgamma(r) = log prod_{i<n}(r+i) + [lgS(y+r)-lgS(r+n)]
+//     with n = min(y, nr), nr = the number of unit steps that lift r to >= 10 (per row and tick),
+//     lgS = Stirling's series (valid as both arguments are >= 10); likewise for digamma with the
+//     derivative of the product.  Samples with y <= nr need no Stirling term, samples on rows
+//     with alpha <= 0.1 need no product;
+//     The nr+1 prefix products and harmonic sums are tabulated once per row and tick in LDS;
+//   * the products of all samples are multiplied up (mantissa/exponent) and logged ONCE per row.
+// mu_j = max(nf_j * groupmean_g, minmu) is rebuilt on the fly from LDS.
+__device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int S, uint64_t gmask,
                                            bool p2, double gm0, double gm1, double minmu, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
                                            double &lp, double &dlp) {
     const double alpha = exp(a);
-    const double r = 1.0 / alpha;
-    double lg_r, dg_r;
-    lgamma_digamma(r, lg_r, dg_r);
+    const double r = rcp(alpha);
+    // lift r to r0 = r + nr >= 10
+    const int nr = r < 10.0 ? (int)ceil(10.0 - r) : 0;
+    const double r0 = r + (double)nr;
+    double lgS0, dgS0;
+    stirling(r0, flog(r0), rcp(r0), lgS0, dgS0);
+    // per-tick table (LDS, [entry][lane]): P_n = prod_{i<n}(r+i) and H_n = sum_{i<n} 1/(r+i), n = 0..nr
+    {
+        double P = 1.0, H = 0.0, zz = r;
+        s_tab[lane] = 1.0;
+        s_tab[11 * 64 + lane] = 0.0;
+        for (int i = 1; i <= nr; i++) {
+            P *= zz;
+            H += rcp(zz);
+            zz += 1.0;
+            s_tab[i * 64 + lane] = P;
+            s_tab[(11 + i) * 64 + lane] = H;
+        }
+    }
     double ll = 0, sd = 0, wA = 0, wB = 0, dA = 0, dB = 0;
+    double pm = 1.0;  // running product of the samples' shift products (mantissas)
+    int pe = 0;       // ... and of their binary exponents
     for (int j = 0; j < S; j++) {
         const double nfj = s_nf[j * 64 + lane];
-        const double y = (double)s_y[j * 64 + lane];
+        const int yi = s_y[j * 64 + lane];
+        const double y = (double)yi;
         const bool g = (gmask >> j) & 1;
         const double mu = fmax(nfj * (g ? gm1 : gm0), minmu);
         const double ma = mu * alpha;
         const double t = 1.0 + ma;
         const double rt = rcp(t);
-        const double L = log(t);
+        const double L = flog1p_from(ma, t, rt);
         const double wj = mu * rt;  // 1 / (1/mu + alpha)
         if (g) { wB += wj; dB -= wj * wj; } else { wA += wj; dA -= wj * wj; }
-        double lg, dg;
-        lgamma_digamma(y + r, lg, dg);
-        ll += (lg - lg_r) - y * (L - a) - r * L;
-        sd += (dg_r - dg) + L - ma * rt + y * alpha * rt;
+        // lgamma(y+r) - lgamma(r), digamma(y+r) - digamma(r)
+        const int n = yi < nr ? yi : nr;
+        const double P = s_tab[n * 64 + lane];
+        double dlg = 0.0, ddg = s_tab[(11 + n) * 64 + lane];
+        pe += __builtin_amdgcn_frexp_exp(P);
+        pm *= __builtin_amdgcn_frexp_mant(P);
+        if (yi > nr) {
+            const double z = y + r;
+            double lgz, dgz;
+            stirling(z, flog(z), rcp(z), lgz, dgz);
+            dlg = lgz - lgS0;
+            ddg += dgz - dgS0;
+        }
+        ll += dlg - y * (L - a) - r * L;
+        sd += L - ddg - ma * rt + y * alpha * rt;
     }
+    ll += fma((double)pe, 0.69314718055994530942, flog(pm));
     double cr, dcr;
     if (p2) {
-        cr = -0.5 * log(wA * wB);
-        dcr = -0.5 * (dA / wA + dB / wB);
+        cr = -0.5 * flog(wA * wB);
+        dcr = -0.5 * (dA * rcp(wA) + dB * rcp(wB));
     } else {
-        cr = -0.5 * log(wA);
-        dcr = -0.5 * (dA / wA);
+        cr = -0.5 * flog(wA);
+        dcr = -0.5 * (dA * rcp(wA));
     }
     double pr = 0, dpr = 0;
     if (use_prior) {
@@ -154,13 +200,15 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, i
     dlp = (r * r * sd + dcr) * alpha + dpr;
 }
 
-template <bool MAP>
-__global__ __launch_bounds__(256) void disp_fit_kernel(DispArgs A) {
+template <bool MAP, int MINW>
+__global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = A.d.S;
     const int64_t n = A.d.n;
-    double *s_nf = smem + (size_t)wave * S * 96;  // per wave: S*64 doubles + S*64 ints = S*96 doubles' worth
+    // per wave: 22*64 doubles (prefix table) + S*64 doubles (nf) + S*64 ints (counts)
+    double *s_tab = smem + (size_t)wave * (22 * 64 + S * 96);
+    double *s_nf = s_tab + 22 * 64;
     int *s_y = reinterpret_cast<int *>(s_nf + S * 64);
     const uint64_t gmask = A.d.gmask;
     const bool p2 = A.d.p == 2;
@@ -184,27 +232,40 @@ __global__ __launch_bounds__(256) void disp_fit_kernel(DispArgs A) {
     double a = 0, lp = 0, dlp = 0, kappa = 0, init_lp = 0, a0 = 0, gm0 = 0, gm1 = 0, prior_mean = 0;
     double gbest = 0, ghat = 0, dgene = 0, a_new = 0;
     bool queue_empty = false;
+    unsigned long long chunk_next = 0, chunk_end = 0;
 
     for (;;) {
         // ---- refill: lanes without a row pull the next ones from the queue -----------------
         for (int attempt = 0; attempt < 4; attempt++) {
             const unsigned long long needmask = __ballot(phase == PH_NEED);
             if (!needmask) break;
-            if (queue_empty) {
-                if (phase == PH_NEED) phase = PH_DONE;
-                break;
+            // rows come from a wave-private chunk: one atomic on the global head per kChunk rows
+            // (a single hot word saturates near 90 dequeues/us, which one atomic per tick per wave hit)
+            if (chunk_next >= chunk_end) {
+                if (queue_empty) {
+                    if (phase == PH_NEED) phase = PH_DONE;
+                    break;
+                }
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(queue, (unsigned long long)kChunk);
+                b = __shfl(b, 0);
+                if (b >= (unsigned long long)n) {
+                    queue_empty = true;
+                    continue;
+                }
+                chunk_next = b;
+                chunk_end = b + kChunk < (unsigned long long)n ? b + kChunk : (unsigned long long)n;
             }
             const int cnt = __popcll(needmask);
-            const int leader = __ffsll((long long)needmask) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(queue, (unsigned long long)cnt);
-            base = __shfl(base, leader);
-            if (base + cnt >= (unsigned long long)n) queue_empty = true;
+            const unsigned long long base = chunk_next;
+            const unsigned long long avail = chunk_end - chunk_next;
+            const int take = (unsigned long long)cnt < avail ? cnt : (int)avail;
+            chunk_next += (unsigned long long)take;
             if (phase == PH_NEED) {
                 const int rank = __popcll(needmask & ((1ull << lane) - 1ull));
                 const int64_t r = (int64_t)base + rank;
-                if (r >= n) {
-                    phase = PH_DONE;
+                if (rank >= take) {
+                    // chunk ran out: stay in PH_NEED, the next attempt opens a new chunk
                 } else if (A.w.allZero[r]) {
                     if (!MAP) {
                         A.w.dispGene[r] = NAN;
@@ -260,7 +321,7 @@ __global__ __launch_bounds__(256) void disp_fit_kernel(DispArgs A) {
         // ---- evaluate -------------------------------------------------------------------------
         double l_new = 0, dl_new = 0;
         if (phase != PH_DONE && phase != PH_NEED)
-            eval_point(s_nf, s_y, lane, S, gmask, p2, gm0, gm1, o.minmu, a_eval, MAP, prior_mean, prior_isig, l_new,
+            eval_point(s_nf, s_y, s_tab, lane, S, gmask, p2, gm0, gm1, o.minmu, a_eval, MAP, prior_mean, prior_isig, l_new,
                        dl_new);
 
         // ---- advance the per-lane state machine ---------------------------------------------
@@ -358,9 +419,9 @@ __global__ __launch_bounds__(256) void disp_fit_kernel(DispArgs A) {
 static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                         hipStream_t st) {
     DispArgs A{counts, nf, d, w, o};
-    const size_t lds_per_wave = (size_t)d.S * 64 * 12;
-    // 256-thread blocks while four waves' rows fit comfortably in LDS, else 64-thread blocks
-    int threads = 256;
+    const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
+    // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks
+    int threads = 128;
     while (threads > 64 && lds_per_wave * (threads / 64) > 40 * 1024) threads >>= 1;
     const size_t lds = lds_per_wave * (threads / 64);
     // persistent grid: enough waves to fill 256 CUs; rows are pulled from the queue
@@ -369,10 +430,17 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     const int64_t max_blocks = 256 * (int64_t)(160 * 1024 / (lds > 0 ? lds : 1) < 8 ? 160 * 1024 / lds : 8);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    if (map)
-        disp_fit_kernel<true><<<(unsigned)blocks, threads, lds, st>>>(A);
-    else
-        disp_fit_kernel<false><<<(unsigned)blocks, threads, lds, st>>>(A);
+    static const int variant = [] {
+        const char *e = getenv("CHICDIFF_DISP_MINW");  // tuning knob: min waves/SIMD the kernel is built for
+        return e ? atoi(e) : 2;
+    }();
+#define LAUNCH(M, W) disp_fit_kernel<M, W><<<(unsigned)blocks, threads, lds, st>>>(A)
+    if (map) {
+        if (variant >= 4) LAUNCH(true, 4); else if (variant == 3) LAUNCH(true, 3); else LAUNCH(true, 2);
+    } else {
+        if (variant >= 4) LAUNCH(false, 4); else if (variant == 3) LAUNCH(false, 3); else LAUNCH(false, 2);
+    }
+#undef LAUNCH
 }
 
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {

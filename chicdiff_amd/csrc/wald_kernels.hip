@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
     }
 }
 
+constexpr int kChunk = 256;  // rows a wave takes from the global queue per atomic
+
 struct WaldArgs {
     const int32_t *counts;
     const double *nf;
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
     unsigned long long *queue = A.w.queue + 2;
 
     bool need = true, done = false, queue_empty = false;
+    unsigned long long chunk_next = 0, chunk_end = 0;
     int64_t row = -1;
     int k = 0;
     double b0 = 0, b1 = 0, alpha = 0, size = 0, crow = 0, dev_old = 0, la = 0;
@@ -71,21 +74,31 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
         for (int attempt = 0; attempt < 4; attempt++) {
             const unsigned long long needmask = __ballot(need && !done);
             if (!needmask) break;
-            if (queue_empty) {
-                if (need) done = true;
-                break;
+            if (chunk_next >= chunk_end) {  // wave-private chunk exhausted: one atomic per kChunk rows
+                if (queue_empty) {
+                    if (need) done = true;
+                    break;
+                }
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(queue, (unsigned long long)kChunk);
+                b = __shfl(b, 0);
+                if (b >= (unsigned long long)n) {
+                    queue_empty = true;
+                    continue;
+                }
+                chunk_next = b;
+                chunk_end = b + kChunk < (unsigned long long)n ? b + kChunk : (unsigned long long)n;
             }
             const int cnt = __popcll(needmask);
-            const int leader = __ffsll((long long)needmask) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(queue, (unsigned long long)cnt);
-            base = __shfl(base, leader);
-            if (base + cnt >= (unsigned long long)n) queue_empty = true;
+            const unsigned long long base = chunk_next;
+            const unsigned long long avail = chunk_end - chunk_next;
+            const int take = (unsigned long long)cnt < avail ? cnt : (int)avail;
+            chunk_next += (unsigned long long)take;
             if (need && !done) {
                 const int rank = __popcll(needmask & ((1ull << lane) - 1ull));
                 const int64_t r = (int64_t)base + rank;
-                if (r >= n) {
-                    done = true;
+                if (rank >= take) {
+                    // chunk ran out: keep `need`, the next attempt opens a new chunk
                 } else if (A.w.allZero[r]) {
                     A.w.beta0[r] = NAN;
                     A.w.beta1[r] = NAN;
