@@ -254,9 +254,8 @@ static int run_select(chicdiff_hip_ctx *c, SelArgs a) {
     int rc = do_allreduce(c, c->w.hist, a.ncol);
     if (rc) return rc;
     launch_sel_begin(a, c->w, st);
-    static const int shifts[6] = {52, 40, 28, 16, 4, 0};
     for (int r = 0; r < 6; r++) {
-        a.shift = shifts[r];
+        a.shift = kSelShifts[r];
         {
             Scope t(c, "select_hist");
             launch_sel_hist(a, c->w, st);
@@ -322,10 +321,12 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         for (int k = 0; k < batch; k++) {
             {
                 Scope t(c, "trend_pass");
-                launch_trend_pass(d, w, o, st);
+                launch_trend_pass(d, w, o, st, c->world <= 1);
             }
-            if ((rc = do_allreduce(c, sums_of(w), kTrendSums))) return rc;
-            launch_trend_step(d, w, o, st);
+            if (c->world > 1) {
+                if ((rc = do_allreduce(c, sums_of(w), kTrendSums))) return rc;
+                launch_trend_step(d, w, o, st);
+            }
         }
         passes += batch;
         HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));

@@ -4,37 +4,11 @@
 #include <stdint.h>
 
 #include "../../include/chicdiff_hip.h"
+#include "fit_state.h"
 
 namespace cd {
 
-constexpr int kMaxS = 64;          // samples per fit (group mask is one 64-bit word)
-constexpr int kSelBits = 12;       // radix-select digit width
-constexpr int kSelBins = 1 << kSelBits;
 constexpr int kRedBlocks = 1024;   // fixed grid of the reduction passes (deterministic two-stage sums)
-constexpr int kTrendSums = 8;      // dev, sw, swx, swxx, swy, swxy, count, invalid
-
-// Device-resident scalars of one fit; the host reads the struct back once, at the end.
-struct FitScalars {
-    double colsum[kMaxS];  // column sums of nf over non-all-zero rows (then all-reduced)
-    double nnz;            // number of non-all-zero rows (double: goes through the f64 all-reduce)
-    double xim;            // mean_j 1/colMeans(nf)_j                  (DESeq2 momentsDispEstimate)
-    // trend state machine (parametricDispersionFit + glm.fit), see trend_step_kernel
-    double coefs[2];       // outer-loop coefficients (define the `good` set)
-    double b[2];           // inner IRLS iterate
-    double devold;
-    int32_t inner_it, outer_it, phase, finished, failed, conv, _pad0, _pad1;
-    double nfit;           // rows with dispGeneEst > 100*minDisp
-    // MAD / prior
-    double med, mad, varLogDispEsts, dispPriorVar;
-    double nres;           // rows with dispGeneEst >= 100*minDisp
-    double sumDeviance;
-    double nonconv;        // rows whose IRLS hit betaMaxit
-    // radix-select state: up to kMaxS columns x 2 ranks
-    uint64_t sel_prefix[kMaxS * 2];
-    double sel_rank[kMaxS * 2];  // remaining 0-based rank inside the current prefix
-    double sel_count[kMaxS];     // population per column
-    double sel_value[kMaxS * 2]; // selected order statistics
-};
 
 struct FitDims {
     int64_t n;
@@ -65,7 +39,7 @@ void launch_xim(FitDims d, FitWork w, hipStream_t st);                  // colsu
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_disp_map(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_trend_init(FitDims d, FitWork w, Opts o, hipStream_t st);
-void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st);   // -> partials -> sums in w.partials[0..8)
+void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st, bool fused_step);  // pass + reduce (+ step when single rank)
 void launch_trend_step(FitDims d, FitWork w, Opts o, hipStream_t st);   // consumes sums, advances the state machine
 void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st);
@@ -103,17 +77,5 @@ void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfra
 void launch_count_join(const int32_t *bait, const int32_t *oe, int64_t nru, const int64_t *keys,
                        const int32_t *vals, int64_t nkeys, int32_t *out, hipStream_t st);
 void launch_pvalues(const double *stat, int64_t n, double *p, hipStream_t st);
-
-// order-preserving map double -> uint64 (NaN never passed in)
-__host__ __device__ inline uint64_t key_of(double x) {
-    union { double d; uint64_t u; } c;
-    c.d = x;
-    return (c.u & 0x8000000000000000ull) ? ~c.u : (c.u | 0x8000000000000000ull);
-}
-__host__ __device__ inline double value_of(uint64_t k) {
-    union { double d; uint64_t u; } c;
-    c.u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
-    return c.d;
-}
 
 }  // namespace cd

@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fit_state.h"
+
 namespace cd {
 
 // 1/x for normal, well-scaled x (no denormal / overflow handling): v_rcp_f64 + two Newton steps,
@@ -70,6 +72,70 @@ __device__ __forceinline__ void stirling(double z, double lz, double zi, double 
     dg = fma(-0.5, zi, lz) - t * z2;
 }
 
+// ---- log Gamma(y + r) - log Gamma(r) for an integer count y >= 0 and r > 0 ---------------------
+// Stable for huge r (alpha -> 1e-8 means r = 1e8, where lgamma(y+r) - lgamma(r) cancels ~9 digits):
+//   y <  nr : log prod_{i<y}(r+i)
+//   y >= nr : log prod_{i<nr}(r+i) + (z - 1/2) log1p(d/z0) + d (log z0 - 1) + tail(z) - tail(z0),
+// with nr = number of unit steps lifting r to z0 = r + nr >= 10, d = y - nr, z = z0 + d, and
+// tail() the Stirling correction series.  Everything that depends only on r sits in LgrCtx.
+__device__ __forceinline__ double lg_tail(double zi) {
+    const double z2 = zi * zi;
+    double s = fma(z2, 1.0 / 156.0, -691.0 / 360360.0);
+    s = fma(z2, s, 1.0 / 1188.0);
+    s = fma(z2, s, -1.0 / 1680.0);
+    s = fma(z2, s, 1.0 / 1260.0);
+    s = fma(z2, s, -1.0 / 360.0);
+    s = fma(z2, s, 1.0 / 12.0);
+    return s * zi;
+}
+struct LgrCtx {
+    double r, z0, iz0, lz0m1, tail0, lP;
+    int nr;
+};
+__device__ __forceinline__ LgrCtx lgr_make(double r) {
+    LgrCtx c;
+    c.r = r;
+    c.nr = r < 10.0 ? (int)ceil(10.0 - r) : 0;
+    double P = 1.0, zz = r;
+    for (int i = 0; i < c.nr; i++) {
+        P *= zz;
+        zz += 1.0;
+    }
+    c.z0 = r + (double)c.nr;
+    c.iz0 = rcp(c.z0);
+    c.lz0m1 = flog(c.z0) - 1.0;
+    c.tail0 = lg_tail(c.iz0);
+    c.lP = c.nr ? flog(P) : 0.0;
+    return c;
+}
+// the context of r = 1, i.e. log(y!) = lgr_eval(lgr_one(), y)
+__device__ __forceinline__ LgrCtx lgr_one() {
+    LgrCtx c;
+    c.r = 1.0;
+    c.nr = 9;
+    c.z0 = 10.0;
+    c.iz0 = 0.1;
+    c.lz0m1 = 2.302585092994045684 - 1.0;
+    c.tail0 = lg_tail(0.1);
+    c.lP = 12.80182748008146961;        // log(9!)
+    return c;
+}
+__device__ __forceinline__ double lgr_eval(const LgrCtx &c, int yi) {
+    if (yi >= c.nr) {
+        const double d = (double)(yi - c.nr);
+        const double z = c.z0 + d;
+        const double u = d * c.iz0, t = 1.0 + u;
+        const double l1p = flog1p_from(u, t, rcp(t));
+        return c.lP + fma(z - 0.5, l1p, d * c.lz0m1) + (lg_tail(rcp(z)) - c.tail0);
+    }
+    double P = 1.0, zz = c.r;
+    for (int i = 0; i < yi; i++) {
+        P *= zz;
+        zz += 1.0;
+    }
+    return flog(P);
+}
+
 // lgamma(x) and digamma(x), x > 0 (general purpose; the fit kernels use the difference form in
 // disp_kernels.hip instead).
 __device__ __forceinline__ void lgamma_digamma(double x, double &lg, double &dg) {
@@ -102,22 +168,6 @@ __device__ __forceinline__ double lgamma_pos(double x) {
     double lg = fma(z - 0.5, lz, -z) + 0.91893853320467274178 + s * zi;
     if (x < 10.0) lg -= flog(P);
     return lg;
-}
-
-__device__ __forceinline__ double trigamma_pos(double x) {
-    double r = 0.0;
-    while (x < 10.0) {
-        r += 1.0 / (x * x);
-        x += 1.0;
-    }
-    const double xi = 1.0 / x, x2 = xi * xi;
-    double s = fma(x2, -7.0 / 6.0, 691.0 / 2730.0);
-    s = fma(x2, -s, 5.0 / 66.0);
-    s = fma(x2, -s, 1.0 / 30.0);
-    s = fma(x2, -s, 1.0 / 42.0);
-    s = fma(x2, -s, 1.0 / 30.0);
-    s = fma(x2, -s, 1.0 / 6.0);
-    return r + xi * (1.0 + 0.5 * xi + x2 * s);
 }
 
 // ---- Loader's saddle-point binomial pieces (R nmath dnbinom_mu), for the reported deviance ----

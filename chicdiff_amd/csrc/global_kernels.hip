@@ -48,120 +48,48 @@ __global__ void reduce_partials_kernel(const double *partials, int nblk, int K, 
 static inline double *sums_of(const FitWork &w) { return w.partials + (size_t)kRedBlocks * 72; }
 
 // ------------------------------------------------------------------------------------------
-// trend
-enum { TR_INNER_START = 0, TR_INNER_ITER = 1 };
-
-__global__ void trend_init_kernel(FitWork w) {
-    FitScalars *sc = w.sc;
-    sc->coefs[0] = 0.1;
-    sc->coefs[1] = 1.0;
-    sc->b[0] = 0.1;
-    sc->b[1] = 1.0;
-    sc->devold = 0;
-    sc->inner_it = 0;
-    sc->outer_it = 0;
-    sc->phase = TR_INNER_START;
-    sc->finished = 0;
-    sc->failed = 0;
-    sc->conv = 0;
-}
+// trend (state machine: fit_state.h)
+__global__ void trend_init_kernel(FitWork w) { trend_init(w.sc); }
 
 __global__ __launch_bounds__(256) void trend_pass_kernel(FitDims d, FitWork w, double minDisp) {
     const FitScalars *sc = w.sc;
     if (sc->finished) return;
-    const double c0 = sc->coefs[0], c1 = sc->coefs[1], b0 = sc->b[0], b1 = sc->b[1];
     double v[kTrendSums] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
         if (w.allZero[i]) continue;
         const double y = w.dispGene[i];
-        if (!(y > 100 * minDisp)) continue;
-        const double bm = w.baseMean[i];
-        const double r = y / (c0 + c1 / bm);
-        if (!(r > 1e-4 && r < 15)) continue;
-        const double x = 1.0 / bm;
-        const double mu = b0 + b1 * x;
-        if (!(mu > 0) || !isfinite(mu)) {
-            v[7] += 1;
-            continue;
-        }
-        v[0] += -2.0 * (log(y / mu) - (y - mu) / mu);
-        const double wt = 1.0 / (mu * mu);
-        v[1] += wt;
-        v[2] += wt * x;
-        v[3] += wt * x * x;
-        v[4] += wt * y;
-        v[5] += wt * x * y;
-        v[6] += 1;
+        if (!(y > 100 * minDisp)) continue;  // useForFit <- dispGeneEst > 100*minDisp
+        trend_row(sc, w.baseMean[i], y, v);
     }
     block_reduce_store<kTrendSums>(v, w.partials + (size_t)blockIdx.x * kTrendSums);
 }
 
-// One thread: R's glm.fit iteration bookkeeping + parametricDispersionFit's outer loop.
-__global__ void trend_step_kernel(FitWork w) {
-    FitScalars *sc = w.sc;
-    if (sc->finished) return;
-    const double *s = w.partials + (size_t)kRedBlocks * 72;
-    const double dev = s[0], sw = s[1], swx = s[2], swxx = s[3], swy = s[4], swxy = s[5], cnt = s[6], bad = s[7];
-    bool inner_done = false, conv = false;
-    if (bad > 0 || cnt < 2) {  // invalid mu (R would step-halve; DESeq2 ends in "fit failed") or no data
-        sc->failed = 1;
-        sc->finished = 1;
-        return;
+// one block: fixed-order sum of the block partials; with a single rank the same block also
+// advances the state machine (with several ranks the sums are all-reduced first)
+__global__ __launch_bounds__(256) void trend_reduce_kernel(FitWork w, int nblk, int do_step) {
+    __shared__ double red[kTrendSums][4];
+    double *sums = w.partials + (size_t)kRedBlocks * 72;
+    if (w.sc->finished) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < kTrendSums; k++) {
+        double acc = 0;
+        for (int b = threadIdx.x; b < nblk; b += 256) acc += w.partials[(size_t)b * kTrendSums + k];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) red[k][wave] = acc;
     }
-    if (sc->phase == TR_INNER_START) {
-        sc->devold = dev;
-        sc->inner_it = 0;
-        sc->phase = TR_INNER_ITER;
-    } else {
-        if (fabs(dev - sc->devold) / (fabs(dev) + 0.1) < 1e-8) {
-            inner_done = true;
-            conv = true;
-        } else {
-            sc->devold = dev;
-            if (sc->inner_it >= 25) inner_done = true;  // glm.fit maxit, not converged
-        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < kTrendSums; k++) sums[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+        if (do_step) trend_step(w.sc, sums);
     }
-    if (!inner_done) {
-        const double det = sw * swxx - swx * swx;
-        const double nb0 = (swxx * swy - swx * swxy) / det, nb1 = (sw * swxy - swx * swy) / det;
-        if (!isfinite(nb0) || !isfinite(nb1)) {
-            sc->failed = 1;
-            sc->finished = 1;
-            return;
-        }
-        sc->b[0] = nb0;
-        sc->b[1] = nb1;
-        sc->inner_it++;
-        return;
-    }
-    // inner loop over: parametricDispersionFit bookkeeping
-    const double o0 = sc->coefs[0], o1 = sc->coefs[1];
-    sc->coefs[0] = sc->b[0];
-    sc->coefs[1] = sc->b[1];
-    if (!(sc->coefs[0] > 0 && sc->coefs[1] > 0)) {
-        sc->failed = 1;
-        sc->finished = 1;
-        return;
-    }
-    const double l0 = log(sc->coefs[0] / o0), l1 = log(sc->coefs[1] / o1);
-    if ((l0 * l0 + l1 * l1 < 1e-6) && conv) {
-        sc->finished = 1;
-        sc->conv = 1;
-        return;
-    }
-    sc->outer_it++;
-    if (sc->outer_it > 10) {
-        sc->failed = 2;
-        sc->finished = 1;
-        return;
-    }
-    sc->phase = TR_INNER_START;  // next glm() call starts from the new coefs, on the new `good` set
 }
+__global__ void trend_step_kernel(FitWork w) { trend_step(w.sc, w.partials + (size_t)kRedBlocks * 72); }
 
 void launch_trend_init(FitDims, FitWork w, Opts, hipStream_t st) { trend_init_kernel<<<1, 1, 0, st>>>(w); }
-void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st) {
-    trend_pass_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp);
-    reduce_partials_kernel<<<1, 256, 0, st>>>(w.partials, kRedBlocks, kTrendSums, sums_of(w));
+constexpr int kTrendBlocks = 512;
+void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st, bool fused_step) {
+    trend_pass_kernel<<<kTrendBlocks, 256, 0, st>>>(d, w, o.minDisp);
+    trend_reduce_kernel<<<1, 256, 0, st>>>(w, kTrendBlocks, fused_step ? 1 : 0);
 }
 void launch_trend_step(FitDims, FitWork w, Opts, hipStream_t st) { trend_step_kernel<<<1, 1, 0, st>>>(w); }
 
@@ -181,17 +109,8 @@ void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st) {
     resid_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp);
 }
 
-// estimateDispersionsPriorVar, closed-form branch (A4)
-__global__ void prior_var_kernel(FitDims d, FitWork w, double prior_in) {
-    FitScalars *sc = w.sc;
-    const double v = sc->mad * sc->mad;
-    sc->varLogDispEsts = v;
-    if (prior_in == prior_in) {
-        sc->dispPriorVar = prior_in;
-    } else {
-        sc->dispPriorVar = fmax(v - trigamma_pos((d.S - d.p) / 2.0), 0.25);
-    }
-}
+// estimateDispersionsPriorVar, closed-form branch (A4): fit_state.h
+__global__ void prior_var_kernel(FitDims d, FitWork w, double prior_in) { prior_var(w.sc, d.S, d.p, prior_in); }
 void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st) {
     prior_var_kernel<<<1, 1, 0, st>>>(d, w, o.dispPriorVarIn);
 }
@@ -231,15 +150,7 @@ __global__ void sel_count_finish_kernel(FitWork w, int nblk, int ncol) {
 }
 __global__ void sel_begin_kernel(FitWork w, int ncol) {
     const int c = threadIdx.x;
-    if (c >= ncol) return;
-    FitScalars *sc = w.sc;
-    const double m = w.hist[c];
-    sc->sel_count[c] = m;
-    const int64_t mi = (int64_t)m;
-    sc->sel_rank[2 * c] = (double)((mi - 1) / 2);
-    sc->sel_rank[2 * c + 1] = (double)(mi / 2);
-    sc->sel_prefix[2 * c] = 0;
-    sc->sel_prefix[2 * c + 1] = 0;
+    if (c < ncol) sel_begin(w.sc, c, w.hist[c]);
 }
 
 // histograms of the current digit for the two live prefixes of column blockIdx.y
@@ -256,10 +167,9 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(SelArgs a, FitWork w, int
     uint64_t key;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
         if (!sel_key(a, sc, col, i, key)) continue;
-        const uint64_t top = (hi >= 64) ? 0ull : (key >> hi);
         const unsigned dig = (unsigned)((key >> a.shift) & mask);
-        if (top == ((hi >= 64) ? 0ull : (p0 >> hi))) atomicAdd(&h[0][dig], 1u);
-        else if (!same && top == (p1 >> hi)) atomicAdd(&h[1][dig], 1u);
+        if (sel_match(key, p0, hi)) atomicAdd(&h[0][dig], 1u);
+        else if (!same && sel_match(key, p1, hi)) atomicAdd(&h[1][dig], 1u);
     }
     __syncthreads();
     double *g = w.hist + (size_t)col * 2 * kSelBins;
@@ -269,39 +179,48 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(SelArgs a, FitWork w, int
     }
 }
 
-// pick the bin holding the wanted rank; one block per column, both rank slots in turn
+// pick the bin holding the wanted rank (parallel form of fit_state.h sel_pick); one block per
+// column, both rank slots in turn: per-thread partial sums, block scan, the owning thread refines
 __global__ __launch_bounds__(256) void sel_step_kernel(SelArgs a, FitWork w, int bits) {
-    __shared__ double part[256];
+    __shared__ double scan[256];
     const int col = blockIdx.x;
     FitScalars *sc = w.sc;
     const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
+    const double rank0 = sc->sel_rank[2 * col], rank1 = sc->sel_rank[2 * col + 1];
     const int nb = 1 << bits, per = (nb + 255) / 256;
     for (int slot = 0; slot < 2; slot++) {
         const int hslot = (slot == 1 && p0 != p1) ? 1 : 0;
         const double *g = w.hist + ((size_t)col * 2 + hslot) * kSelBins;
+        const double rank = slot ? rank1 : rank0;
+        double mine[16];
         double acc = 0;
-        for (int k = 0; k < per; k++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
             const int b = threadIdx.x * per + k;
-            if (b < nb) acc += g[b];
+            mine[k] = (k < per && b < nb) ? g[b] : 0.0;
+            acc += mine[k];
         }
         __syncthreads();
-        part[threadIdx.x] = acc;
+        scan[threadIdx.x] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const double rank = sc->sel_rank[2 * col + slot];
-            double cum = 0;
-            int t = 0;
-            for (; t < 255; t++) {
-                if (cum + part[t] > rank) break;
-                cum += part[t];
+        for (int off = 1; off < 256; off <<= 1) {  // inclusive Hillis-Steele scan (counts: exact in fp64)
+            const double add = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0.0;
+            __syncthreads();
+            scan[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const double incl = scan[threadIdx.x], before = incl - acc;
+        const bool last_thread = (int)threadIdx.x == (nb - 1) / per;
+        if ((before <= rank && rank < incl) || (last_thread && rank >= incl && incl == scan[255])) {
+            double cum = before;
+            int k = 0;
+            for (; k < per - 1 && threadIdx.x * per + k < nb - 1; k++) {
+                if (cum + mine[k] > rank) break;
+                cum += mine[k];
             }
-            int b = t * per;
-            for (; b < nb - 1 && b < (t + 1) * per - 1; b++) {
-                if (cum + g[b] > rank) break;
-                cum += g[b];
-            }
-            const uint64_t mine = (slot == 0) ? p0 : p1;
-            sc->sel_prefix[2 * col + slot] = mine | ((uint64_t)b << a.shift);
+            const int b = threadIdx.x * per + k;
+            const uint64_t pre = (slot == 0) ? p0 : p1;
+            sc->sel_prefix[2 * col + slot] = pre | ((uint64_t)b << a.shift);
             sc->sel_rank[2 * col + slot] = rank - cum;
         }
     }
@@ -311,15 +230,14 @@ __global__ void sel_finish_kernel(SelArgs a, FitWork w) {
     const int c = threadIdx.x;
     if (c >= a.ncol) return;
     FitScalars *sc = w.sc;
-    const double lo = value_of(sc->sel_prefix[2 * c]), hi = value_of(sc->sel_prefix[2 * c + 1]);
-    const double med = (sc->sel_count[c] > 0) ? (lo + hi) / 2.0 : NAN;
-    sc->sel_value[2 * c] = lo;
-    sc->sel_value[2 * c + 1] = hi;
+    const double med = sel_median(sc, c);
+    sc->sel_value[2 * c] = value_of(sc->sel_prefix[2 * c]);
+    sc->sel_value[2 * c + 1] = value_of(sc->sel_prefix[2 * c + 1]);
     if (a.mode == SEL_RESID) {
         sc->med = med;
         sc->nres = sc->sel_count[c];
     } else if (a.mode == SEL_ABSDEV) {
-        sc->mad = 1.4826 * med;
+        sc->mad = 1.4826 * med;  // R mad(): constant 1.4826
     } else {
         sc->sel_value[2 * c] = exp(med);  // size factor of column c
     }
@@ -338,12 +256,12 @@ void launch_sel_count(SelArgs a, FitWork w, hipStream_t st) {
 }
 void launch_sel_begin(SelArgs a, FitWork w, hipStream_t st) { sel_begin_kernel<<<1, 64, 0, st>>>(w, a.ncol); }
 void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st) {
-    const int bits = a.shift == 0 ? 4 : kSelBits;
+    const int bits = sel_bits(a.shift);
     (void)hipMemsetAsync(w.hist, 0, sizeof(double) * (size_t)a.ncol * 2 * kSelBins, st);
     sel_hist_kernel<<<dim3(sel_blocks(a.n), a.ncol), 256, 0, st>>>(a, w, bits);
 }
 void launch_sel_step(SelArgs a, FitWork w, hipStream_t st) {
-    const int bits = a.shift == 0 ? 4 : kSelBits;
+    const int bits = sel_bits(a.shift);
     sel_step_kernel<<<a.ncol, 256, 0, st>>>(a, w, bits);
 }
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st) { sel_finish_kernel<<<1, 64, 0, st>>>(a, w); }

@@ -23,14 +23,14 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
     const int S = d.S;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         if (w.allZero[i]) continue;
-        const double size = 1.0 / w.disp[i];
-        const double lg_size = lgamma_pos(size);
+        const LgrCtx cs = lgr_make(rcp(w.disp[i])), c1 = lgr_one();
         double lA = 0, lB = 0, c = 0;
         for (int j = 0; j < S; j++) {
-            const double y = (double)counts[(int64_t)j * n + i];
-            const double l = log(y / nf[(int64_t)j * n + i] + 0.1);
+            const int yi = counts[(int64_t)j * n + i];
+            const double l = flog((double)yi / nf[(int64_t)j * n + i] + 0.1);
             if ((d.gmask >> j) & 1) lB += l; else lA += l;
-            if (y > 0) c += lgamma_pos(y + size) - lg_size - lgamma_pos(y + 1.0);
+            // lgamma(y+size) - lgamma(size) - lgamma(y+1): the mu-independent part of log dnbinom
+            if (yi > 0) c += lgr_eval(cs, yi) - lgr_eval(c1, yi);
         }
         lA /= d.nA;
         lB /= d.nB;
@@ -181,25 +181,6 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
     }
 }
 
-// trimmed mean of v[0..n) dropping `lo` values at each end (R mean(x, trim)); destroys v
-__device__ __forceinline__ double trimmed_mean(double *v, int n, int lo) {
-    for (int t = 0; t < lo; t++) {
-        int imin = 0, imax = 0;
-        for (int k = 1; k < n; k++) {
-            if (v[k] < v[imin]) imin = k;
-            if (v[k] >= v[imax]) imax = k;
-        }
-        if (imin == imax) imax = (imin + 1) % n;
-        // remove the two (order of removal keeps indices valid)
-        const int a = imin > imax ? imin : imax, b = imin > imax ? imax : imin;
-        v[a] = v[n - 1];
-        v[b] = v[n - 2];
-        n -= 2;
-    }
-    double s = 0;
-    for (int k = 0; k < n; k++) s += v[k];
-    return s / n;
-}
 __device__ __forceinline__ int trim_lo(int n) {
     // trimratio c(1/3, 1/4, 1/8) on bins (0,3.5], (3.5,23.5], (23.5,Inf)
     const double tr = n <= 3 ? 1.0 / 3 : (n <= 23 ? 1.0 / 4 : 1.0 / 8);
@@ -207,32 +188,68 @@ __device__ __forceinline__ int trim_lo(int n) {
 }
 __device__ __forceinline__ double trim_scale(int n) { return n <= 3 ? 2.04 : (n <= 23 ? 1.86 : 1.51); }
 
+// R mean(x, trim) over the samples of cell `c`: drop the `lo` smallest and `lo` largest values.
+// The row's values sit in LDS as s_q[j * T + tid]; `sq` selects (q - cm)^2 instead of q.  An
+// element is kept when its rank (ties broken by index) lies in [lo, nc - lo): O(nc^2) LDS reads,
+// no per-thread arrays (so no scratch), exact and order-independent.
+__device__ __forceinline__ double cell_trimmed_mean(const double *s_q, int T, int tid, int S, uint64_t gmask, int c,
+                                                    int nc, int lo, bool sq, double cm) {
+    double sum = 0;
+    for (int j = 0; j < S; j++) {
+        if ((int)((gmask >> j) & 1) != c) continue;
+        double vj = s_q[j * T + tid];
+        if (sq) vj = (vj - cm) * (vj - cm);
+        int rank = 0;
+        for (int k = 0; k < S; k++) {
+            if ((int)((gmask >> k) & 1) != c) continue;
+            double vk = s_q[k * T + tid];
+            if (sq) vk = (vk - cm) * (vk - cm);
+            rank += (vk < vj || (vk == vj && k < j)) ? 1 : 0;
+        }
+        if (rank >= lo && rank < nc - lo) sum += vj;
+    }
+    return sum / (nc - 2 * lo);
+}
+
 __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restrict__ counts,
                                                          const double *__restrict__ nf, FitDims d, FitWork w, Opts o,
                                                          chicdiff_nbglm_out out) {
+    extern __shared__ double s_q[];  // [S][blockDim.x] normalised counts of this thread's row
+    const int T = blockDim.x, tid = threadIdx.x;
     const int64_t n = d.n;
     const int S = d.S;
     const double lambda = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
+    const bool want_cooks = out.maxCooks && (d.nA >= 3 || d.nB >= 3);
     double v[3] = {0, 0, 0};  // sum deviance, non-converged rows, all-zero rows
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = blockIdx.x * (int64_t)T + tid; i < n; i += (int64_t)gridDim.x * T) {
         const bool az = w.allZero[i];
         double B0 = NAN, B1 = NAN, s0 = NAN, s1 = NAN, st = NAN, pv = NAN, dv = NAN, mc = NAN;
         int bconv = 0, biter = 0;
         if (!az) {
-            const double alpha = w.disp[i], size = 1.0 / alpha;
+            const double alpha = w.disp[i], size = rcp(alpha);
             const double b0 = w.beta0[i], b1 = w.beta1[i];
             biter = w.betaIter[i];
             bconv = biter < o.betaMaxit;
             const double E0 = exp(b0), E1 = exp(b0 + b1);
-            double wA = 0, wB = 0, ll = 0;
+            const double la = flog(alpha);
+            double wA = 0, wB = 0, ll = w.crow[i], m = 0;
             for (int j = 0; j < S; j++) {
                 const bool g = (d.gmask >> j) & 1;
                 const double y = (double)counts[(int64_t)j * n + i];
-                const double muf = nf[(int64_t)j * n + i] * (g ? E1 : E0);  // no floor for the likelihood
+                const double nfj = nf[(int64_t)j * n + i];
+                const double muf = nfj * (g ? E1 : E0);  // no floor for the likelihood
                 const double mu = fmax(muf, o.minmu);
-                const double wj = mu / (1.0 + alpha * mu);
+                const double wj = mu * rcp(fma(alpha, mu, 1.0));
                 if (g) wB += wj; else wA += wj;
-                ll += dnbinom_mu_log(y, size, muf);
+                // log dnbinom(y; size, mu) = crow_j - (size+y) log1p(alpha mu) + y log(alpha mu)
+                const double ma = alpha * muf, t = 1.0 + ma;
+                ll -= (size + y) * flog1p_from(ma, t, rcp(t));
+                if (y > 0) ll += y * (la + flog(muf));
+                if (want_cooks) {
+                    const double q = y / nfj;
+                    s_q[j * T + tid] = q;
+                    m += q;
+                }
             }
             const double m00 = wA + wB + lambda, m01 = wB, m11 = wB + lambda, det = m00 * m11 - m01 * m01;
             const double i00 = m11 / det, i01 = -m01 / det, i11 = m00 / det;
@@ -248,26 +265,16 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
             pv = pnorm_two_sided(st);
             dv = -2.0 * ll;
             if (!bconv || !(v0 > 0) || !(v1 > 0)) v[1] += 1;
-            if (out.maxCooks && (d.nA >= 3 || d.nB >= 3)) {
-                // robustMethodOfMomentsDisp: max over cells (>=3 samples) of the scaled trimmed variance
-                double tmp[kMaxS];
-                double vmax = -INFINITY, m = 0;
-                for (int j = 0; j < S; j++) m += (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i];
+            if (want_cooks) {
+                // robustMethodOfMomentsDisp: max over cells (>= 3 samples) of the scaled trimmed variance
                 m /= S;
+                double vmax = -INFINITY;
                 for (int c = 0; c < 2; c++) {
                     const int nc = c ? d.nB : d.nA;
                     if (nc < 3) continue;
-                    int kk = 0;
-                    for (int j = 0; j < S; j++)
-                        if ((int)((d.gmask >> j) & 1) == c) tmp[kk++] = (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i];
-                    const double cm = trimmed_mean(tmp, nc, trim_lo(nc));
-                    kk = 0;
-                    for (int j = 0; j < S; j++)
-                        if ((int)((d.gmask >> j) & 1) == c) {
-                            const double dd = (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i] - cm;
-                            tmp[kk++] = dd * dd;
-                        }
-                    const double vv = trim_scale(nc) * trimmed_mean(tmp, nc, trim_lo(nc));
+                    const int lo = trim_lo(nc);
+                    const double cm = cell_trimmed_mean(s_q, T, tid, S, d.gmask, c, nc, lo, false, 0.0);
+                    const double vv = trim_scale(nc) * cell_trimmed_mean(s_q, T, tid, S, d.gmask, c, nc, lo, true, cm);
                     if (vv > vmax) vmax = vv;
                 }
                 const double arob = fmax((vmax - m) / (m * m), 0.04);
@@ -275,13 +282,14 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
                 for (int j = 0; j < S; j++) {
                     const bool g = (d.gmask >> j) & 1;
                     if ((g ? d.nB : d.nA) < 3) continue;
-                    const double y = (double)counts[(int64_t)j * n + i];
-                    const double muf = nf[(int64_t)j * n + i] * (g ? E1 : E0);
+                    const double nfj = nf[(int64_t)j * n + i];
+                    const double yc = (double)counts[(int64_t)j * n + i];
+                    const double muf = nfj * (g ? E1 : E0);
                     const double mu = fmax(muf, o.minmu);
-                    const double wj = mu / (1.0 + alpha * mu);
+                    const double wj = mu * rcp(fma(alpha, mu, 1.0));
                     const double h = wj * (g ? (i00 + 2 * i01 + i11) : i00);
                     const double V = muf + arob * muf * muf;
-                    const double ck = (y - muf) * (y - muf) / V / 2.0 * h / ((1 - h) * (1 - h));
+                    const double ck = (yc - muf) * (yc - muf) / V / 2.0 * h / ((1 - h) * (1 - h));
                     if (ck > mc) mc = ck;
                 }
             }
@@ -300,18 +308,21 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
         if (out.betaConv) out.betaConv[i] = bconv;
         if (out.betaIter) out.betaIter[i] = biter;
     }
-    // block partials: 3 values
+    // block partials: 3 values (blocks of 64..256 threads)
     __shared__ double red[3][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = T >> 6;
+    __syncthreads();
     for (int k = 0; k < 3; k++) {
         double x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
         if (lane == 0) red[k][wave] = x;
     }
     __syncthreads();
-    if (threadIdx.x < 3)
-        w.partials[(size_t)blockIdx.x * 3 + threadIdx.x] =
-            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < 3) {
+        double acc = 0;
+        for (int q = 0; q < nw; q++) acc += red[threadIdx.x][q];
+        w.partials[(size_t)blockIdx.x * 3 + threadIdx.x] = acc;
+    }
 }
 
 // design ~1: fitNbinomGLMs' intercept-only shortcut (no IRLS)
@@ -325,17 +336,22 @@ __global__ __launch_bounds__(256) void wald_intercept_kernel(const int32_t *__re
         double B0 = NAN, s0 = NAN, st = NAN, pv = NAN, dv = NAN;
         const bool az = w.allZero[i];
         if (!az) {
-            const double alpha = w.disp[i], size = 1.0 / alpha;
+            const double alpha = w.disp[i], size = rcp(alpha);
             double bm = 0;
             for (int j = 0; j < S; j++) bm += (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i];
             bm /= S;
             B0 = log2(bm);
             const double e = exp2(B0);
+            const LgrCtx cs = lgr_make(size), c1 = lgr_one();
+            const double la = flog(alpha);
             double ll = 0, xtwx = 0;
             for (int j = 0; j < S; j++) {
                 const double mu = nf[(int64_t)j * n + i] * e;
-                ll += dnbinom_mu_log((double)counts[(int64_t)j * n + i], size, mu);
-                xtwx += 1.0 / (1.0 / mu + alpha);
+                const int yi = counts[(int64_t)j * n + i];
+                const double y = (double)yi, ma = alpha * mu, t = 1.0 + ma, rt = rcp(t);
+                ll -= (size + y) * flog1p_from(ma, t, rt);
+                if (yi > 0) ll += lgr_eval(cs, yi) - lgr_eval(c1, yi) + y * (la + flog(mu));
+                xtwx += mu * rt;
             }
             s0 = kLog2e * sqrt(1.0 / xtwx);
             st = B0 / s0;
@@ -404,7 +420,8 @@ void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWor
 }
 void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                        const chicdiff_nbglm_out &out, hipStream_t st) {
-    wald_final_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w, o, out);
+    const int threads = d.S <= 16 ? 256 : 64;
+    wald_final_kernel<<<kRedBlocks, threads, (size_t)d.S * threads * sizeof(double), st>>>(counts, nf, d, w, o, out);
 }
 void launch_wald_intercept(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts,
                            const chicdiff_nbglm_out &out, hipStream_t st) {
