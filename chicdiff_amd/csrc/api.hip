@@ -237,34 +237,63 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
 }
 
 static int do_allreduce(chicdiff_hip_ctx *c, double *dev, int64_t count) {
-    if (c->world <= 1) return CHICDIFF_OK;
+    if (!c->allreduce) return CHICDIFF_OK;  // a callback registered with world_size 1 is still called (tests)
     if (c->allreduce(c->allreduce_user, dev, count) != 0) return fail(c, CHICDIFF_E_COMM, "all-reduce callback failed");
     return CHICDIFF_OK;
 }
 
 static double *sums_of(const FitWork &w) { return w.partials + (size_t)kRedBlocks * 72; }
 
+// ---- HIP backend of fit_driver.h -----------------------------------------------------------
+struct HipBackend {
+    chicdiff_hip_ctx *c;
+    FitDims d;
+    Opts o;
+    SelArgs sa;  // key source of the running select
+    int err = 0;
+    int world() const { return c->allreduce ? (c->world > 1 ? c->world : 2) : 1; }  // callback set => sharded protocol
+    int allreduce(double *buf, int64_t n) { return do_allreduce(c, buf, n); }
+    double *sums() { return sums_of(c->w); }
+    double *hist() { return c->w.hist; }
+    void trend_init() { launch_trend_init(d, c->w, o, c->stream); }
+    void trend_pass(bool fused) {
+        Scope t(c, "trend_pass");
+        launch_trend_pass(d, c->w, o, c->stream, fused);
+    }
+    void trend_step() { launch_trend_step(d, c->w, o, c->stream); }
+    const FitScalars *sync_scalars() {
+        hipError_t e = hipMemcpyAsync(c->h_sc, c->w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            err = fail(c, CHICDIFF_E_HIP, "reading fit scalars: %s", hipGetErrorString(e));
+            c->h_sc->finished = 1;  // stop the driver; the caller sees `err`
+        }
+        return c->h_sc;
+    }
+    void sel_count(const SelSpec &) {
+        Scope t(c, "select_count");
+        launch_sel_count(sa, c->w, c->stream);
+    }
+    void sel_begin(const SelSpec &) { launch_sel_begin(sa, c->w, c->stream); }
+    void sel_hist(const SelSpec &, int shift) {
+        Scope t(c, "select_hist");
+        sa.shift = shift;
+        launch_sel_hist(sa, c->w, c->stream);
+    }
+    void sel_step(const SelSpec &, int shift) {
+        Scope t(c, "select_step");
+        sa.shift = shift;
+        launch_sel_step(sa, c->w, c->stream);
+    }
+    void sel_finish(const SelSpec &) { launch_sel_finish(sa, c->w, c->stream); }
+};
+
 // exact medians by radix select; results land in w.sc (see sel_finish_kernel)
 static int run_select(chicdiff_hip_ctx *c, SelArgs a) {
-    hipStream_t st = c->stream;
-    {
-        Scope t(c, "select_count");
-        launch_sel_count(a, c->w, st);
-    }
-    int rc = do_allreduce(c, c->w.hist, a.ncol);
-    if (rc) return rc;
-    launch_sel_begin(a, c->w, st);
-    for (int r = 0; r < 6; r++) {
-        a.shift = kSelShifts[r];
-        {
-            Scope t(c, "select_hist");
-            launch_sel_hist(a, c->w, st);
-        }
-        if ((rc = do_allreduce(c, c->w.hist, (int64_t)a.ncol * 2 * kSelBins))) return rc;
-        Scope t(c, "select_step");
-        launch_sel_step(a, c->w, st);
-    }
-    launch_sel_finish(a, c->w, st);
+    HipBackend be{c, FitDims{}, Opts{}, a};
+    SelSpec spec{a.mode, a.ncol};
+    const int rc = drive_select(be, spec);
+    if (rc) return c->err[0] ? CHICDIFF_E_COMM : fail(c, CHICDIFF_E_COMM, "select: all-reduce failed");
     return CHICDIFF_OK;
 }
 
@@ -313,26 +342,13 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         Scope t(c, "disp_gene");
         launch_disp_gene(d_counts, d_nf, d, w, o, st);
     }
-    // trend: batches of passes, host polls the finished flag between batches
-    launch_trend_init(d, w, o, st);
-    int passes = 0;
-    for (;;) {
-        const int batch = passes == 0 ? 12 : 8;
-        for (int k = 0; k < batch; k++) {
-            {
-                Scope t(c, "trend_pass");
-                launch_trend_pass(d, w, o, st, c->world <= 1);
-            }
-            if (c->world > 1) {
-                if ((rc = do_allreduce(c, sums_of(w), kTrendSums))) return rc;
-                launch_trend_step(d, w, o, st);
-            }
-        }
-        passes += batch;
-        HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        if (c->h_sc->finished) break;
-        if (passes > 11 * 27 + 16) return fail(c, CHICDIFF_E_NUMERIC, "trend state machine did not finish");
+    // trend: fit_driver.h runs batches of IRLS passes and polls the finished flag between batches
+    {
+        HipBackend be{c, d, o, SelArgs{}};
+        const int trc = drive_trend(be);
+        if (be.err) return be.err;
+        if (trc == -1) return CHICDIFF_E_COMM;
+        if (trc == -2) return fail(c, CHICDIFF_E_NUMERIC, "trend state machine did not finish");
     }
     int status = 0;
     if (c->h_sc->failed) status |= CHICDIFF_ST_TREND_FAILED;

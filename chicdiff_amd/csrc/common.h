@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/chicdiff_hip.h"
+#include "fit_driver.h"
 #include "fit_state.h"
 
 namespace cd {
@@ -51,8 +52,7 @@ void launch_wald_intercept(const int32_t *counts, const double *nf, FitDims d, F
                            const chicdiff_nbglm_out &out, hipStream_t st);
 void launch_dev_sum_finish(FitDims d, FitWork w, hipStream_t st);
 
-// radix select over keys produced on the fly; `mode` picks the key generator
-enum SelMode { SEL_RESID = 0, SEL_ABSDEV = 1, SEL_SIZEFACTOR = 2 };
+// radix select over keys produced on the fly; `mode` (SelMode, fit_driver.h) picks the key generator
 struct SelArgs {
     int mode;
     int ncol;               // columns selected simultaneously (1, or S for size factors)

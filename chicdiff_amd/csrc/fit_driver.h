@@ -1,0 +1,62 @@
+// fit_driver.h — launch order of the fit's global steps, written once against a small backend
+// interface.  The HIP backend (api.hip) enqueues kernels on a stream and all-reduces device
+// buffers through the caller's callback; the CPU test backend (tests/harness/shard_harness.cpp)
+// runs plain loops over a row shard and all-reduces host buffers over gloo.  Same driver, same
+// state machines (fit_state.h), so the sharded control flow is exercised without a GPU.
+//
+// Backend concept:
+//   int  world() const;                       // ranks sharing the fit
+//   int  allreduce(double *buf, int64_t n);   // sum-all-reduce in place (backend memory); 0 = ok
+//   double *sums();  double *hist();          // backend buffers the driver hands to allreduce
+//   void trend_init(); void trend_pass(bool fused_step); void trend_step();
+//   const FitScalars *sync_scalars();         // make the scalars host-visible (may block)
+//   void sel_count(const SelSpec&); void sel_begin(const SelSpec&); void sel_hist(const SelSpec&, int shift);
+//   void sel_step(const SelSpec&, int shift); void sel_finish(const SelSpec&);
+#pragma once
+#include "fit_state.h"
+
+namespace cd {
+
+enum SelMode { SEL_RESID = 0, SEL_ABSDEV = 1, SEL_SIZEFACTOR = 2 };
+struct SelSpec {
+    int mode;
+    int ncol;  // columns selected simultaneously (1, or S for size factors)
+};
+
+// returns 0, or -1 (all-reduce failed) / -2 (state machine did not finish)
+template <class B>
+int drive_trend(B &be) {
+    be.trend_init();
+    int passes = 0;
+    for (;;) {
+        const int batch = passes == 0 ? 12 : 8;  // IRLS passes between two looks at the finished flag
+        for (int k = 0; k < batch; k++) {
+            const bool single = be.world() <= 1;
+            be.trend_pass(single);  // single rank: the reducing block also advances the state machine
+            if (!single) {
+                if (be.allreduce(be.sums(), kTrendSums)) return -1;
+                be.trend_step();
+            }
+        }
+        passes += batch;
+        if (be.sync_scalars()->finished) return 0;
+        if (passes > 11 * 27 + 16) return -2;
+    }
+}
+
+// exact medians (lower/upper middle order statistics) of `ncol` columns by 12-bit radix select
+template <class B>
+int drive_select(B &be, const SelSpec &a) {
+    be.sel_count(a);
+    if (be.allreduce(be.hist(), a.ncol)) return -1;
+    be.sel_begin(a);
+    for (int r = 0; r < 6; r++) {
+        be.sel_hist(a, kSelShifts[r]);
+        if (be.allreduce(be.hist(), (int64_t)a.ncol * 2 * kSelBins)) return -1;
+        be.sel_step(a, kSelShifts[r]);
+    }
+    be.sel_finish(a);
+    return 0;
+}
+
+}  // namespace cd

@@ -12,12 +12,13 @@ import os
 
 import numpy as np
 
+from .dist import ALLREDUCE_FN
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libchicdiff_hip.so")
 
 ST_TREND_FAILED, ST_PRIORVAR_MC, ST_BETA_NONCONV, ST_ALLZERO_ROWS = 1, 2, 4, 8
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 
 # every symbol include/chicdiff_hip.h declares (tests check the library exports each)
 EXPORTS = [
@@ -163,26 +164,10 @@ class HipContext:
 
     def set_process_group(self, group=None):
         """Route the library's sum-all-reduces through torch.distributed (backend nccl = RCCL)."""
-        import torch.distributed as dist
+        from .dist import AllReduceHook
 
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        torch = self.torch
-
-        class _Raw:  # expose a raw device pointer to torch through __cuda_array_interface__
-            def __init__(self, ptr, count):
-                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-        def cb(_user, dev_ptr, count):
-            try:
-                t = torch.as_tensor(_Raw(int(dev_ptr), int(count)), device=self.device)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                return 0
-            except Exception as e:  # never let an exception cross the C boundary
-                self._cb_error = e
-                return 1
-
-        self._cb = ALLREDUCE_FN(cb)
-        self._check(self.lib.chicdiff_hip_set_allreduce(self.h, self._cb, None, world, rank))
+        self._hook = AllReduceHook(group, memory="device", device=self.device)
+        self._check(self.lib.chicdiff_hip_set_allreduce(self.h, self._hook.fn, None, self._hook.world, self._hook.rank))
 
     def to_device(self, a, dtype):
         """(n, S) host array -> (S, n) contiguous device tensor (sample-major)."""

@@ -55,8 +55,9 @@ const char *chicdiff_hip_last_error(const chicdiff_hip_ctx *ctx); /* ctx may be 
 /* hipStream_t to enqueue on (NULL = HIP's null stream).  Until this is called the context
  * uses a private non-blocking stream. */
 int chicdiff_hip_set_stream(chicdiff_hip_ctx *ctx, void *hip_stream);
-/* world_size > 1 turns every global statistic (size-factor medians, nf column means, trend
- * sums, MAD medians, deviance sums) into local partials + one callback. */
+/* A non-NULL callback turns every global statistic (size-factor medians, nf column means, trend
+ * sums, MAD medians, deviance sums) into local partials + one callback (also with world_size 1,
+ * where the all-reduce is the identity); fn = NULL restores the single-process path. */
 int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, void *user,
                                int32_t world_size, int32_t rank);
 

@@ -1,0 +1,114 @@
+"""The row-sharded (N > 1) path on CPU: world_size 2 over gloo.
+
+The product's driver (chicdiff_amd/csrc/fit_driver.h) and state machines (fit_state.h) are
+compiled into a test-only CPU backend (tests/harness/shard_harness.cpp); each rank holds a row
+shard, every global sum goes through chicdiff_amd.dist.AllReduceHook (the same callback type the
+HIP library calls, here on host memory), and the result must equal the single-rank oracle."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS_SRC = os.path.join(ROOT, "tests", "harness", "shard_harness.cpp")
+HARNESS_SO = os.path.join(ROOT, "tests", "harness", "libshard_harness.so")
+
+
+def build_harness():
+    if not os.path.exists(HARNESS_SO) or os.path.getmtime(HARNESS_SO) < max(
+            os.path.getmtime(HARNESS_SRC), os.path.getmtime(os.path.join(ROOT, "chicdiff_amd", "csrc", "fit_state.h")),
+            os.path.getmtime(os.path.join(ROOT, "chicdiff_amd", "csrc", "fit_driver.h"))):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", HARNESS_SO, HARNESS_SRC], check=True)
+    from chicdiff_amd.dist import ALLREDUCE_FN
+    L = C.CDLL(HARNESS_SO)
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    L.harness_trend_mad.argtypes = [pd, pd, pi, C.c_int64, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                                    ALLREDUCE_FN, C.c_void_p, pd]
+    L.harness_size_factors.argtypes = [pi, C.c_int64, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p, pd]
+    return L
+
+
+def _worker(rank, world, port, n, S, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from chicdiff_amd import synth
+    from chicdiff_amd.dist import AllReduceHook, shard_bounds
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = build_harness()
+        d = synth.make(n, S)
+        ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"])  # per-row inputs of the global steps + expected scalars
+        lo, hi = shard_bounds(n, world, rank)
+        hook = AllReduceHook(memory="host")
+        f = lambda a, t: np.ascontiguousarray(a[lo:hi], dtype=t)
+        bm, dg, az = f(ref["baseMean"], np.float64), f(np.nan_to_num(ref["dispGeneEst"]), np.float64), f(ref["allZero"], np.int32)
+        out = np.zeros(8)
+        pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        rc = L.harness_trend_mad(bm.ctypes.data_as(pd), dg.ctypes.data_as(pd), az.ctypes.data_as(pi), hi - lo, 1e-8, S, 2,
+                                 float("nan"), world, hook.fn, None, out.ctypes.data_as(pd))
+        assert rc == 0 and hook.error is None, (rc, hook.error)
+        k = np.asfortranarray(d["counts"][lo:hi].astype(np.int32))
+        sf = np.zeros(S)
+        rc = L.harness_size_factors(k.ctypes.data_as(pi), hi - lo, S, world, hook.fn, None, sf.ctypes.data_as(pd))
+        assert rc == 0 and hook.error is None, (rc, hook.error)
+        q.put((rank, out.tolist(), sf.tolist(), hook.calls, ref["trendCoef"].tolist(), ref["varLogDispEsts"],
+               ref["dispPriorVar"], ref["trendOuterIter"], oracle.size_factors(d["counts"]).tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,S", [(6001, 8), (3000, 4)])
+def test_sharded_global_steps_match_single_rank_oracle(n, S):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, out, sf, calls, coefs, varlog, prior, outer, sf_ref in res:
+        assert calls > 20  # trend passes + 3 selects x 7 all-reduces really went through gloo
+        assert np.allclose(out[:2], coefs, rtol=1e-9), (out, coefs)
+        assert np.isclose(out[2], varlog, rtol=1e-9) and np.isclose(out[3], prior, rtol=1e-9)
+        assert int(out[4]) == outer and out[5] == 0
+        assert np.allclose(sf, sf_ref, rtol=1e-13)
+    # both ranks end with bit-identical scalars (they consumed the same all-reduced sums)
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+
+
+def test_single_rank_harness_matches_oracle():
+    """world_size 1: no callback involved; the driver + state machines alone reproduce the oracle."""
+    sys.path.insert(0, ROOT)
+    from chicdiff_amd import synth
+    from chicdiff_amd.dist import ALLREDUCE_FN, shard_bounds
+    from oracle import oracle
+    assert [shard_bounds(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    L = build_harness()
+    d = synth.make(5000, 6)
+    ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"])
+    out = np.zeros(8)
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    bm = np.ascontiguousarray(ref["baseMean"])
+    dg = np.ascontiguousarray(np.nan_to_num(ref["dispGeneEst"]))
+    az = np.ascontiguousarray(ref["allZero"], dtype=np.int32)
+    null_cb = C.cast(None, ALLREDUCE_FN)
+    rc = L.harness_trend_mad(bm.ctypes.data_as(pd), dg.ctypes.data_as(pd), az.ctypes.data_as(pi), len(bm), 1e-8, 6, 2,
+                             float("nan"), 1, null_cb, None, out.ctypes.data_as(pd))
+    assert rc == 0
+    assert np.allclose(out[:2], ref["trendCoef"], rtol=1e-10)
+    assert np.isclose(out[2], ref["varLogDispEsts"], rtol=1e-10) and np.isclose(out[3], ref["dispPriorVar"], rtol=1e-10)
+    k = np.asfortranarray(d["counts"].astype(np.int32))
+    sf = np.zeros(6)
+    assert L.harness_size_factors(k.ctypes.data_as(pi), len(k), 6, 1, null_cb, None, sf.ctypes.data_as(pd)) == 0
+    assert np.allclose(sf, oracle.size_factors(d["counts"]), rtol=1e-13)

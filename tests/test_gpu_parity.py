@@ -209,3 +209,30 @@ def test_host_entry_point_and_errors(ctx, oracle):
     bad[5, 2] = np.iinfo(np.int32).min  # NA_integer_
     with pytest.raises(hip.ChicdiffHipError):
         ctx.nbglm_fit_host(bad, d["nf"], d["group"])
+
+
+def test_allreduce_hook_on_device_single_rank(ctx, oracle):
+    """The sharded protocol end to end on one GPU: a 1-rank RCCL group, every global sum goes
+    through chicdiff_amd.dist.AllReduceHook on DEVICE memory (identity all-reduce), results must
+    equal the fused single-process path bit for bit."""
+    import torch.distributed as dist
+    from chicdiff_amd import hip
+    d = synth.make(20000, 8)
+    dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64)
+    base, sc0 = ctx.nbglm_fit(dk, dn, d["group"])
+    base = {k: v.clone() for k, v in base.items()}
+    sf0 = ctx.size_factors(dk)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1)
+    try:
+        c2 = hip.HipContext(0)
+        c2.set_process_group()
+        out, sc1 = c2.nbglm_fit(dk, dn, d["group"])
+        sf1 = c2.size_factors(dk)
+        assert c2._hook.error is None and c2._hook.calls > 20
+        for k in base:
+            assert np.array_equal(base[k].cpu().numpy(), out[k].cpu().numpy(), equal_nan=True), k
+        assert np.array_equal(sc0["trendCoef"], sc1["trendCoef"]) and sc0["dispPriorVar"] == sc1["dispPriorVar"]
+        assert np.array_equal(sf0, sf1)
+        c2.close()
+    finally:
+        dist.destroy_process_group()
