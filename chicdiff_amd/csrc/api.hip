@@ -447,7 +447,7 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const dou
     const size_t cb = sizeof(int32_t) * (size_t)n * S, fb = sizeof(double) * (size_t)n * S;
     const size_t nd = (sizeof(double) * (size_t)n + 255) & ~(size_t)255;
     char *buf = nullptr;
-    HIPCHK(c, hipMalloc((void **)&buf, ((cb + 255) & ~(size_t)255) + fb + 256 + nd * 20));
+    HIPCHK(c, hipMalloc((void **)&buf, ((cb + 255) & ~(size_t)255) + fb + 256 + nd * 22));
     int32_t *d_counts = (int32_t *)buf;
     double *d_nf = (double *)(buf + ((cb + 255) & ~(size_t)255));
     char *po = (char *)d_nf + ((fb + 255) & ~(size_t)255);
@@ -459,10 +459,10 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const dou
     double **dd[] = {&dout.baseMean, &dout.baseVar, &dout.dispGeneEst, &dout.dispFit, &dout.dispMAP, &dout.dispersion,
                      &dout.log2FoldChange, &dout.lfcSE, &dout.stat, &dout.pvalue, &dout.intercept, &dout.interceptSE,
                      &dout.deviance, &dout.maxCooks};
-    int32_t *const *hi[] = {&ho.dispGeneIter, &ho.dispIter, &ho.dispOutlier, &ho.betaConv, &ho.betaIter, &ho.allZero};
-    int32_t **di[] = {&dout.dispGeneIter, &dout.dispIter, &dout.dispOutlier, &dout.betaConv, &dout.betaIter, &dout.allZero};
+    int32_t *const *hi[] = {&ho.dispGeneIter, &ho.dispIter, &ho.dispOutlier, &ho.betaConv, &ho.betaIter, &ho.allZero, &ho.cooksArgmax};
+    int32_t **di[] = {&dout.dispGeneIter, &dout.dispIter, &dout.dispOutlier, &dout.betaConv, &dout.betaIter, &dout.allZero, &dout.cooksArgmax};
     for (int k = 0; k < 14; k++) { if (*hd[k]) *dd[k] = (double *)po; po += nd; }
-    for (int k = 0; k < 6; k++) { if (*hi[k]) *di[k] = (int32_t *)po; po += nd; }
+    for (int k = 0; k < 7; k++) { if (*hi[k]) *di[k] = (int32_t *)po; po += nd; }
     int rc = CHICDIFF_OK;
     hipError_t e;
     if ((e = hipMemcpyAsync(d_counts, counts, cb, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
@@ -473,7 +473,7 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const dou
         for (int k = 0; k < 14 && !rc; k++)
             if (*hd[k] && (e = hipMemcpy(*hd[k], *dd[k], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess)
                 rc = fail(c, CHICDIFF_E_HIP, "D2H copy: %s", hipGetErrorString(e));
-        for (int k = 0; k < 6 && !rc; k++)
+        for (int k = 0; k < 7 && !rc; k++)
             if (*hi[k] && (e = hipMemcpy(*hi[k], *di[k], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess)
                 rc = fail(c, CHICDIFF_E_HIP, "D2H copy: %s", hipGetErrorString(e));
     }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
     for (int64_t i = blockIdx.x * (int64_t)T + tid; i < n; i += (int64_t)gridDim.x * T) {
         const bool az = w.allZero[i];
         double B0 = NAN, B1 = NAN, s0 = NAN, s1 = NAN, st = NAN, pv = NAN, dv = NAN, mc = NAN;
-        int bconv = 0, biter = 0;
+        int bconv = 0, biter = 0, amax = -1;
         if (!az) {
             const double alpha = w.disp[i], size = rcp(alpha);
             const double b0 = w.beta0[i], b1 = w.beta1[i];
@@ -279,9 +279,9 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
                 }
                 const double arob = fmax((vmax - m) / (m * m), 0.04);
                 mc = -INFINITY;
+                double call = -INFINITY;  // which.max(cooks[i, ]) runs over ALL samples
                 for (int j = 0; j < S; j++) {
                     const bool g = (d.gmask >> j) & 1;
-                    if ((g ? d.nB : d.nA) < 3) continue;
                     const double nfj = nf[(int64_t)j * n + i];
                     const double yc = (double)counts[(int64_t)j * n + i];
                     const double muf = nfj * (g ? E1 : E0);
@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
                     const double h = wj * (g ? (i00 + 2 * i01 + i11) : i00);
                     const double V = muf + arob * muf * muf;
                     const double ck = (yc - muf) * (yc - muf) / V / 2.0 * h / ((1 - h) * (1 - h));
-                    if (ck > mc) mc = ck;
+                    if (ck > call) { call = ck; amax = j; }
+                    if ((g ? d.nB : d.nA) >= 3 && ck > mc) mc = ck;
                 }
             }
             v[0] += dv;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
         if (out.maxCooks) out.maxCooks[i] = mc;
         if (out.betaConv) out.betaConv[i] = bconv;
         if (out.betaIter) out.betaIter[i] = biter;
+        if (out.cooksArgmax) out.cooksArgmax[i] = amax;
     }
     // block partials: 3 values (blocks of 64..256 threads)
     __shared__ double red[3][4];
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256) void wald_intercept_kernel(const int32_t *__re
         if (out.maxCooks) out.maxCooks[i] = NAN;
         if (out.betaConv) out.betaConv[i] = az ? 0 : 1;
         if (out.betaIter) out.betaIter[i] = az ? 0 : 1;
+        if (out.cooksArgmax) out.cooksArgmax[i] = -1;
     }
     __shared__ double red[3][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

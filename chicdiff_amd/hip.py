@@ -38,7 +38,7 @@ class Opts(C.Structure):
 
 OUT_DOUBLE = ["baseMean", "baseVar", "dispGeneEst", "dispFit", "dispMAP", "dispersion", "log2FoldChange",
               "lfcSE", "stat", "pvalue", "intercept", "interceptSE", "deviance", "maxCooks"]
-OUT_INT = ["dispGeneIter", "dispIter", "dispOutlier", "betaConv", "betaIter", "allZero"]
+OUT_INT = ["dispGeneIter", "dispIter", "dispOutlier", "betaConv", "betaIter", "allZero", "cooksArgmax"]
 
 
 class Out(C.Structure):

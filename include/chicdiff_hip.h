@@ -93,6 +93,7 @@ typedef struct {
     double *deviance;       /* mcols(dds)$deviance = -2 logLik                       */
     double *maxCooks;       /* NaN unless a group has >= 3 samples                   */
     int32_t *dispGeneIter, *dispIter, *dispOutlier, *betaConv, *betaIter, *allZero;
+    int32_t *cooksArgmax;   /* 0-based sample with the largest Cook's distance (-1 if none)   */
 } chicdiff_nbglm_out;
 
 typedef struct {

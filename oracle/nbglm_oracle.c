@@ -530,7 +530,7 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
             SET(dispMAP, i, NAN); SET(dispersion, i, NAN); SET(dispIter, i, 0); SET(dispOutlier, i, 0);
             SET(beta0, i, NAN); SET(beta1, i, NAN); SET(se0, i, NAN); SET(se1, i, NAN);
             SET(stat, i, NAN); SET(pvalue, i, NAN); SET(deviance, i, NAN);
-            SET(betaConv, i, 0); SET(betaIter, i, 0); SET(maxCooks, i, NAN);
+            SET(betaConv, i, 0); SET(betaIter, i, 0); SET(maxCooks, i, NAN); SET(cooksArgmax, i, -1);
             if (out->mu) for (int j = 0; j < S; j++) out->mu[(int64_t)j * n + i] = NAN;
             sumdev += NAN;
             continue;
@@ -572,7 +572,7 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
             double se = LOG2E * sqrt(1.0 / xtwx), st = beta / se;
             SET(beta0, i, beta); SET(beta1, i, NAN); SET(se0, i, se); SET(se1, i, NAN);
             SET(stat, i, st); SET(pvalue, i, oracle_pnorm_two_sided(st));
-            SET(deviance, i, -2.0 * ll); SET(betaConv, i, 1); SET(betaIter, i, 1); SET(maxCooks, i, NAN);
+            SET(deviance, i, -2.0 * ll); SET(betaConv, i, 1); SET(betaIter, i, 1); SET(maxCooks, i, NAN); SET(cooksArgmax, i, -1);
             sumdev += -2.0 * ll;
             continue;
         }
@@ -602,14 +602,19 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
             if (cellsize[0] >= 3 || cellsize[1] >= 3) {
                 double arob = robust_mom_disp(q, g, S, cellsize);
                 mc = -INFINITY;
+                double call = -INFINITY;
+                int amax = -1;
                 for (int j = 0; j < S; j++) {
-                    if (cellsize[g[j]] < 3) continue;
                     double V = muf[j] + arob * muf[j] * muf[j];
                     double pr = (y[j] - muf[j]) * (y[j] - muf[j]) / V;
                     double h = fb.hat[j];
                     double ck = pr / p * h / ((1 - h) * (1 - h));
-                    if (ck > mc) mc = ck;
+                    if (ck > call) { call = ck; amax = j; }
+                    if (cellsize[g[j]] >= 3 && ck > mc) mc = ck;
                 }
+                SET(cooksArgmax, i, amax);
+            } else {
+                SET(cooksArgmax, i, -1);
             }
             out->maxCooks[i] = mc;
         }

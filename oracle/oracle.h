@@ -56,6 +56,7 @@ typedef struct {
     double *deviance;
     int32_t *betaConv, *betaIter;
     double *maxCooks;      /* NaN unless some group has >= 3 samples               */
+    int32_t *cooksArgmax;  /* which.max(cooks[i,]) - 1 over all samples; -1 if not computed */
     double *mu;            /* n x S column-major, fitted mean of the Wald fit      */
     /* scalars */
     double trendCoef[2];   /* asymptDisp, extraPois                              */

@@ -43,7 +43,7 @@ _OUT_FIELDS = [("baseMean", _PD), ("baseVar", _PD), ("allZero", _PI), ("dispInit
                ("dispGeneEst", _PD), ("dispGeneIter", _PI), ("dispFit", _PD), ("dispMAP", _PD),
                ("dispersion", _PD), ("dispIter", _PI), ("dispOutlier", _PI), ("beta0", _PD),
                ("beta1", _PD), ("se0", _PD), ("se1", _PD), ("stat", _PD), ("pvalue", _PD),
-               ("deviance", _PD), ("betaConv", _PI), ("betaIter", _PI), ("maxCooks", _PD), ("mu", _PD)]
+               ("deviance", _PD), ("betaConv", _PI), ("betaIter", _PI), ("maxCooks", _PD), ("cooksArgmax", _PI), ("mu", _PD)]
 
 
 class Out(C.Structure):

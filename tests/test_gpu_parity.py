@@ -236,3 +236,95 @@ def test_allreduce_hook_on_device_single_rank(ctx, oracle):
         c2.close()
     finally:
         dist.destroy_process_group()
+
+
+def _make_tables(n, S, F, tmp_path, seed=0):
+    """Synthetic RU + long FullRegionData in the reference's schema (chicdiff.R:392-425, :912-925) + an rmap file."""
+    import pandas as pd
+    d = synth.make(n, S, fragments=F)
+    keep = d["counts"].sum(1) > 0  # every region has a count somewhere (the reference needs that for the theta grid)
+    idx = np.nonzero(keep)[0]
+    n2 = len(idx)
+    rng = np.random.default_rng(seed)
+    bait = 1000 + (np.arange(n2) // 7) * 40                       # a bait every 40 fragments, 7 regions per bait
+    oe0 = bait + 2 + (np.arange(n2) % 7) * F
+    region = np.repeat(np.arange(1, n2 + 1), F)
+    oe = (oe0[:, None] + np.arange(F)[None, :]).ravel()
+    RU = pd.DataFrame({"baitID": np.repeat(bait, F), "regionID": region, "otherEndID": oe})
+    samples = [f"s{j}" for j in range(S)]
+    conds = ["Mono" if g else "CD4" for g in d["group"]]
+    fN = d["fragN"].reshape(n, F, S)[idx].reshape(n2 * F, S)
+    fM = d["fragFullMean"].reshape(n, F, S)[idx].reshape(n2 * F, S)
+    long = pd.DataFrame({
+        "baitID": np.tile(RU["baitID"].to_numpy(), S), "otherEndID": np.tile(oe, S), "regionID": np.tile(region, S),
+        "sample": np.repeat(samples, n2 * F), "N": fN.T.ravel(), "FullMean": fM.T.ravel(),
+        "condition": np.repeat(conds, n2 * F)})
+    # recast layout: rows of one (region, fragment) are sample-major; then shuffle regions to exercise the sort
+    long = long.sort_values(["regionID", "otherEndID"], kind="stable").reset_index(drop=True)
+    maxid = int(oe.max()) + 50
+    rmap = pd.DataFrame({"chr": ['"19"'] * maxid, "start": np.arange(maxid) * 1000 + 1, "end": np.arange(maxid) * 1000 + 1000,
+                         "id": np.arange(1, maxid + 1)})
+    path = tmp_path / "test.rmap"
+    rmap.to_csv(path, sep=" ", header=False, index=False, quoting=3)
+    counts = d["counts"][idx]
+    _, FM = None, fM.reshape(n2, F, S).sum(axis=1)
+    return RU, long, str(path), counts, FM, d["group"], fN, fM
+
+
+@pytest.mark.parametrize("norm", ["combined", "fullmean", "standard"])
+def test_deseq2wrap_mirror(ctx, oracle, tmp_path, norm):
+    """The host mirror of DESeq2Wrap() (chicdiff.R:1494) against the same pipeline composed from the oracle."""
+    from chicdiff_amd import results
+    from chicdiff_amd.deseq2wrap import DESeq2Wrap
+    RU, long, rmapfile, counts, _, group, fN, fM = _make_tables(2500, 8, 5, tmp_path)
+    n = len(counts)
+    settings = {"norm": norm, "theta": None, "theta_grid": [0, 0.25, 0.5, 0.75, 1], "rmapfile": rmapfile,
+                "saveAuxData": False, "outprefix": str(tmp_path / "x")}
+    out = DESeq2Wrap(settings, RU, long, ctx=ctx)
+    assert list(out.columns) == ["baseMean", "log2FoldChange", "lfcSE", "stat", "pvalue", "padj", "baitID", "maxOE",
+                                 "minOE", "regionID", "OEchr", "OEstart", "OEend", "baitchr", "baitstart", "baitend"]
+    assert np.array_equal(out["regionID"].to_numpy(), np.arange(1, n + 1))
+    # oracle pipeline
+    rp = np.arange(0, (n + 1) * 5, 5, dtype=np.int64)
+    N, FM = oracle.window_sums(fN, fM, rp)
+    assert np.array_equal(N, counts)
+    sf = oracle.size_factors(N)
+    if norm == "standard":
+        nf = np.tile(sf, (n, 1))
+    elif norm == "fullmean":
+        nf = oracle.offsets(FM, sf, None)
+    else:
+        g0 = np.zeros(8, dtype=np.int32)
+        devs = [oracle.nbglm_fit(N, oracle.offsets(FM, sf, th), g0)["sumDeviance"] for th in settings["theta_grid"]]
+        tt = settings["theta_grid"][int(np.argmin(devs))]
+        assert out.attrs["theta"] == tt
+        nf = oracle.offsets(FM, sf, tt)
+    ref = oracle.nbglm_fit(N, nf, group)
+    check_close("lfc", out["log2FoldChange"].to_numpy(), ref["log2FoldChange"], np.abs(ref["log2FoldChange"]) > 1e-3, 1e-6, 0.999)
+    pv, nout = results.cooks_filter(ref["pvalue"], ref["maxCooks"], ref["cooksArgmax"], lambda idx: N[idx], group)
+    got_p = out["pvalue"].to_numpy()
+    assert np.array_equal(np.isnan(got_p), np.isnan(pv)) and nout > 0  # Cook's outliers flagged identically (4v4)
+    ok = ~np.isnan(pv)
+    check_close("pvalue", got_p, pv, ok, 1e-6, 0.999)
+    padj_ref, _ = results.independent_filtering(ref["baseMean"], pv)
+    got = out["padj"].to_numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(padj_ref))
+    okp = ~np.isnan(padj_ref)
+    check_close("padj", got, padj_ref, okp, 1e-6, 0.999)
+    # annotation: window bounds and rmap coordinates (chicdiff.R:1703-1714)
+    r0 = out.iloc[0]
+    assert r0["minOE"] == RU[RU.regionID == 1].otherEndID.min() and r0["OEstart"] == (r0["minOE"] - 1) * 1000 + 1
+    assert r0["OEend"] == r0["maxOE"] * 1000 and r0["baitstart"] == (r0["baitID"] - 1) * 1000 + 1
+
+
+def test_deseq2wrap_argument_handling(ctx, tmp_path):
+    from chicdiff_amd.deseq2wrap import DESeq2Wrap
+    RU, long, rmapfile, *_ = _make_tables(600, 4, 3, tmp_path)
+    base = {"theta": None, "theta_grid": [0, 0.5, 1], "rmapfile": rmapfile, "saveAuxData": False, "outprefix": ""}
+    with pytest.raises(ValueError, match="Unknown normalisation method"):
+        DESeq2Wrap(dict(base, norm="median"), RU, long, ctx=ctx)
+    with pytest.warns(UserWarning, match='equivalent to norm = "standard"'):
+        out = DESeq2Wrap(dict(base, norm="combined"), RU, long, theta=1, ctx=ctx)
+    assert "theta" not in out.attrs
+    out = DESeq2Wrap(dict(base, norm="combined", theta=0.25), RU, long, ctx=ctx)  # theta from the settings list
+    assert out.attrs["theta"] == 0.25
