@@ -1,0 +1,110 @@
+/*
+ * chicdiff_hip_shim.c — the `.Call` shim a Chicdiff maintainer adds to reach the HIP library.
+ *
+ * NOT compiled or tested in this repository: R (R.h / Rinternals.h / libR) is absent from the
+ * authoring image and from the GPU box.  It is kept deliberately thin:
+ * every code path it reaches is the C ABI of include/chicdiff_hip.h, which IS tested (through
+ * the ctypes binding in chicdiff_amd/hip.py).  Build where R exists:
+ *     R CMD SHLIB chicdiff_hip_shim.c -I../../include -L../../chicdiff_amd/lib -lchicdiff_hip
+ *
+ * It replaces, inside DESeq2Wrap (chicdiff.R:1494), the DESeq2 calls at chicdiff.R:1557-1674:
+ *   estimateSizeFactors            -> chicdiff_hip_size_factors      (host wrapper below)
+ *   normalizationFactors<- / sc    -> chicdiff_hip_offsets           ( " )
+ *   estimateDispersions + nbinomWaldTest -> chicdiff_hip_nbglm_fit
+ * R matrices are column-major, so INTEGER(counts) / REAL(nf) are passed through untransposed.
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include <string.h>
+
+#include "chicdiff_hip.h"
+
+static chicdiff_hip_ctx *g_ctx = NULL;
+
+static chicdiff_hip_ctx *ctx_or_error(void) {
+    if (!g_ctx) {
+        int rc = chicdiff_hip_create(&g_ctx, 0);
+        if (rc) Rf_error("chicdiff_hip: %s", chicdiff_hip_last_error(NULL));
+    }
+    return g_ctx;
+}
+
+static SEXP named_list(int n, const char **names) {
+    SEXP l = PROTECT(Rf_allocVector(VECSXP, n)), nm = PROTECT(Rf_allocVector(STRSXP, n));
+    for (int i = 0; i < n; i++) SET_STRING_ELT(nm, i, Rf_mkChar(names[i]));
+    Rf_setAttrib(l, R_NamesSymbol, nm);
+    UNPROTECT(2);
+    return l;
+}
+
+/* .Call("chicdiff_hip_fit", counts (integer n x S), nf (double n x S), group (integer S, 0/1),
+ *       dispPriorVar (double, NA = estimate))  ->  named list */
+SEXP chicdiff_hip_fit(SEXP counts, SEXP nf, SEXP group, SEXP dispPriorVar) {
+    if (!Rf_isInteger(counts) || !Rf_isReal(nf) || !Rf_isInteger(group)) Rf_error("chicdiff_hip_fit: bad argument types");
+    SEXP dim = Rf_getAttrib(counts, R_DimSymbol);
+    if (Rf_length(dim) != 2) Rf_error("chicdiff_hip_fit: counts must be a matrix");
+    const R_xlen_t n = INTEGER(dim)[0];
+    const int S = INTEGER(dim)[1];
+    if (XLENGTH(nf) != n * S || LENGTH(group) != S) Rf_error("chicdiff_hip_fit: shapes do not match");
+    chicdiff_hip_ctx *c = ctx_or_error();
+
+    static const char *names[] = {"baseMean", "dispGeneEst", "dispFit", "dispersion", "log2FoldChange", "lfcSE", "stat",
+                                  "pvalue", "deviance", "maxCooks", "betaConv", "cooksArgmax", "trendCoef",
+                                  "dispPriorVar", "sumDeviance", "status"};
+    SEXP out = PROTECT(named_list(16, names));
+    chicdiff_nbglm_out o;
+    memset(&o, 0, sizeof o);
+    double **dst[] = {&o.baseMean, &o.dispGeneEst, &o.dispFit, &o.dispersion, &o.log2FoldChange, &o.lfcSE, &o.stat,
+                      &o.pvalue, &o.deviance, &o.maxCooks};
+    for (int k = 0; k < 10; k++) {
+        SEXP v = Rf_allocVector(REALSXP, n);
+        SET_VECTOR_ELT(out, k, v); /* protected by `out` */
+        *dst[k] = REAL(v);
+    }
+    SEXP bc = Rf_allocVector(INTSXP, n);
+    SET_VECTOR_ELT(out, 10, bc);
+    o.betaConv = INTEGER(bc);
+    SEXP am = Rf_allocVector(INTSXP, n);
+    SET_VECTOR_ELT(out, 11, am);
+    o.cooksArgmax = INTEGER(am);
+
+    chicdiff_nbglm_opts opts;
+    chicdiff_hip_default_opts(&opts);
+    if (Rf_length(dispPriorVar) == 1 && !ISNA(Rf_asReal(dispPriorVar))) opts.dispPriorVar = Rf_asReal(dispPriorVar);
+    chicdiff_nbglm_scalars sc;
+    const int rc = chicdiff_hip_nbglm_fit(c, INTEGER(counts), REAL(nf), (int64_t)n, S, INTEGER(group), &opts, &o, &sc);
+    if (rc) {
+        /* copy the message before longjmp-ing out; `out` is released by UNPROTECT */
+        char msg[512];
+        strncpy(msg, chicdiff_hip_last_error(c), sizeof msg - 1);
+        msg[sizeof msg - 1] = 0;
+        UNPROTECT(1);
+        Rf_error("chicdiff_hip_fit: %s", msg);
+    }
+    /* NaN -> NA_real_ for all-zero rows is left to the R wrapper (is.nan -> NA) */
+    SEXP tc = Rf_allocVector(REALSXP, 2);
+    SET_VECTOR_ELT(out, 12, tc);
+    REAL(tc)[0] = sc.trendCoef[0];
+    REAL(tc)[1] = sc.trendCoef[1];
+    SET_VECTOR_ELT(out, 13, Rf_ScalarReal(sc.dispPriorVar));
+    SET_VECTOR_ELT(out, 14, Rf_ScalarReal(sc.sumDeviance));
+    SET_VECTOR_ELT(out, 15, Rf_ScalarInteger(sc.status));
+    UNPROTECT(1);
+    return out;
+}
+
+static const R_CallMethodDef call_methods[] = {{"chicdiff_hip_fit", (DL_FUNC)&chicdiff_hip_fit, 4}, {NULL, NULL, 0}};
+
+void R_init_chicdiffhip(DllInfo *dll) {
+    R_registerRoutines(dll, NULL, call_methods, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}
+
+void R_unload_chicdiffhip(DllInfo *dll) {
+    (void)dll;
+    if (g_ctx) {
+        chicdiff_hip_destroy(g_ctx);
+        g_ctx = NULL;
+    }
+}
