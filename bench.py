@@ -85,15 +85,12 @@ def main():
         ctx.set_process_group()
     dk = ctx.to_device(d["counts"], np.int32)
     dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)  # region-level FullMean (window sums)
-    dnf = torch.empty_like(dfm)
     group = d["group"]
     want = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue"]
     outputs = {}
 
     def step():
-        sf = ctx.size_factors(dk)
-        ctx.offsets(dfm, sf, args.theta, out=dnf)
-        return ctx.nbglm_fit(dk, dnf, group, want=want, outputs=outputs)
+        return ctx.wald_test(dk, dfm, group, theta=args.theta, want=want, outputs=outputs)
 
     def barrier():
         if dist is not None:
@@ -107,13 +104,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sf = ctx.size_factors(dk)
-        for k, (ms, cnt) in ctx.kernel_times().items():
-            a = ktimes.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
-        ctx.offsets(dfm, sf, args.theta, out=dnf)
-        for k, (ms, cnt) in ctx.kernel_times().items():
-            a = ktimes.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
-        _, sc = ctx.nbglm_fit(dk, dnf, group, want=want, outputs=outputs)
+        _, sc = step()
         for k, (ms, cnt) in ctx.kernel_times().items():
             a = ktimes.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
     barrier()

@@ -43,6 +43,8 @@ struct chicdiff_hip_ctx {
     bool timing = false;
     std::vector<KTimer> timers;
     std::vector<std::pair<int, hipEvent_t>> pending;
+    std::vector<hipEvent_t> event_pool;  // recycled: creating events per launch cost ~0.9 ms per step
+    int scope_depth = 0;                 // nested scopes are folded into the outermost one
 };
 
 static char g_create_err[512];
@@ -103,10 +105,7 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (auto &t : c->timers) {
-        if (t.e0) (void)hipEventDestroy(t.e0);
-        if (t.e1) (void)hipEventDestroy(t.e1);
-    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->h_sc) (void)hipHostFree(c->h_sc);
@@ -145,6 +144,7 @@ struct Scope {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     Scope(chicdiff_hip_ctx *c_, const char *name) : c(c_) {
         if (!c->timing) return;
+        if (c->scope_depth++ > 0) return;  // inside an outer scope: no events of its own
         for (size_t i = 0; i < c->timers.size(); i++)
             if (c->timers[i].name == name) idx = (int)i;
         if (idx < 0) {
@@ -153,12 +153,24 @@ struct Scope {
             c->timers.push_back(t);
             idx = (int)c->timers.size() - 1;
         }
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
+        e0 = take();
+        e1 = take();
         (void)hipEventRecord(e0, c->stream);
+    }
+    hipEvent_t take() {
+        hipEvent_t e = nullptr;
+        if (!c->event_pool.empty()) {
+            e = c->event_pool.back();
+            c->event_pool.pop_back();
+        } else {
+            (void)hipEventCreate(&e);
+        }
+        return e;
     }
     ~Scope() {
         if (!c->timing) return;
+        c->scope_depth--;
+        if (idx < 0) return;
         (void)hipEventRecord(e1, c->stream);
         c->pending.push_back({idx, e0});
         c->pending.push_back({idx, e1});
@@ -178,8 +190,8 @@ static void timing_collect(chicdiff_hip_ctx *c) {
         (void)hipEventElapsedTime(&ms, c->pending[i].second, c->pending[i + 1].second);
         c->timers[c->pending[i].first].ms += ms;
         c->timers[c->pending[i].first].launches++;
-        (void)hipEventDestroy(c->pending[i].second);
-        (void)hipEventDestroy(c->pending[i + 1].second);
+        c->event_pool.push_back(c->pending[i].second);
+        c->event_pool.push_back(c->pending[i + 1].second);
     }
     c->pending.clear();
 }
@@ -344,6 +356,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     }
     // trend: fit_driver.h runs batches of IRLS passes and polls the finished flag between batches
     {
+        Scope t(c, "trend_fit");
         HipBackend be{c, d, o, SelArgs{}};
         const int trc = drive_trend(be);
         if (be.err) return be.err;
@@ -358,11 +371,14 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     sa.n = d.n;
     sa.ncol = 1;
     sa.resid = w.resid;
-    sa.mode = SEL_RESID;
-    if ((rc = run_select(c, sa))) return rc;
-    sa.mode = SEL_ABSDEV;
-    if ((rc = run_select(c, sa))) return rc;
-    launch_prior_var(d, w, o, st);
+    {
+        Scope t(c, "mad_select");
+        sa.mode = SEL_RESID;
+        if ((rc = run_select(c, sa))) return rc;
+        sa.mode = SEL_ABSDEV;
+        if ((rc = run_select(c, sa))) return rc;
+        launch_prior_var(d, w, o, st);
+    }
     {
         Scope t(c, "disp_map");
         launch_disp_map(d_counts, d_nf, d, w, o, st);
@@ -481,17 +497,10 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const dou
     return rc;
 }
 
-int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S, double *sf_host) {
-    if (!c) return CHICDIFF_E_INVALID;
-    if (!d_counts || !sf_host || n < 1 || S < 1 || S > kMaxS) return fail(c, CHICDIFF_E_INVALID, "size_factors: bad arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = ensure_workspace(c, n, S);
-    if (rc) return rc;
-    timing_reset(c);
-    {
-        Scope t(c, "row_lgm");
-        launch_row_lgm(d_counts, n, S, c->d_lgm, c->stream);
-    }
+// size factors -> c->d_sf (device) ; no host synchronisation
+static int size_factors_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S) {
+    Scope t(c, "size_factors");
+    launch_row_lgm(d_counts, n, S, c->d_lgm, c->stream);
     SelArgs sa{};
     sa.mode = SEL_SIZEFACTOR;
     sa.ncol = S;
@@ -499,7 +508,20 @@ int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, 
     sa.counts = d_counts;
     sa.lgm = c->d_lgm;
     sa.S = S;
-    if ((rc = run_select(c, sa))) return rc;
+    int rc = run_select(c, sa);
+    if (rc) return rc;
+    launch_gather_sf(c->w, S, c->d_sf, c->stream);
+    return CHICDIFF_OK;
+}
+
+int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S, double *sf_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_counts || !sf_host || n < 1 || S < 1 || S > kMaxS) return fail(c, CHICDIFF_E_INVALID, "size_factors: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_workspace(c, n, S);
+    if (rc) return rc;
+    timing_reset(c);
+    if ((rc = size_factors_impl(c, d_counts, n, S))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_sc, c->w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_collect(c);
@@ -509,6 +531,31 @@ int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, 
         sf_host[j] = c->h_sc->sel_value[2 * j];
     }
     return CHICDIFF_OK;
+}
+
+// a5 + a4 + a6 + a7 in one enqueue: estimateSizeFactors -> sc(theta) -> estimateDispersions -> nbinomWaldTest
+// (chicdiff.R:1561-1562, 1666-1674) with the size factors and offsets never leaving HBM.
+int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, const double *d_fullMean, int64_t n, int32_t S,
+                               const int32_t *group, double theta, const chicdiff_nbglm_opts *opts,
+                               const chicdiff_nbglm_out *d_out, chicdiff_nbglm_scalars *scalars, double *sf_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_counts || !d_fullMean) return fail(c, CHICDIFF_E_INVALID, "counts / fullMean pointer is NULL");
+    FitDims d;
+    int rc = check_counts_group(c, n, S, group, d);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, n, S))) return rc;
+    timing_reset(c);
+    if ((rc = size_factors_impl(c, d_counts, n, S))) return rc;
+    const int mix = theta == theta;
+    {
+        Scope t(c, "offsets");
+        launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, c->d_nf_tmp, c->stream);
+    }
+    if (sf_host) HIPCHK(c, hipMemcpyAsync(sf_host, c->d_sf, sizeof(double) * S, hipMemcpyDeviceToHost, c->stream));
+    rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(opts, S), d_out, scalars);
+    timing_collect(c);
+    return rc;
 }
 
 int chicdiff_hip_offsets_dev(chicdiff_hip_ctx *c, const double *d_fullMean, const double *sf_host, int64_t n, int32_t S,

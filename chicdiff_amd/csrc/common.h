@@ -69,6 +69,7 @@ void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st);     // digit histogr
 void launch_sel_step(SelArgs a, FitWork w, hipStream_t st);     // pick bins, extend prefixes
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st);   // prefixes -> values; median into sc
 
+void launch_gather_sf(FitWork w, int S, double *d_sf, hipStream_t st);  // select results -> sf[S]
 void launch_row_lgm(const int32_t *counts, int64_t n, int S, double *lgm, hipStream_t st);
 void launch_offsets(const double *fullMean, const double *sf_dev, int64_t n, int S, double theta, int mix,
                     double *out, hipStream_t st);

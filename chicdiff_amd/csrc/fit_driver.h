@@ -29,7 +29,7 @@ int drive_trend(B &be) {
     be.trend_init();
     int passes = 0;
     for (;;) {
-        const int batch = passes == 0 ? 12 : 8;  // IRLS passes between two looks at the finished flag
+        const int batch = passes == 0 ? 24 : 8;  // IRLS passes between two looks at the finished flag (typical total ~20)
         for (int k = 0; k < batch; k++) {
             const bool single = be.world() <= 1;
             be.trend_pass(single);  // single rank: the reducing block also advances the state machine

@@ -267,6 +267,11 @@ void launch_sel_step(SelArgs a, FitWork w, hipStream_t st) {
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st) { sel_finish_kernel<<<1, 64, 0, st>>>(a, w); }
 
 // ------------------------------------------------------------------------------------------
+__global__ void gather_sf_kernel(FitWork w, int S, double *sf) {
+    if ((int)threadIdx.x < S) sf[threadIdx.x] = w.sc->sel_value[2 * threadIdx.x];
+}
+void launch_gather_sf(FitWork w, int S, double *d_sf, hipStream_t st) { gather_sf_kernel<<<1, 64, 0, st>>>(w, S, d_sf); }
+
 // a5 helper: row log geometric means, loggeomeans <- rowMeans(log(counts))
 __global__ __launch_bounds__(256) void row_lgm_kernel(const int32_t *__restrict__ counts, int64_t n, int S,
                                                       double *__restrict__ lgm) {

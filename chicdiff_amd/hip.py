@@ -25,7 +25,7 @@ EXPORTS = [
     "chicdiff_hip_create", "chicdiff_hip_destroy", "chicdiff_hip_last_error", "chicdiff_hip_set_stream",
     "chicdiff_hip_set_allreduce", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
-    "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_theta_grid_dev",
+    "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
     "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
 
@@ -89,6 +89,8 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_nbglm_fit_dev.argtypes = [vp, vp, vp, i64, i32, C.POINTER(i32), C.POINTER(Opts), C.POINTER(Out),
                                              C.POINTER(Scalars)]
     L.chicdiff_hip_nbglm_fit.argtypes = L.chicdiff_hip_nbglm_fit_dev.argtypes
+    L.chicdiff_hip_wald_test_dev.argtypes = [vp, vp, vp, i64, i32, C.POINTER(i32), dbl, C.POINTER(Opts), C.POINTER(Out),
+                                             C.POINTER(Scalars), C.POINTER(dbl)]
     L.chicdiff_hip_theta_grid_dev.argtypes = [vp, vp, vp, C.POINTER(dbl), i64, i32, C.POINTER(dbl), i32,
                                               C.POINTER(Opts), C.POINTER(dbl)]
     L.chicdiff_hip_wald_pvalues_dev.argtypes = [vp, vp, i64, vp]
@@ -236,6 +238,29 @@ class HipContext:
                                                         C.byref(opts) if opts is not None else None, C.byref(out),
                                                         C.byref(sc)))
         return bufs, _scalars_dict(sc)
+
+    def wald_test(self, d_counts, d_fullmean, group, theta=None, want=None, opts: Opts | None = None,
+                  outputs: dict | None = None):
+        """size factors -> offsets(theta) -> dispersions -> Wald test in one enqueue (device-resident)."""
+        torch = self.torch
+        S, n = d_counts.shape
+        assert d_fullmean.shape == (S, n) and d_counts.is_contiguous() and d_fullmean.is_contiguous()
+        want = list(want) if want is not None else ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue"]
+        out = Out()
+        bufs = outputs if outputs is not None else {}
+        for k in want:
+            if k not in bufs:
+                bufs[k] = torch.empty(n, dtype=torch.float64 if k in OUT_DOUBLE else torch.int32, device=self.device)
+            setattr(out, k, bufs[k].data_ptr())
+        g = (C.c_int32 * S)(*[int(x) for x in group])
+        sc = Scalars()
+        sf = (C.c_double * S)()
+        self._check(self.lib.chicdiff_hip_wald_test_dev(
+            self.h, d_counts.data_ptr(), d_fullmean.data_ptr(), n, S, g, float("nan") if theta is None else float(theta),
+            C.byref(opts) if opts is not None else None, C.byref(out), C.byref(sc), sf))
+        res = _scalars_dict(sc)
+        res["sizeFactors"] = np.array(sf[:])
+        return bufs, res
 
     def nbglm_fit_host(self, counts, nf, group, want=None, opts: Opts | None = None):
         """Host-buffer entry point (what the R .Call shim uses): numpy (n, S) in, numpy out."""

@@ -140,6 +140,13 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *ctx, const int32_t *counts, const d
                            const int32_t *group, const chicdiff_nbglm_opts *opts, const chicdiff_nbglm_out *out,
                            chicdiff_nbglm_scalars *scalars);
 
+/* a5 + a4 + a6 + a7 in one call — size factors -> sc(theta) -> dispersions -> Wald test
+ * (chicdiff.R:1561-1562, 1666-1674), with size factors and offsets kept in HBM.  theta = NaN uses
+ * normFactorsM3 (norm = "fullmean").  sf_host (S doubles) may be NULL. */
+int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts, const double *d_fullMean, int64_t n,
+                               int32_t S, const int32_t *group, double theta, const chicdiff_nbglm_opts *opts,
+                               const chicdiff_nbglm_out *d_out, chicdiff_nbglm_scalars *scalars, double *sf_host);
+
 /* a8 — theta grid (chicdiff.R:1619-1662): for each theta, sc(theta) -> design ~1 fit ->
  * deviances[t] = sum(deviance).  d_fullMean n x S, sf_host the null size factors. */
 int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts, const double *d_fullMean,

@@ -333,3 +333,17 @@ def test_deseq2wrap_argument_handling(ctx, tmp_path):
     assert "theta" not in out.attrs
     out = DESeq2Wrap(dict(base, norm="combined", theta=0.25), RU, long, ctx=ctx)  # theta from the settings list
     assert out.attrs["theta"] == 0.25
+
+
+def test_fused_wald_test_equals_composed_calls(ctx, oracle):
+    d = synth.make(30000, 8, fragments=2)
+    _, FM = oracle.window_sums(None, d["fragFullMean"], d["region_ptr"])
+    dk, dF = ctx.to_device(d["counts"], np.int32), ctx.to_device(FM, np.float64)
+    sf = ctx.size_factors(dk)
+    ref, sc_ref = ctx.nbglm_fit(dk, ctx.offsets(dF, sf, 0.25), d["group"])
+    ref = {k: v.clone() for k, v in ref.items()}
+    out, sc = ctx.wald_test(dk, dF, d["group"], theta=0.25)
+    assert np.array_equal(sc["sizeFactors"], sf)
+    for k in ref:
+        assert np.array_equal(ref[k].cpu().numpy(), out[k].cpu().numpy(), equal_nan=True), k
+    assert np.array_equal(sc["trendCoef"], sc_ref["trendCoef"])
