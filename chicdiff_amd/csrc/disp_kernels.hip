@@ -15,7 +15,10 @@
 //   * iteration counts are heavy-tailed (median ~7, 1.7 % of rows run 100 + 40 grid points),
 //     so a finished lane immediately pulls the next row from a global queue (one atomic per
 //     wave per refill) instead of idling until its 63 neighbours finish.
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include "common.h"
 #include "devmath.h"
@@ -100,7 +103,7 @@ void launch_prep_finish(FitDims d, FitWork w, hipStream_t st) { colsum_finish_ke
 void launch_xim(FitDims d, FitWork w, hipStream_t st) { xim_kernel<<<1, 64, 0, st>>>(d, w); }
 
 // ------------------------------------------------------------------------------------------
-constexpr int kChunk = 256;  // rows a wave takes from the global queue per atomic
+constexpr int kChunk = 64;   // rows a wave takes from the global queue per atomic
 enum Phase : int { PH_NEED = 0, PH_INIT = 1, PH_SEARCH = 2, PH_GRID1 = 3, PH_GRID2 = 4, PH_DONE = 5 };
 
 struct DispArgs {
@@ -109,6 +112,7 @@ struct DispArgs {
     FitDims d;
     FitWork w;
     Opts o;
+    unsigned long long *stamps;  // diagnostic only (CHICDIFF_DISP_STAMPS=file): per wave start / queue-empty / exit
 };
 
 // log posterior of a = log(alpha) and its derivative for one row held in LDS (A2.6).
@@ -126,23 +130,82 @@ struct DispArgs {
 //     The nr+1 prefix products and harmonic sums are tabulated once per row and tick in LDS;
 //   * the products of all samples are multiplied up (mantissa/exponent) and logged ONCE per row.
 // mu_j = max(nf_j * groupmean_g, minmu) is rebuilt on the fly from LDS.
+struct RowConsts {  // what depends only on the evaluation point a = log(alpha)
+    double a, alpha, r, lgS0, dgS0;
+    int nr;
+};
+__device__ __forceinline__ RowConsts row_consts(double a) {
+    RowConsts c;
+    c.a = a;
+    c.alpha = exp(a);
+    c.r = rcp(c.alpha);
+    c.nr = c.r < 10.0 ? (int)ceil(10.0 - c.r) : 0;  // unit steps lifting r to r0 = r + nr >= 10
+    const double r0 = c.r + (double)c.nr;
+    stirling(r0, flog(r0), rcp(r0), c.lgS0, c.dgS0);
+    return c;
+}
+struct Acc {  // sums over samples
+    double ll = 0, sd = 0, wA = 0, wB = 0, dA = 0, dB = 0;
+    double pm = 1.0;  // product of the samples' shift products (mantissas) ...
+    int pe = 0;       // ... and of their binary exponents
+};
+// one sample's terms; P = prod_{i<n}(r+i), H = sum_{i<n} 1/(r+i) for n = min(y, nr)
+__device__ __forceinline__ void sample_terms(Acc &acc, const RowConsts &c, double nfj, int yi, bool g, double gm0,
+                                             double gm1, double minmu, double P, double H) {
+    const double y = (double)yi;
+    const double mu = fmax(nfj * (g ? gm1 : gm0), minmu);
+    const double ma = mu * c.alpha;
+    const double t = 1.0 + ma;
+    const double rt = rcp(t);
+    const double L = flog1p_from(ma, t, rt);
+    const double wj = mu * rt;  // 1 / (1/mu + alpha)
+    if (g) { acc.wB += wj; acc.dB -= wj * wj; } else { acc.wA += wj; acc.dA -= wj * wj; }
+    double dlg = 0.0, ddg = H;
+    acc.pe += __builtin_amdgcn_frexp_exp(P);
+    acc.pm *= __builtin_amdgcn_frexp_mant(P);
+    if (yi > c.nr) {
+        const double z = y + c.r;
+        double lgz, dgz;
+        stirling(z, flog(z), rcp(z), lgz, dgz);
+        dlg = lgz - c.lgS0;
+        ddg += dgz - c.dgS0;
+    }
+    acc.ll += dlg - y * (L - c.a) - c.r * L;
+    acc.sd += L - ddg - ma * rt + y * c.alpha * rt;
+}
+__device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c, bool p2, bool use_prior,
+                                             double prior_mean, double prior_isig, double &lp, double &dlp) {
+    const double ll = acc.ll + fma((double)acc.pe, 0.69314718055994530942, flog(acc.pm));
+    double cr, dcr;
+    if (p2) {
+        cr = -0.5 * flog(acc.wA * acc.wB);
+        dcr = -0.5 * (acc.dA * rcp(acc.wA) + acc.dB * rcp(acc.wB));
+    } else {
+        cr = -0.5 * flog(acc.wA);
+        dcr = -0.5 * (acc.dA * rcp(acc.wA));
+    }
+    double pr = 0, dpr = 0;
+    if (use_prior) {
+        const double dd = c.a - prior_mean;
+        pr = -0.5 * dd * dd * prior_isig;
+        dpr = -dd * prior_isig;
+    }
+    lp = ll + pr + cr;
+    dlp = (c.r * c.r * acc.sd + dcr) * c.alpha + dpr;
+}
+
+// Row-per-lane evaluation: the lane's own row, all S samples.
 __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int S, uint64_t gmask,
                                            bool p2, double gm0, double gm1, double minmu, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
                                            double &lp, double &dlp) {
-    const double alpha = exp(a);
-    const double r = rcp(alpha);
-    // lift r to r0 = r + nr >= 10
-    const int nr = r < 10.0 ? (int)ceil(10.0 - r) : 0;
-    const double r0 = r + (double)nr;
-    double lgS0, dgS0;
-    stirling(r0, flog(r0), rcp(r0), lgS0, dgS0);
-    // per-tick table (LDS, [entry][lane]): P_n = prod_{i<n}(r+i) and H_n = sum_{i<n} 1/(r+i), n = 0..nr
+    const RowConsts c = row_consts(a);
+    // per-tick table (LDS, [entry][lane]): P_n and H_n for n = 0..nr
     {
-        double P = 1.0, H = 0.0, zz = r;
+        double P = 1.0, H = 0.0, zz = c.r;
         s_tab[lane] = 1.0;
         s_tab[11 * 64 + lane] = 0.0;
-        for (int i = 1; i <= nr; i++) {
+        for (int i = 1; i <= c.nr; i++) {
             P *= zz;
             H += rcp(zz);
             zz += 1.0;
@@ -150,54 +213,69 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
             s_tab[(11 + i) * 64 + lane] = H;
         }
     }
-    double ll = 0, sd = 0, wA = 0, wB = 0, dA = 0, dB = 0;
-    double pm = 1.0;  // running product of the samples' shift products (mantissas)
-    int pe = 0;       // ... and of their binary exponents
+    Acc acc;
     for (int j = 0; j < S; j++) {
-        const double nfj = s_nf[j * 64 + lane];
         const int yi = s_y[j * 64 + lane];
-        const double y = (double)yi;
-        const bool g = (gmask >> j) & 1;
-        const double mu = fmax(nfj * (g ? gm1 : gm0), minmu);
-        const double ma = mu * alpha;
-        const double t = 1.0 + ma;
-        const double rt = rcp(t);
-        const double L = flog1p_from(ma, t, rt);
-        const double wj = mu * rt;  // 1 / (1/mu + alpha)
-        if (g) { wB += wj; dB -= wj * wj; } else { wA += wj; dA -= wj * wj; }
-        // lgamma(y+r) - lgamma(r), digamma(y+r) - digamma(r)
-        const int n = yi < nr ? yi : nr;
-        const double P = s_tab[n * 64 + lane];
-        double dlg = 0.0, ddg = s_tab[(11 + n) * 64 + lane];
-        pe += __builtin_amdgcn_frexp_exp(P);
-        pm *= __builtin_amdgcn_frexp_mant(P);
-        if (yi > nr) {
-            const double z = y + r;
-            double lgz, dgz;
-            stirling(z, flog(z), rcp(z), lgz, dgz);
-            dlg = lgz - lgS0;
-            ddg += dgz - dgS0;
+        const int n = yi < c.nr ? yi : c.nr;
+        sample_terms(acc, c, s_nf[j * 64 + lane], yi, (gmask >> j) & 1, gm0, gm1, minmu, s_tab[n * 64 + lane],
+                     s_tab[(11 + n) * 64 + lane]);
+    }
+    finish_point(acc, c, p2, use_prior, prior_mean, prior_isig, lp, dlp);
+}
+
+// Drain mode: once the queue is empty a wave's rows finish one by one and its lanes would idle.
+// When <= 64/G rows are left (G = 2, 4, 8, 16) the 64 lanes regroup as G lanes per row: lane
+// G*g + jj works on samples jj, jj+G, ... of the g-th unfinished row (whose data already sits in
+// the wave's LDS slots); partial sums are xor-reduced inside each group and handed back to the
+// owning lane.  A 100-iteration straggler then costs a fraction of the instructions per tick,
+// which is what bounds the kernel's tail.
+__device__ __forceinline__ void eval_point_grouped(const double *s_nf, const int *s_y, int lane, int S, uint64_t gmask,
+                                                   bool p2, double minmu, int lg, unsigned long long actmask, bool active,
+                                                   double a_eval, double gm0, double gm1, bool use_prior,
+                                                   double prior_mean, double prior_isig, double &lp, double &dlp) {
+    const int G = 1 << lg;
+    const int g = lane >> lg, jj = lane & (G - 1);
+    const int nact = __popcll(actmask);
+    // owner lane of group g = position of the g-th set bit of actmask
+    unsigned long long m = actmask;
+    for (int q = 0; q < g; q++) m &= m - 1ull;
+    const bool has = g < nact;
+    const int owner = has ? (__ffsll((long long)m) - 1) : 0;
+    const double a_o = __shfl(a_eval, owner);
+    const double gm0_o = __shfl(gm0, owner), gm1_o = __shfl(gm1, owner);
+    const double pm_o = __shfl(prior_mean, owner);
+    double lp_g = 0, dlp_g = 0;
+    {
+        const RowConsts c = row_consts(a_o);
+        Acc acc;
+        for (int j = jj; j < S; j += G) {
+            const int yi = s_y[j * 64 + owner];
+            const int n = has ? (yi < c.nr ? yi : c.nr) : 0;  // idle groups (no row) must not loop on garbage
+            double P = 1.0, H = 0.0, zz = c.r;
+            for (int i = 0; i < n && i < 10; i++) {
+                P *= zz;
+                H += rcp(zz);
+                zz += 1.0;
+            }
+            sample_terms(acc, c, s_nf[j * 64 + owner], yi, (gmask >> j) & 1, gm0_o, gm1_o, minmu, P, H);
         }
-        ll += dlg - y * (L - a) - r * L;
-        sd += L - ddg - ma * rt + y * alpha * rt;
+        for (int off = 1; off < G; off <<= 1) {
+            acc.ll += __shfl_xor(acc.ll, off);
+            acc.sd += __shfl_xor(acc.sd, off);
+            acc.wA += __shfl_xor(acc.wA, off);
+            acc.wB += __shfl_xor(acc.wB, off);
+            acc.dA += __shfl_xor(acc.dA, off);
+            acc.dB += __shfl_xor(acc.dB, off);
+            acc.pm *= __shfl_xor(acc.pm, off);
+            acc.pe += __shfl_xor(acc.pe, off);
+        }
+        finish_point(acc, c, p2, use_prior, pm_o, prior_isig, lp_g, dlp_g);
     }
-    ll += fma((double)pe, 0.69314718055994530942, flog(pm));
-    double cr, dcr;
-    if (p2) {
-        cr = -0.5 * flog(wA * wB);
-        dcr = -0.5 * (dA * rcp(wA) + dB * rcp(wB));
-    } else {
-        cr = -0.5 * flog(wA);
-        dcr = -0.5 * (dA * rcp(wA));
-    }
-    double pr = 0, dpr = 0;
-    if (use_prior) {
-        const double dd = a - prior_mean;
-        pr = -0.5 * dd * dd * prior_isig;
-        dpr = -dd * prior_isig;
-    }
-    lp = ll + pr + cr;
-    dlp = (r * r * sd + dcr) * alpha + dpr;
+    // hand the group's result to its owner: an active lane's group is its rank among the active lanes
+    const int my_group = __popcll(actmask & ((1ull << lane) - 1ull));
+    const int src = (active ? my_group : 0) << lg;
+    lp = __shfl(lp_g, src);
+    dlp = __shfl(dlp_g, src);
 }
 
 template <bool MAP, int MINW>
@@ -214,6 +292,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     const bool p2 = A.d.p == 2;
     const Opts o = A.o;
     const double min_log_alpha = log(o.minDisp / 10.0);
+    const int maxlg = S > 8 ? 4 : (S > 4 ? 3 : 2);  // never more lanes per row than samples
     const double glo = log(1e-8), ghi = log(o.maxDisp), gstep = (ghi - glo) / 19.0;
     FitScalars *sc = A.w.sc;
     // fit-wide scalars (uniform)
@@ -233,6 +312,9 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     double gbest = 0, ghat = 0, dgene = 0, a_new = 0;
     bool queue_empty = false;
     unsigned long long chunk_next = 0, chunk_end = 0;
+    const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;
+    bool stamped = false;
+    if (A.stamps && lane == 0) A.stamps[gwave * 4 + 0] = __builtin_amdgcn_s_memrealtime();
 
     for (;;) {
         // ---- refill: lanes without a row pull the next ones from the queue -----------------
@@ -302,6 +384,13 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
         }
         if (__ballot(phase != PH_DONE) == 0ull) break;
+        if (A.stamps && queue_empty && !stamped) {
+            stamped = true;
+            if (lane == 0) {
+                A.stamps[gwave * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+                A.stamps[gwave * 4 + 3] = __popcll(__ballot(phase != PH_DONE && phase != PH_NEED));
+            }
+        }
 
         // ---- choose this tick's evaluation point -------------------------------------------
         double a_eval = a;
@@ -320,9 +409,21 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
 
         // ---- evaluate -------------------------------------------------------------------------
         double l_new = 0, dl_new = 0;
-        if (phase != PH_DONE && phase != PH_NEED)
+        const bool active = phase != PH_DONE && phase != PH_NEED;
+        const unsigned long long actmask = __ballot(active);
+        int lg = 0;  // log2(lanes per row); > 0 only while draining (wave-uniform)
+        if (queue_empty && chunk_next >= chunk_end) {
+            const int nact = __popcll(actmask);
+            while (lg < maxlg && (nact << (lg + 1)) <= 64) lg++;
+            if (lg < 2) lg = 0;  // 2 lanes per row does not pay for the regrouping overhead
+        }
+        if (lg > 0) {
+            eval_point_grouped(s_nf, s_y, lane, S, gmask, p2, o.minmu, lg, actmask, active, a_eval, gm0, gm1, MAP,
+                               prior_mean, prior_isig, l_new, dl_new);
+        } else if (active) {
             eval_point(s_nf, s_y, s_tab, lane, S, gmask, p2, gm0, gm1, o.minmu, a_eval, MAP, prior_mean, prior_isig, l_new,
                        dl_new);
+        }
 
         // ---- advance the per-lane state machine ---------------------------------------------
         bool finished = false;  // line search over: decide between result and grid fallback
@@ -414,11 +515,13 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             phase = PH_NEED;
         }
     }
+    if (A.stamps && lane == 0) A.stamps[gwave * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
 static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                         hipStream_t st) {
-    DispArgs A{counts, nf, d, w, o};
+    DispArgs A{counts, nf, d, w, o, nullptr};
+    const char *stamp_file = getenv("CHICDIFF_DISP_STAMPS");
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks
     int threads = 128;
@@ -430,6 +533,10 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     const int64_t max_blocks = 256 * (int64_t)(160 * 1024 / (lds > 0 ? lds : 1) < 8 ? 160 * 1024 / lds : 8);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
+    if (stamp_file) {
+        (void)hipMalloc((void **)&A.stamps, (size_t)blocks * (threads / 64) * 4 * 8);
+        (void)hipMemsetAsync(A.stamps, 0, (size_t)blocks * (threads / 64) * 4 * 8, st);
+    }
     static const int variant = [] {
         const char *e = getenv("CHICDIFF_DISP_MINW");  // tuning knob: min waves/SIMD the kernel is built for
         return e ? atoi(e) : 2;
@@ -441,6 +548,19 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
         if (variant >= 4) LAUNCH(false, 4); else if (variant == 3) LAUNCH(false, 3); else LAUNCH(false, 2);
     }
 #undef LAUNCH
+    if (stamp_file) {  // diagnostic: blocking, never used in timed runs
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)blocks * (threads / 64) * 4);
+        (void)hipMemcpy(h.data(), A.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        FILE *f = fopen(stamp_file, map ? "ab" : "wb");
+        if (f) {
+            unsigned long long hdr[2] = {map ? 1ull : 0ull, h.size() / 4};
+            fwrite(hdr, 8, 2, f);
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+        (void)hipFree(A.stamps);
+    }
 }
 
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
     }
 }
 
-constexpr int kChunk = 256;  // rows a wave takes from the global queue per atomic
+constexpr int kChunk = 64;   // rows a wave takes from the global queue per atomic
 
 struct WaldArgs {
     const int32_t *counts;
