@@ -69,7 +69,10 @@ def test_sharded_global_steps_match_single_rank_oracle(n, S):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + n) % 2000
+    import socket
+    with socket.socket() as sk:  # a free port chosen by the OS (a fixed one can collide with a stale rendezvous)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n, S, q)) for r in range(2)]
     for p in procs:
         p.start()
