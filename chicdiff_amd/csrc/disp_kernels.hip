@@ -134,14 +134,14 @@ struct RowConsts {  // what depends only on the evaluation point a = log(alpha)
     double a, alpha, r, lgS0, dgS0;
     int nr;
 };
-__device__ __forceinline__ RowConsts row_consts(double a) {
+__device__ __forceinline__ RowConsts row_consts(double a, const LogEntry *lt) {
     RowConsts c;
     c.a = a;
     c.alpha = exp(a);
     c.r = rcp(c.alpha);
     c.nr = c.r < 10.0 ? (int)ceil(10.0 - c.r) : 0;  // unit steps lifting r to r0 = r + nr >= 10
     const double r0 = c.r + (double)c.nr;
-    stirling(r0, flog(r0), rcp(r0), c.lgS0, c.dgS0);
+    stirling(r0, tlog(r0, lt), rcp(r0), c.lgS0, c.dgS0);
     return c;
 }
 struct Acc {  // sums over samples
@@ -151,13 +151,13 @@ struct Acc {  // sums over samples
 };
 // one sample's terms; P = prod_{i<n}(r+i), H = sum_{i<n} 1/(r+i) for n = min(y, nr)
 __device__ __forceinline__ void sample_terms(Acc &acc, const RowConsts &c, double nfj, int yi, bool g, double gm0,
-                                             double gm1, double minmu, double P, double H) {
+                                             double gm1, double minmu, double P, double H, const LogEntry *lt) {
     const double y = (double)yi;
     const double mu = fmax(nfj * (g ? gm1 : gm0), minmu);
     const double ma = mu * c.alpha;
     const double t = 1.0 + ma;
     const double rt = rcp(t);
-    const double L = flog1p_from(ma, t, rt);
+    const double L = tlog1p_from(ma, t, rt, lt);
     const double wj = mu * rt;  // 1 / (1/mu + alpha)
     if (g) { acc.wB += wj; acc.dB -= wj * wj; } else { acc.wA += wj; acc.dA -= wj * wj; }
     double dlg = 0.0, ddg = H;
@@ -166,7 +166,7 @@ __device__ __forceinline__ void sample_terms(Acc &acc, const RowConsts &c, doubl
     if (yi > c.nr) {
         const double z = y + c.r;
         double lgz, dgz;
-        stirling(z, flog(z), rcp(z), lgz, dgz);
+        stirling(z, tlog(z, lt), rcp(z), lgz, dgz);
         dlg = lgz - c.lgS0;
         ddg += dgz - c.dgS0;
     }
@@ -174,14 +174,15 @@ __device__ __forceinline__ void sample_terms(Acc &acc, const RowConsts &c, doubl
     acc.sd += L - ddg - ma * rt + y * c.alpha * rt;
 }
 __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c, bool p2, bool use_prior,
-                                             double prior_mean, double prior_isig, double &lp, double &dlp) {
-    const double ll = acc.ll + fma((double)acc.pe, 0.69314718055994530942, flog(acc.pm));
+                                             double prior_mean, double prior_isig, double &lp, double &dlp,
+                                             const LogEntry *lt) {
+    const double ll = acc.ll + fma((double)acc.pe, 0.69314718055994530942, tlog(acc.pm, lt));
     double cr, dcr;
     if (p2) {
-        cr = -0.5 * flog(acc.wA * acc.wB);
+        cr = -0.5 * tlog(acc.wA * acc.wB, lt);
         dcr = -0.5 * (acc.dA * rcp(acc.wA) + acc.dB * rcp(acc.wB));
     } else {
-        cr = -0.5 * flog(acc.wA);
+        cr = -0.5 * tlog(acc.wA, lt);
         dcr = -0.5 * (acc.dA * rcp(acc.wA));
     }
     double pr = 0, dpr = 0;
@@ -198,8 +199,8 @@ __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c,
 __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int S, uint64_t gmask,
                                            bool p2, double gm0, double gm1, double minmu, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
-                                           double &lp, double &dlp) {
-    const RowConsts c = row_consts(a);
+                                           double &lp, double &dlp, const LogEntry *lt) {
+    const RowConsts c = row_consts(a, lt);
     // per-tick table (LDS, [entry][lane]): P_n and H_n for n = 0..nr
     {
         double P = 1.0, H = 0.0, zz = c.r;
@@ -218,69 +219,16 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
         const int yi = s_y[j * 64 + lane];
         const int n = yi < c.nr ? yi : c.nr;
         sample_terms(acc, c, s_nf[j * 64 + lane], yi, (gmask >> j) & 1, gm0, gm1, minmu, s_tab[n * 64 + lane],
-                     s_tab[(11 + n) * 64 + lane]);
+                     s_tab[(11 + n) * 64 + lane], lt);
     }
-    finish_point(acc, c, p2, use_prior, prior_mean, prior_isig, lp, dlp);
-}
-
-// Drain mode: once the queue is empty a wave's rows finish one by one and its lanes would idle.
-// When <= 64/G rows are left (G = 2, 4, 8, 16) the 64 lanes regroup as G lanes per row: lane
-// G*g + jj works on samples jj, jj+G, ... of the g-th unfinished row (whose data already sits in
-// the wave's LDS slots); partial sums are xor-reduced inside each group and handed back to the
-// owning lane.  A 100-iteration straggler then costs a fraction of the instructions per tick,
-// which is what bounds the kernel's tail.
-__device__ __forceinline__ void eval_point_grouped(const double *s_nf, const int *s_y, int lane, int S, uint64_t gmask,
-                                                   bool p2, double minmu, int lg, unsigned long long actmask, bool active,
-                                                   double a_eval, double gm0, double gm1, bool use_prior,
-                                                   double prior_mean, double prior_isig, double &lp, double &dlp) {
-    const int G = 1 << lg;
-    const int g = lane >> lg, jj = lane & (G - 1);
-    const int nact = __popcll(actmask);
-    // owner lane of group g = position of the g-th set bit of actmask
-    unsigned long long m = actmask;
-    for (int q = 0; q < g; q++) m &= m - 1ull;
-    const bool has = g < nact;
-    const int owner = has ? (__ffsll((long long)m) - 1) : 0;
-    const double a_o = __shfl(a_eval, owner);
-    const double gm0_o = __shfl(gm0, owner), gm1_o = __shfl(gm1, owner);
-    const double pm_o = __shfl(prior_mean, owner);
-    double lp_g = 0, dlp_g = 0;
-    {
-        const RowConsts c = row_consts(a_o);
-        Acc acc;
-        for (int j = jj; j < S; j += G) {
-            const int yi = s_y[j * 64 + owner];
-            const int n = has ? (yi < c.nr ? yi : c.nr) : 0;  // idle groups (no row) must not loop on garbage
-            double P = 1.0, H = 0.0, zz = c.r;
-            for (int i = 0; i < n && i < 10; i++) {
-                P *= zz;
-                H += rcp(zz);
-                zz += 1.0;
-            }
-            sample_terms(acc, c, s_nf[j * 64 + owner], yi, (gmask >> j) & 1, gm0_o, gm1_o, minmu, P, H);
-        }
-        for (int off = 1; off < G; off <<= 1) {
-            acc.ll += __shfl_xor(acc.ll, off);
-            acc.sd += __shfl_xor(acc.sd, off);
-            acc.wA += __shfl_xor(acc.wA, off);
-            acc.wB += __shfl_xor(acc.wB, off);
-            acc.dA += __shfl_xor(acc.dA, off);
-            acc.dB += __shfl_xor(acc.dB, off);
-            acc.pm *= __shfl_xor(acc.pm, off);
-            acc.pe += __shfl_xor(acc.pe, off);
-        }
-        finish_point(acc, c, p2, use_prior, pm_o, prior_isig, lp_g, dlp_g);
-    }
-    // hand the group's result to its owner: an active lane's group is its rank among the active lanes
-    const int my_group = __popcll(actmask & ((1ull << lane) - 1ull));
-    const int src = (active ? my_group : 0) << lg;
-    lp = __shfl(lp_g, src);
-    dlp = __shfl(dlp_g, src);
+    finish_point(acc, c, p2, use_prior, prior_mean, prior_isig, lp, dlp, lt);
 }
 
 template <bool MAP, int MINW>
 __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     extern __shared__ double smem[];
+    __shared__ LogEntry s_logtab[64];
+    log_table_to_lds(s_logtab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = A.d.S;
     const int64_t n = A.d.n;
@@ -292,7 +240,6 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     const bool p2 = A.d.p == 2;
     const Opts o = A.o;
     const double min_log_alpha = log(o.minDisp / 10.0);
-    const int maxlg = S > 8 ? 4 : (S > 4 ? 3 : 2);  // never more lanes per row than samples
     const double glo = log(1e-8), ghi = log(o.maxDisp), gstep = (ghi - glo) / 19.0;
     FitScalars *sc = A.w.sc;
     // fit-wide scalars (uniform)
@@ -410,20 +357,12 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         // ---- evaluate -------------------------------------------------------------------------
         double l_new = 0, dl_new = 0;
         const bool active = phase != PH_DONE && phase != PH_NEED;
-        const unsigned long long actmask = __ballot(active);
-        int lg = 0;  // log2(lanes per row); > 0 only while draining (wave-uniform)
-        if (queue_empty && chunk_next >= chunk_end) {
-            const int nact = __popcll(actmask);
-            while (lg < maxlg && (nact << (lg + 1)) <= 64) lg++;
-            if (lg < 2) lg = 0;  // 2 lanes per row does not pay for the regrouping overhead
-        }
-        if (lg > 0) {
-            eval_point_grouped(s_nf, s_y, lane, S, gmask, p2, o.minmu, lg, actmask, active, a_eval, gm0, gm1, MAP,
-                               prior_mean, prior_isig, l_new, dl_new);
-        } else if (active) {
+        // (A "drain mode" that regrouped a straggler wave's lanes as 4-16 lanes per remaining row cut the
+        // tail by ~0.3 ms at 2 M rows but summed the samples in tree order, so results were no longer
+        // bit-reproducible from run to run; removed in favour of determinism.)
+        if (active)
             eval_point(s_nf, s_y, s_tab, lane, S, gmask, p2, gm0, gm1, o.minmu, a_eval, MAP, prior_mean, prior_isig, l_new,
-                       dl_new);
-        }
+                       dl_new, s_logtab);
 
         // ---- advance the per-lane state machine ---------------------------------------------
         bool finished = false;  // line search over: decide between result and grid fallback

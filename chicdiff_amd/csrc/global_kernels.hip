@@ -382,4 +382,27 @@ void launch_pvalues(const double *stat, int64_t n, double *p, hipStream_t st) {
     pvalue_kernel<<<(unsigned)blocks, 256, 0, st>>>(stat, n, p);
 }
 
+// device-math self test (tests/test_gpu_parity.py::test_device_math): out[i] = f_op(x[i])
+__global__ __launch_bounds__(256) void math_selftest_kernel(int op, const double *__restrict__ x, int64_t n,
+                                                            double *__restrict__ out) {
+    __shared__ LogEntry s_logtab[64];
+    log_table_to_lds(s_logtab);
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = x[i];
+        double r = NAN, t;
+        switch (op) {
+            case 0: r = flog(v); break;
+            case 1: r = tlog(v, s_logtab); break;
+            case 2: r = rcp(v); break;
+            case 3: r = lgamma_pos(v); break;
+            case 4: lgamma_digamma(v, t, r); break;
+            case 5: r = pnorm_two_sided(v); break;
+        }
+        out[i] = r;
+    }
+}
+void launch_math_selftest(int op, const double *x, int64_t n, double *out, hipStream_t st) {
+    math_selftest_kernel<<<256, 256, 0, st>>>(op, x, n, out);
+}
+
 }  // namespace cd

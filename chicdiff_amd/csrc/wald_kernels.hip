@@ -54,6 +54,8 @@ struct WaldArgs {
 // weighted sums that give beta_{k+1}.  DESeq2's loop index t equals k-1.
 __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
     extern __shared__ double smem[];
+    __shared__ LogEntry s_logtab[64];
+    log_table_to_lds(s_logtab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = A.d.S;
     const int64_t n = A.d.n;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
                     }
                     alpha = A.w.disp[r];
                     size = 1.0 / alpha;
-                    la = log(alpha);
+                    la = tlog(alpha, s_logtab);
                     crow = A.w.crow[r];
                     b0 = A.w.binit0[r];
                     b1 = A.w.binit1[r];
@@ -134,14 +136,16 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
                 const bool floored = raw < o.minmu;
                 const double mu = floored ? o.minmu : raw;
                 const double ma = alpha * mu;
-                const double rt = rcp(1.0 + ma);
+                const double t1 = 1.0 + ma;
+                const double rt = rcp(t1);
                 const double wj = mu * rt;
-                const double eta = floored ? log(mu / nfj) : (g ? b0 + b1 : b0);
-                const double z = eta + (y - mu) / mu;
+                const double lmu = tlog(mu, s_logtab);
+                const double eta = floored ? lmu - tlog(nfj, s_logtab) : (g ? b0 + b1 : b0);
+                const double z = eta + (y - mu) * rcp(mu);
                 if (g) { wB += wj; zB += wj * z; } else { wA += wj; zA += wj * z; }
                 // -log dnbinom's mu-dependent part: (size+y) log1p(alpha mu) - y log(alpha mu)
-                double dj = (size + y) * log1p(ma);
-                if (y > 0) dj -= y * (la + log(mu));
+                double dj = (size + y) * tlog1p_from(ma, t1, rt, s_logtab);
+                if (y > 0) dj -= y * (la + lmu);
                 D += dj;
             }
             bool stop = false;

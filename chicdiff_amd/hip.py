@@ -26,7 +26,7 @@ EXPORTS = [
     "chicdiff_hip_set_allreduce", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
-    "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
+    "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
 
 
@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_theta_grid_dev.argtypes = [vp, vp, vp, C.POINTER(dbl), i64, i32, C.POINTER(dbl), i32,
                                               C.POINTER(Opts), C.POINTER(dbl)]
     L.chicdiff_hip_wald_pvalues_dev.argtypes = [vp, vp, i64, vp]
+    L.chicdiff_hip_selftest_math_dev.argtypes = [vp, i32, vp, i64, vp]
     L.chicdiff_hip_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     L.chicdiff_hip_kernel_times.restype = i32
     L.chicdiff_hip_enable_timing.argtypes = [vp, i32]
@@ -288,6 +289,11 @@ class HipContext:
         self._check(self.lib.chicdiff_hip_theta_grid_dev(self.h, d_counts.data_ptr(), d_fullmean.data_ptr(), sf, n, S, th,
                                                          len(thetas), C.byref(opts) if opts is not None else None, dev))
         return np.array(dev[:])
+
+    def selftest_math(self, op: int, d_x):
+        out = self.torch.empty_like(d_x)
+        self._check(self.lib.chicdiff_hip_selftest_math_dev(self.h, op, d_x.data_ptr(), d_x.numel(), out.data_ptr()))
+        return out
 
     def wald_pvalues(self, d_stat):
         out = self.torch.empty_like(d_stat)

@@ -156,6 +156,10 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts, 
 /* Wald p-values alone: p[i] = 2*pnorm(-|stat[i]|) (Cody's algorithm, the one R's pnorm uses). */
 int chicdiff_hip_wald_pvalues_dev(chicdiff_hip_ctx *ctx, const double *d_stat, int64_t n, double *d_p);
 
+/* Device-math self test: out[i] = f(x[i]) with op 0 log (polynomial), 1 log (table), 2 reciprocal,
+ * 3 lgamma, 4 digamma, 5 2*pnorm(-|x|) — the special functions the fit kernels are built on. */
+int chicdiff_hip_selftest_math_dev(chicdiff_hip_ctx *ctx, int32_t op, const double *d_x, int64_t n, double *d_out);
+
 /* Timing of the last *_dev call's kernels, measured with HIP events on the context's stream:
  * fills up to `cap` (name, milliseconds, launches) records; returns the number available. */
 typedef struct {

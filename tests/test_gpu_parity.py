@@ -67,7 +67,13 @@ def test_fit_parity_two_groups(ctx, oracle, n, S):
     assert np.isclose(sc["dispPriorVar"], ref["dispPriorVar"], rtol=1e-7)
     check_close("baseMean", got["baseMean"], ref["baseMean"], nz, 1e-13, 1.0)
     check_close("baseVar", got["baseVar"], ref["baseVar"], nz & (ref["baseVar"] > 0), 1e-11, 1.0)
-    check_close("dispGeneEst", got["dispGeneEst"], ref["dispGeneEst"], nz, 1e-6, 0.999)
+    # gene-wise estimates at the floor (alpha < 1e-6, i.e. 1/alpha > 1e6): the profile likelihood is flat to
+    # within its own rounding noise there (DESeq2 included) and the grid argmax is decided by that noise;
+    # such rows are excluded from the trend (alpha > 1e-6 rule) and restart from the trend in the MAP step,
+    # so only "both at the floor" is required of them
+    floor = ref["dispGeneEst"] < 1e-6
+    assert np.all(got["dispGeneEst"][nz & floor] < 1e-6)
+    check_close("dispGeneEst", got["dispGeneEst"], ref["dispGeneEst"], nz & ~floor, 1e-6, 0.999)
     check_close("dispFit", got["dispFit"], ref["dispFit"], nz, 1e-7, 1.0)
     check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6, 0.999)
     check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6, 0.999, 1e-2)
@@ -347,3 +353,29 @@ def test_fused_wald_test_equals_composed_calls(ctx, oracle):
     for k in ref:
         assert np.array_equal(ref[k].cpu().numpy(), out[k].cpu().numpy(), equal_nan=True), k
     assert np.array_equal(sc["trendCoef"], sc_ref["trendCoef"])
+
+
+def test_device_math(ctx):
+    """The special functions the fit kernels are built on, against scipy (fp64, ~1 ulp expected)."""
+    import torch
+    from scipy import special
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.exp(rng.uniform(-40, 40, 200000)), 1 + rng.uniform(-0.05, 0.05, 50000),
+                        1 + rng.uniform(0, 1e-7, 1000), rng.uniform(0.5, 2.0, 50000)])
+    dx = torch.as_tensor(x).to(ctx.device)
+    for op, name in ((0, "flog"), (1, "tlog")):
+        got = ctx.selftest_math(op, dx).cpu().numpy()
+        ref = np.log(x)
+        r = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
+        print(name, "max rel", r.max())
+        assert r.max() < 2e-15, name
+    got = ctx.selftest_math(2, dx).cpu().numpy()
+    assert np.max(np.abs(got * x - 1)) < 4e-16
+    xg = np.exp(rng.uniform(-11, 21, 200000))
+    dg = torch.as_tensor(xg).to(ctx.device)
+    lg = ctx.selftest_math(3, dg).cpu().numpy()
+    ref = special.gammaln(xg)
+    assert np.max(np.abs(lg - ref) / np.maximum(1, np.abs(ref))) < 1e-14
+    di = ctx.selftest_math(4, dg).cpu().numpy()
+    ref = special.digamma(xg)
+    assert np.max(np.abs(di - ref) / np.maximum(1, np.abs(ref))) < 4e-15
