@@ -63,8 +63,6 @@ struct SelArgs {
     int S;
     int shift;              // bit position of the current digit
 };
-void launch_sel_count(SelArgs a, FitWork w, hipStream_t st);    // population per column -> partials -> hist[0..ncol)
-void launch_sel_begin(SelArgs a, FitWork w, hipStream_t st);    // ranks from populations
 void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st);     // digit histograms for the live prefixes
 void launch_sel_step(SelArgs a, FitWork w, hipStream_t st);     // pick bins, extend prefixes
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st);   // prefixes -> values; median into sc

@@ -10,8 +10,9 @@
 //   double *sums();  double *hist();          // backend buffers the driver hands to allreduce
 //   void trend_init(); void trend_pass(bool fused_step); void trend_step();
 //   const FitScalars *sync_scalars();         // make the scalars host-visible (may block)
-//   void sel_count(const SelSpec&); void sel_begin(const SelSpec&); void sel_hist(const SelSpec&, int shift);
-//   void sel_step(const SelSpec&, int shift); void sel_finish(const SelSpec&);
+//   void sel_hist(const SelSpec&, int shift);   // digit histograms for the live prefixes (first round: all keys)
+//   void sel_step(const SelSpec&, int shift);   // first round also derives the populations and ranks
+//   void sel_finish(const SelSpec&);
 #pragma once
 #include "fit_state.h"
 
@@ -47,9 +48,7 @@ int drive_trend(B &be) {
 // exact medians (lower/upper middle order statistics) of `ncol` columns by 12-bit radix select
 template <class B>
 int drive_select(B &be, const SelSpec &a) {
-    be.sel_count(a);
-    if (be.allreduce(be.hist(), a.ncol)) return -1;
-    be.sel_begin(a);
+    // round 0 doubles as the population count: the sum of its (all-reduced) histogram
     for (int r = 0; r < 6; r++) {
         be.sel_hist(a, kSelShifts[r]);
         if (be.allreduce(be.hist(), (int64_t)a.ncol * 2 * kSelBins)) return -1;

@@ -189,6 +189,7 @@ CD_HD double sel_median(const FitScalars *sc, int col) {
     return (sc->sel_count[col] > 0) ? (lo + hi) / 2.0 : NAN;
 }
 static const int kSelShifts[6] = {52, 40, 28, 16, 4, 0};  // 5 x 12 bits + 4 bits
+CD_HD bool sel_first_round(int shift) { return shift == 52; }
 CD_HD int sel_bits(int shift) { return shift == 0 ? 4 : kSelBits; }
 
 // ---- prior variance (estimateDispersionsPriorVar, closed-form branch) ---------------------------

@@ -133,26 +133,6 @@ __device__ __forceinline__ bool sel_key(const SelArgs &a, const FitScalars *sc, 
     return true;
 }
 
-__global__ __launch_bounds__(256) void sel_count_kernel(SelArgs a, FitWork w) {
-    const int col = blockIdx.y;
-    double v[1] = {0};
-    uint64_t key;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256)
-        if (sel_key(a, w.sc, col, i, key)) v[0] += 1;
-    block_reduce_store<1>(v, w.partials + ((size_t)col * gridDim.x + blockIdx.x));
-}
-__global__ void sel_count_finish_kernel(FitWork w, int nblk, int ncol) {
-    const int c = threadIdx.x;
-    if (c >= ncol) return;
-    double s = 0;
-    for (int b = 0; b < nblk; b++) s += w.partials[(size_t)c * nblk + b];
-    w.hist[c] = s;  // rides the all-reduce from here
-}
-__global__ void sel_begin_kernel(FitWork w, int ncol) {
-    const int c = threadIdx.x;
-    if (c < ncol) sel_begin(w.sc, c, w.hist[c]);
-}
-
 // histograms of the current digit for the two live prefixes of column blockIdx.y
 __global__ __launch_bounds__(256) void sel_hist_kernel(SelArgs a, FitWork w, int bits) {
     __shared__ unsigned int h[2][kSelBins];
@@ -160,7 +140,8 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(SelArgs a, FitWork w, int
     const FitScalars *sc = w.sc;
     for (int k = threadIdx.x; k < 2 * kSelBins; k += 256) (&h[0][0])[k] = 0;
     __syncthreads();
-    const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
+    const bool first = sel_first_round(a.shift);  // first round: every key, whatever an earlier select left behind
+    const uint64_t p0 = first ? 0 : sc->sel_prefix[2 * col], p1 = first ? 0 : sc->sel_prefix[2 * col + 1];
     const int hi = a.shift + bits;  // bits above `hi` are fixed by the prefix
     const bool same = (p0 == p1);
     const uint64_t mask = (1ull << bits) - 1ull;
@@ -185,13 +166,13 @@ __global__ __launch_bounds__(256) void sel_step_kernel(SelArgs a, FitWork w, int
     __shared__ double scan[256];
     const int col = blockIdx.x;
     FitScalars *sc = w.sc;
-    const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
-    const double rank0 = sc->sel_rank[2 * col], rank1 = sc->sel_rank[2 * col + 1];
+    const bool first = sel_first_round(a.shift);
+    const uint64_t p0 = first ? 0 : sc->sel_prefix[2 * col], p1 = first ? 0 : sc->sel_prefix[2 * col + 1];
+    double rank0 = sc->sel_rank[2 * col], rank1 = sc->sel_rank[2 * col + 1];
     const int nb = 1 << bits, per = (nb + 255) / 256;
     for (int slot = 0; slot < 2; slot++) {
         const int hslot = (slot == 1 && p0 != p1) ? 1 : 0;
         const double *g = w.hist + ((size_t)col * 2 + hslot) * kSelBins;
-        const double rank = slot ? rank1 : rank0;
         double mine[16];
         double acc = 0;
 #pragma unroll
@@ -209,6 +190,13 @@ __global__ __launch_bounds__(256) void sel_step_kernel(SelArgs a, FitWork w, int
             scan[threadIdx.x] += add;
             __syncthreads();
         }
+        if (first && slot == 0) {  // the first histogram's total is the population: ranks of the two middles
+            const int64_t mi = (int64_t)scan[255];
+            rank0 = (double)((mi - 1) / 2);
+            rank1 = (double)(mi / 2);
+            if (threadIdx.x == 0) sc->sel_count[col] = (double)mi;
+        }
+        const double rank = slot ? rank1 : rank0;
         const double incl = scan[threadIdx.x], before = incl - acc;
         const bool last_thread = (int)threadIdx.x == (nb - 1) / per;
         if ((before <= rank && rank < incl) || (last_thread && rank >= incl && incl == scan[255])) {
@@ -249,12 +237,6 @@ static int sel_blocks(int64_t n) {
     if (b > 512) b = 512;
     return (int)b;
 }
-void launch_sel_count(SelArgs a, FitWork w, hipStream_t st) {
-    const int nb = sel_blocks(a.n);
-    sel_count_kernel<<<dim3(nb, a.ncol), 256, 0, st>>>(a, w);
-    sel_count_finish_kernel<<<1, 64, 0, st>>>(w, nb, a.ncol);
-}
-void launch_sel_begin(SelArgs a, FitWork w, hipStream_t st) { sel_begin_kernel<<<1, 64, 0, st>>>(w, a.ncol); }
 void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st) {
     const int bits = sel_bits(a.shift);
     (void)hipMemsetAsync(w.hist, 0, sizeof(double) * (size_t)a.ncol * 2 * kSelBins, st);
@@ -397,6 +379,8 @@ __global__ __launch_bounds__(256) void math_selftest_kernel(int op, const double
             case 3: r = lgamma_pos(v); break;
             case 4: lgamma_digamma(v, t, r); break;
             case 5: r = pnorm_two_sided(v); break;
+            case 6: r = __builtin_amdgcn_rcp(v); break;  // raw v_rcp_f64 (~25 bits)
+            case 7: { double q = __builtin_amdgcn_rcp(v); r = fma(q, fma(-v, q, 1.0), q); } break;  // + 1 Newton step
         }
         out[i] = r;
     }

@@ -70,24 +70,14 @@ struct CpuBackend {
         k = key_of(x);
         return true;
     }
-    void sel_count(const SelSpec &a) {
-        uint64_t k;
-        for (int c = 0; c < a.ncol; c++) {
-            double m = 0;
-            for (int64_t i = 0; i < n; i++) m += key(a, c, i, k) ? 1 : 0;
-            hist_[c] = m;
-        }
-    }
-    void sel_begin(const SelSpec &a) {
-        for (int c = 0; c < a.ncol; c++) cd::sel_begin(&sc, c, hist_[c]);
-    }
     void sel_hist(const SelSpec &a, int shift) {
         const int bits = sel_bits(shift), hi = shift + bits;
         const uint64_t mask = (1ull << bits) - 1ull;
         std::fill(hist_.begin(), hist_.begin() + (size_t)a.ncol * 2 * kSelBins, 0.0);
         uint64_t k;
         for (int c = 0; c < a.ncol; c++) {
-            const uint64_t p0 = sc.sel_prefix[2 * c], p1 = sc.sel_prefix[2 * c + 1];
+            const bool first = sel_first_round(shift);  // stale prefixes of an earlier select must not matter
+            const uint64_t p0 = first ? 0 : sc.sel_prefix[2 * c], p1 = first ? 0 : sc.sel_prefix[2 * c + 1];
             double *g = hist_.data() + (size_t)c * 2 * kSelBins;
             for (int64_t i = 0; i < n; i++) {
                 if (!key(a, c, i, k)) continue;
@@ -100,6 +90,11 @@ struct CpuBackend {
     void sel_step(const SelSpec &a, int shift) {
         const int nb = 1 << sel_bits(shift);
         for (int c = 0; c < a.ncol; c++) {
+            if (sel_first_round(shift)) {  // population = sum of the first histogram
+                double total = 0;
+                for (int b = 0; b < nb; b++) total += hist_[(size_t)c * 2 * kSelBins + b];
+                cd::sel_begin(&sc, c, total);
+            }
             const uint64_t p0 = sc.sel_prefix[2 * c], p1 = sc.sel_prefix[2 * c + 1];
             for (int slot = 0; slot < 2; slot++) {
                 const int hslot = (slot == 1 && p0 != p1) ? 1 : 0;
