@@ -650,3 +650,31 @@ extern "C" int chicdiff_hip_selftest_math_dev(chicdiff_hip_ctx *c, int32_t op, c
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CHICDIFF_OK;
 }
+
+// a3 — per-fragment background (Bmean, Tmean, FullMean) for every RU row and replicate
+extern "C" int chicdiff_hip_fragment_background_dev(chicdiff_hip_ctx *c, const int32_t *d_bait, const int32_t *d_oe, int64_t nru,
+                                                    int32_t id_min, int32_t nid, const int64_t *d_midsum, int32_t S,
+                                                    const double *d_sj, const double *d_si, const int32_t *d_tblb,
+                                                    const int32_t *d_tlb, const double *d_T, int32_t ntblb, int32_t ntlb,
+                                                    const double *distfun_host, double *d_bmean, double *d_tmean,
+                                                    double *d_fullmean) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_bait || !d_oe || !d_midsum || !d_sj || !d_si || !d_tblb || !d_tlb || !d_T || !distfun_host || nru < 0 || nid < 1 ||
+        S < 1 || S > kMaxS || ntblb < 1 || ntlb < 1)
+        return fail(c, CHICDIFF_E_INVALID, "fragment_background: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    double *d_df = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_df, sizeof(double) * 10 * S));
+    hipError_t e = hipMemcpyAsync(d_df, distfun_host, sizeof(double) * 10 * S, hipMemcpyHostToDevice, c->stream);
+    timing_reset(c);
+    if (e == hipSuccess && nru > 0) {
+        Scope t(c, "fragment_background");
+        launch_fragment_background(d_bait, d_oe, nru, id_min, nid, d_midsum, S, d_sj, d_si, d_tblb, d_tlb, d_T, ntblb, ntlb, d_df,
+                                   d_bmean, d_tmean, d_fullmean, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    timing_collect(c);
+    (void)hipFree(d_df);
+    if (e != hipSuccess) return fail(c, CHICDIFF_E_HIP, "fragment_background: %s", hipGetErrorString(e));
+    return CHICDIFF_OK;
+}

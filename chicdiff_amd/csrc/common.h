@@ -75,6 +75,10 @@ void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfra
                         int64_t n, int32_t *N, double *FM, hipStream_t st);
 void launch_count_join(const int32_t *bait, const int32_t *oe, int64_t nru, const int64_t *keys,
                        const int32_t *vals, int64_t nkeys, int32_t *out, hipStream_t st);
+void launch_fragment_background(const int32_t *bait, const int32_t *oe, int64_t nru, int32_t id_min, int32_t nid,
+                                const int64_t *midsum, int32_t S, const double *sj, const double *si, const int32_t *tblb,
+                                const int32_t *tlb, const double *T, int32_t ntblb, int32_t ntlb, const double *distfun_dev,
+                                double *bmean, double *tmean, double *fullmean, hipStream_t st);
 void launch_math_selftest(int op, const double *x, int64_t n, double *out, hipStream_t st);
 void launch_pvalues(const double *stat, int64_t n, double *p, hipStream_t st);
 

@@ -364,6 +364,66 @@ void launch_pvalues(const double *stat, int64_t n, double *p, hipStream_t st) {
     pvalue_kernel<<<(unsigned)blocks, 256, 0, st>>>(stat, n, p);
 }
 
+// a3: per-fragment background (chicdiff.R:628-703 + Chicago .estimateBMean/.distFun): a gather from
+// dense per-fragment tables plus one log and one exp per (RU row, replicate).  HBM/L2-gather bound.
+struct BgArgs {
+    const int32_t *bait, *oe;
+    int64_t nru;
+    int32_t id_min, nid, S, ntblb, ntlb;
+    const int64_t *midsum;
+    const double *sj, *si;
+    const int32_t *tblb, *tlb;
+    const double *T;
+    const double *distfun;  // device, S x 10
+    double *bmean, *tmean, *fullmean;
+};
+__global__ __launch_bounds__(256) void fragment_background_kernel(BgArgs a) {
+    const int s = blockIdx.y;
+    const double *p = a.distfun + 10 * s;
+    const double c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3], h0 = p[4], h1 = p[5], t0 = p[6], t1 = p[7], omin = p[8],
+                 omax = p[9];
+    for (int64_t r = blockIdx.x * 256 + threadIdx.x; r < a.nru; r += (int64_t)gridDim.x * 256) {
+        const int32_t b = a.bait[r] - a.id_min, o = a.oe[r] - a.id_min;
+        double B = NAN, Tm = NAN;
+        if (b >= 0 && b < a.nid && o >= 0 && o < a.nid) {
+            const double dist = rint((double)(a.midsum[o] - a.midsum[b]) / 2.0);  // R round(): half to even
+            const double s_j = a.sj[(int64_t)s * a.nid + b];
+            double s_i = a.si[(int64_t)s * a.nid + o];
+            if (s_i != s_i) s_i = 1.0;
+            const double ld = log(fabs(dist));
+            double e;
+            if (ld > omax) e = t0 + ld * t1;
+            else if (ld < omin) e = h0 + ld * h1;
+            else e = c0 + c1 * ld + c2 * (ld * ld) + c3 * (ld * ld * ld);
+            B = s_j * s_i * exp(e);
+            const int32_t tb = a.tblb[(int64_t)s * a.nid + b], tl = a.tlb[(int64_t)s * a.nid + o];
+            if (tb >= 0 && tl >= 0) {
+                Tm = a.T[((int64_t)s * a.ntblb + tb) * a.ntlb + tl];
+            } else if (tb >= 0) {
+                double m = INFINITY;
+                for (int k = 0; k < a.ntlb; k++) {
+                    const double v = a.T[((int64_t)s * a.ntblb + tb) * a.ntlb + k];
+                    if (v == v && v < m) m = v;
+                }
+                Tm = isfinite(m) ? m : NAN;
+            }
+        }
+        if (a.bmean) a.bmean[(int64_t)s * a.nru + r] = B;
+        if (a.tmean) a.tmean[(int64_t)s * a.nru + r] = Tm;
+        if (a.fullmean) a.fullmean[(int64_t)s * a.nru + r] = B + Tm;
+    }
+}
+void launch_fragment_background(const int32_t *bait, const int32_t *oe, int64_t nru, int32_t id_min, int32_t nid,
+                                const int64_t *midsum, int32_t S, const double *sj, const double *si, const int32_t *tblb,
+                                const int32_t *tlb, const double *T, int32_t ntblb, int32_t ntlb, const double *distfun_dev,
+                                double *bmean, double *tmean, double *fullmean, hipStream_t st) {
+    BgArgs a{bait, oe, nru, id_min, nid, S, ntblb, ntlb, midsum, sj, si, tblb, tlb, T, distfun_dev, bmean, tmean, fullmean};
+    int64_t blocks = (nru + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    fragment_background_kernel<<<dim3((unsigned)blocks, S), 256, 0, st>>>(a);
+}
+
 // device-math self test (tests/test_gpu_parity.py::test_device_math): out[i] = f_op(x[i])
 __global__ __launch_bounds__(256) void math_selftest_kernel(int op, const double *__restrict__ x, int64_t n,
                                                             double *__restrict__ out) {

@@ -25,6 +25,7 @@ EXPORTS = [
     "chicdiff_hip_create", "chicdiff_hip_destroy", "chicdiff_hip_last_error", "chicdiff_hip_set_stream",
     "chicdiff_hip_set_allreduce", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
+    "chicdiff_hip_fragment_background_dev",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
     "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
@@ -86,6 +87,8 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_offsets_dev.argtypes = [vp, vp, C.POINTER(dbl), i64, i32, dbl, vp]
     L.chicdiff_hip_window_sums_dev.argtypes = [vp, vp, vp, i64, i32, vp, i64, vp, vp]
     L.chicdiff_hip_count_join_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp]
+    L.chicdiff_hip_fragment_background_dev.argtypes = [vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32,
+                                                       C.POINTER(dbl), vp, vp, vp]
     L.chicdiff_hip_nbglm_fit_dev.argtypes = [vp, vp, vp, i64, i32, C.POINTER(i32), C.POINTER(Opts), C.POINTER(Out),
                                              C.POINTER(Scalars)]
     L.chicdiff_hip_nbglm_fit.argtypes = L.chicdiff_hip_nbglm_fit_dev.argtypes
@@ -215,6 +218,21 @@ class HipContext:
                                                          d_keys.data_ptr(), d_vals.data_ptr(), d_keys.numel(),
                                                          out.data_ptr()))
         return out
+
+    # -- a3 ---------------------------------------------------------------------------------
+    def fragment_background(self, d_bait, d_oe, id_min, d_midsum, d_sj, d_si, d_tblb, d_tlb, d_T, distfun):
+        """Bmean, Tmean, FullMean (S, nru) for RU rows (d_bait, d_oe); tables as in the header."""
+        torch = self.torch
+        S, nid = d_sj.shape
+        nru = d_bait.numel()
+        df = np.ascontiguousarray(distfun, dtype=np.float64)
+        assert df.shape == (S, 10) and d_T.shape[0] == S
+        outs = [torch.empty((S, nru), dtype=torch.float64, device=self.device) for _ in range(3)]
+        self._check(self.lib.chicdiff_hip_fragment_background_dev(
+            self.h, d_bait.data_ptr(), d_oe.data_ptr(), nru, int(id_min), nid, d_midsum.data_ptr(), S, d_sj.data_ptr(),
+            d_si.data_ptr(), d_tblb.data_ptr(), d_tlb.data_ptr(), d_T.data_ptr(), d_T.shape[1], d_T.shape[2],
+            df.ctypes.data_as(C.POINTER(C.c_double)), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr()))
+        return outs
 
     # -- a6 + a7 ----------------------------------------------------------------------------
     def nbglm_fit(self, d_counts, d_nf, group, want=None, opts: Opts | None = None, outputs: dict | None = None):

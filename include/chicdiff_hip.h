@@ -128,6 +128,24 @@ int chicdiff_hip_count_join_dev(chicdiff_hip_ctx *ctx, const int32_t *d_ru_bait,
                                 int64_t nru, const int64_t *d_keys, const int32_t *d_vals, int64_t nkeys,
                                 int32_t *d_out);
 
+/* a3 — per-fragment background, the offset ingredients (chicdiff.R:628-703, 894-896 and Chicago's
+ * .estimateBMean/.distFun): for every RU row r = (bait, oe) and replicate s
+ *   distSign = round(((start+end)[oe] - (start+end)[bait]) / 2)                         (:648)
+ *   Bmean    = s_j[bait] * s_i[oe] * f_s(|distSign|);  s_i NA -> 1;  NA when s_j is NA  (:659-672, 701-702)
+ *   Tmean    = T_s[tblb[bait]][tlb[oe]];  tlb NA and tblb known -> min over tlb;  else NA (:676-692)
+ *   FullMean = Bmean + Tmean                                                             (:896)
+ * Lookup tables are dense over fragment ids [id_min, id_min + nid): d_midsum[nid] (= start+end),
+ * and per replicate d_sj, d_si [S][nid] (NaN = absent), d_tblb, d_tlb [S][nid] (-1 = NA),
+ * d_T [S][ntblb][ntlb] (NaN = combination absent).  distfun_host[S][10] = cubicFit[0..3],
+ * head.coef[0..1], tail.coef[0..1], obs.min, obs.max (chicdiff.R:553-569).  Outputs [S][nru], any
+ * may be NULL.  Reading the Chicago objects and the lm() refit stay host R. */
+int chicdiff_hip_fragment_background_dev(chicdiff_hip_ctx *ctx, const int32_t *d_bait, const int32_t *d_oe, int64_t nru,
+                                         int32_t id_min, int32_t nid, const int64_t *d_midsum, int32_t S,
+                                         const double *d_sj, const double *d_si, const int32_t *d_tblb,
+                                         const int32_t *d_tlb, const double *d_T, int32_t ntblb, int32_t ntlb,
+                                         const double *distfun_host, double *d_bmean, double *d_tmean,
+                                         double *d_fullmean);
+
 /* a6 + a7 — estimateDispersions + nbinomWaldTest (chicdiff.R:1573-1574, 1602-1603, 1643-1644,
  * 1673-1674) for design ~condition (group[j] in {0,1}, both present) or ~1 (all group[j]==0).
  * d_nf = normalizationFactors (n x S).  `group` is a HOST array of S ints. */

@@ -116,3 +116,47 @@ int oracle_bh_adjust(const double *p, int64_t n, double *padj) {
     free(v);
     return 0;
 }
+
+/* a3. Chicago .distFun: exp of a cubic in log d inside [obs.min, obs.max], log-linear head and tail. */
+static double dist_fun(double d, const double *p) {
+    const double ld = log(d);
+    double out;
+    if (ld > p[9]) out = p[6] + ld * p[7];
+    else if (ld < p[8]) out = p[4] + ld * p[5];
+    else out = p[0] + p[1] * ld + p[2] * (ld * ld) + p[3] * (ld * ld * ld);
+    return exp(out);
+}
+
+int oracle_fragment_background(const int32_t *bait, const int32_t *oe, int64_t nru, int32_t id_min, int32_t nid,
+                               const int64_t *midsum, int32_t S, const double *sj, const double *si,
+                               const int32_t *tblb, const int32_t *tlb, const double *T, int32_t ntblb, int32_t ntlb,
+                               const double *distfun, double *bmean, double *tmean, double *fullmean) {
+    for (int s = 0; s < S; s++) {
+        const double *p = distfun + 10 * s;
+        for (int64_t r = 0; r < nru; r++) {
+            const int32_t b = bait[r] - id_min, o = oe[r] - id_min;
+            if (b < 0 || b >= nid || o < 0 || o >= nid) return -1;
+            const double dist = nearbyint((double)(midsum[o] - midsum[b]) / 2.0); /* R round(): half to even */
+            const double s_j = sj[(int64_t)s * nid + b];
+            double s_i = si[(int64_t)s * nid + o];
+            if (isnan(s_i)) s_i = 1.0;
+            const double B = s_j * s_i * dist_fun(fabs(dist), p);
+            const int32_t tb = tblb[(int64_t)s * nid + b], tl = tlb[(int64_t)s * nid + o];
+            double Tm = NAN;
+            if (tb >= 0 && tl >= 0) {
+                Tm = T[((int64_t)s * ntblb + tb) * ntlb + tl];
+            } else if (tb >= 0) { /* tlb missing: lowest Tmean of this tblb */
+                double m = INFINITY;
+                for (int k = 0; k < ntlb; k++) {
+                    const double v = T[((int64_t)s * ntblb + tb) * ntlb + k];
+                    if (!isnan(v) && v < m) m = v;
+                }
+                Tm = isfinite(m) ? m : NAN;
+            }
+            if (bmean) bmean[(int64_t)s * nru + r] = B;
+            if (tmean) tmean[(int64_t)s * nru + r] = Tm;
+            if (fullmean) fullmean[(int64_t)s * nru + r] = B + Tm;
+        }
+    }
+    return 0;
+}

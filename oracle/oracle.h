@@ -98,6 +98,20 @@ int oracle_offsets(const double *FullMean, const double *sizeFactors, int64_t n,
 int oracle_count_join(const int32_t *ru_bait, const int32_t *ru_oe, int64_t nru, const int64_t *keys,
                       const int32_t *vals, int64_t nkeys, int32_t *out);
 
+/* a3: per-fragment background (offset ingredients), chicdiff.R:628-703 + Chicago .estimateBMean /
+ * .distFun (Appendix B): for every RU row (bait, oe) and replicate s
+ *   distSign = round(((start+end)_oe - (start+end)_bait)/2)                       (:648)
+ *   Bmean = s_j[bait] * s_i[oe] * f(|distSign|), s_i NA -> 1, NA when s_j NA      (:659-672, :701-702)
+ *   Tmean = T[tblb[bait]][tlb[oe]]; tlb NA & tblb known -> min over tlb; else NA  (:676-692)
+ *   FullMean = Bmean + Tmean                                                      (:896)
+ * Dense lookup tables over fragment ids [id_min, id_min+nid): midsum (int64), and per replicate
+ * sj, si (NaN = absent), tblb, tlb (-1 = NA), T (ntblb x ntlb row-major, NaN = missing).
+ * distfun per replicate: cubic[4], head[2], tail[2], obs_min, obs_max (10 doubles).  Outputs [S][nru]. */
+int oracle_fragment_background(const int32_t *bait, const int32_t *oe, int64_t nru, int32_t id_min, int32_t nid,
+                               const int64_t *midsum, int32_t S, const double *sj, const double *si,
+                               const int32_t *tblb, const int32_t *tlb, const double *T, int32_t ntblb, int32_t ntlb,
+                               const double *distfun, double *bmean, double *tmean, double *fullmean);
+
 /* a9 helpers: BH adjustment (p.adjust(method="BH") on the non-NaN entries; NaN stays NaN) */
 int oracle_bh_adjust(const double *p, int64_t n, double *padj);
 

@@ -80,6 +80,9 @@ def lib():
         L.oracle_offsets.argtypes = [_PD, _PD, C.c_int64, C.c_int32, C.c_double, _PD]
         L.oracle_count_join.argtypes = [_PI, _PI, C.c_int64, C.POINTER(C.c_int64), _PI, C.c_int64, _PI]
         L.oracle_bh_adjust.argtypes = [_PD, C.c_int64, _PD]
+        P64 = C.POINTER(C.c_int64)
+        L.oracle_fragment_background.argtypes = [_PI, _PI, C.c_int64, C.c_int32, C.c_int32, P64, C.c_int32, _PD, _PD, _PI, _PI,
+                                                 _PD, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD]
         _lib = L
     return _lib
 
@@ -209,3 +212,25 @@ def bh_adjust(p):
 def pnorm_two_sided(z):
     f = lib().oracle_pnorm_two_sided
     return np.array([f(float(x)) for x in np.atleast_1d(z)])
+
+
+def fragment_background(bait, oe, id_min, midsum, sj, si, tblb, tlb, T, distfun):
+    """sj/si/tblb/tlb: (S, nid); T: (S, ntblb, ntlb); distfun: (S, 10).  Returns Bmean, Tmean, FullMean (S, nru)."""
+    b = np.ascontiguousarray(bait, dtype=np.int32)
+    o = np.ascontiguousarray(oe, dtype=np.int32)
+    ms = np.ascontiguousarray(midsum, dtype=np.int64)
+    sj = np.ascontiguousarray(sj, dtype=np.float64)
+    si = np.ascontiguousarray(si, dtype=np.float64)
+    tb = np.ascontiguousarray(tblb, dtype=np.int32)
+    tl = np.ascontiguousarray(tlb, dtype=np.int32)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    df = np.ascontiguousarray(distfun, dtype=np.float64)
+    S, nid = sj.shape
+    nru = len(b)
+    B, Tm, F = (np.empty((S, nru)) for _ in range(3))
+    rc = lib().oracle_fragment_background(_pi(b), _pi(o), nru, int(id_min), nid, ms.ctypes.data_as(C.POINTER(C.c_int64)), S,
+                                          _pd(sj), _pd(si), _pi(tb), _pi(tl), _pd(T), T.shape[1], T.shape[2], _pd(df),
+                                          _pd(B), _pd(Tm), _pd(F))
+    if rc:
+        raise RuntimeError(f"oracle_fragment_background rc={rc}")
+    return B, Tm, F

@@ -379,3 +379,17 @@ def test_device_math(ctx):
     di = ctx.selftest_math(4, dg).cpu().numpy()
     ref = special.digamma(xg)
     assert np.max(np.abs(di - ref) / np.maximum(1, np.abs(ref))) < 4e-15
+
+
+def test_fragment_background(ctx, oracle):
+    """a3 on device against the oracle: real chr19 HindIII fragment geometry, synthetic Chicago tables."""
+    import torch
+    from test_oracle import _a3_inputs
+    a = _a3_inputs(seed=3, S=4)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(ctx.device)
+    B, Tm, F = ctx.fragment_background(t(a["bait"]), t(a["oe"]), a["id_min"], t(a["midsum"]), t(a["sj"]), t(a["si"]),
+                                       t(a["tblb"]), t(a["tlb"]), t(a["T"]), a["distfun"])
+    Br, Tr, Fr = oracle.fragment_background(**a)
+    assert np.array_equal(Tm.cpu().numpy(), Tr, equal_nan=True)          # pure lookup: bit-exact
+    assert np.allclose(B.cpu().numpy(), Br, rtol=1e-13, equal_nan=True) and np.isnan(Br).any()
+    assert np.allclose(F.cpu().numpy(), Fr, rtol=1e-13, equal_nan=True)

@@ -246,3 +246,70 @@ def test_count_join():
     lut = dict(zip(keys.tolist(), vals.tolist()))
     ref = np.array([lut.get((int(b) << 32) | int(e), 0) for b, e in zip(bait, oe)], dtype=np.int32)
     assert np.array_equal(got, ref) and (got == 0).any() and (got > 0).any()
+
+
+# ---------------------------------------------------------------- a3 fragment background
+def _a3_inputs(seed=0, S=3):
+    """Real restriction-fragment geometry (first 3000 chr19 HindIII fragments of the reference's rmap) +
+    synthetic Chicago tables (s_j, s_i, tblb/tlb bins, Tmean table, refitted distance function)."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    rmap = np.loadtxt(os.path.join(here, "golden", "chr19_HindIII_first3000.rmap"), dtype=str)
+    start, end, ids = rmap[:, 1].astype(np.int64), rmap[:, 2].astype(np.int64), rmap[:, 3].astype(np.int64)
+    baits = np.loadtxt(os.path.join(here, "golden", "chr19_baitIDs_first3000.txt"), dtype=np.int64)
+    rng = np.random.default_rng(seed)
+    id_min, nid = int(ids[0]), len(ids)
+    assert np.array_equal(ids, np.arange(id_min, id_min + nid))
+    bait = np.repeat(baits[:150], 40)
+    oe = bait + rng.integers(-60, 61, len(bait))
+    keep = (np.abs(oe - bait) > 1) & (oe >= id_min) & (oe < id_min + nid)
+    bait, oe = bait[keep].astype(np.int32), oe[keep].astype(np.int32)
+    sj = np.full((S, nid), np.nan)
+    sj[:, baits - id_min] = np.exp(rng.normal(0, 0.3, (S, len(baits))))
+    sj[:, baits[::17] - id_min] = np.nan                       # baits filtered out by Chicago: s_j NA
+    si = np.where(rng.random((S, nid)) < 0.8, np.exp(rng.normal(0, 0.3, (S, nid))), np.nan)
+    ntblb, ntlb = 5, 6
+    tblb = np.full((S, nid), -1, dtype=np.int32)
+    tblb[:, baits - id_min] = rng.integers(0, ntblb, (S, len(baits)))
+    tblb[np.isnan(sj)] = -1
+    tlb = np.where(rng.random((S, nid)) < 0.85, rng.integers(0, ntlb, (S, nid)), -1).astype(np.int32)
+    T = np.exp(rng.normal(-3, 0.5, (S, ntblb, ntlb)))
+    T[:, 2, 3] = np.nan                                         # a (tblb, tlb) pair never observed
+    distfun = np.zeros((S, 10))
+    for s in range(S):
+        fit = np.array([14.0 + 0.2 * s, -1.6, 0.05, -0.003])    # log f = cubic in log d
+        omin, omax = np.log(10000.0), np.log(1.5e6)
+        x = np.array([omin, omax])
+        beta = fit[1] + 2 * fit[2] * x + 3 * fit[3] * x ** 2    # chicdiff.R:565-566
+        alpha = fit[0] + (fit[1] - beta) * x + fit[2] * x ** 2 + fit[3] * x ** 3
+        distfun[s] = [*fit, alpha[0], beta[0], alpha[1], beta[1], omin, omax]
+    midsum = (start + end).astype(np.int64)
+    return dict(bait=bait, oe=oe, id_min=id_min, midsum=midsum, sj=sj, si=si, tblb=tblb, tlb=tlb, T=T, distfun=distfun)
+
+
+def test_fragment_background_matches_numpy_restatement():
+    a = _a3_inputs()
+    B, Tm, F = oracle.fragment_background(**a)
+    b, o = a["bait"] - a["id_min"], a["oe"] - a["id_min"]
+    dist = np.rint((a["midsum"][o] - a["midsum"][b]) / 2.0)
+    for s in range(a["sj"].shape[0]):
+        p = a["distfun"][s]
+        ld = np.log(np.abs(dist))
+        e = np.where(ld > p[9], p[6] + ld * p[7], np.where(ld < p[8], p[4] + ld * p[5], p[0] + p[1] * ld + p[2] * ld ** 2 + p[3] * ld ** 3))
+        si = np.where(np.isnan(a["si"][s, o]), 1.0, a["si"][s, o])
+        Bref = a["sj"][s, b] * si * np.exp(e)
+        assert np.allclose(B[s], Bref, rtol=1e-13, equal_nan=True) and np.isnan(Bref).any()
+        tb, tl = a["tblb"][s, b], a["tlb"][s, o]
+        Tref = np.full(len(b), np.nan)
+        both = (tb >= 0) & (tl >= 0)
+        Tref[both] = a["T"][s][tb[both], tl[both]]
+        only = (tb >= 0) & (tl < 0)
+        Tref[only] = np.nanmin(a["T"][s], axis=1)[tb[only]]
+        assert np.array_equal(Tm[s], Tref, equal_nan=True)
+        assert np.allclose(F[s], Bref + Tref, rtol=1e-13, equal_nan=True)
+    # the refitted distance function is C1 at both ends of the observed range (chicdiff.R:553, 565-569)
+    p = a["distfun"][0]
+    for edge in (p[8], p[9]):
+        inside = p[0] + p[1] * edge + p[2] * edge ** 2 + p[3] * edge ** 3
+        lin = (p[4] + edge * p[5]) if edge == p[8] else (p[6] + edge * p[7])
+        assert abs(inside - lin) < 1e-9

@@ -60,3 +60,7 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+# Design-file fixtures (data only): tests/golden/chr19_HindIII_first3000.rmap is the first 3000 lines of
+# ChicdiffData/inst/extdata/designDir/chr19_GRCh37_HindIII.rmap, chr19_baitIDs_first3000.txt the IDs of the
+# baits of chr19_GRCh37_HindIII.baitmap that fall in that range (made with head/awk, see git history).
