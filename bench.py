@@ -50,6 +50,44 @@ def cpu_baseline(S, theta, sample_rows, threads):
     return sample_rows / dt, dt
 
 
+def hbm_kernels(ctx, torch, n, S, F=11):
+    """The HBM-bound rows of the path (a2 window sums, a4 offsets, a1 count join) at the same scale,
+    outside the timed region: achieved GB/s on their algorithmic bytes vs 8 TB/s."""
+    dev = ctx.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    fragN = torch.randint(0, 50, (S, n * F), dtype=torch.int32, device=dev, generator=g)
+    fragFM = torch.rand((S, n * F), dtype=torch.float64, device=dev, generator=g) + 0.1
+    rp = torch.arange(0, (n + 1) * F, F, dtype=torch.int64, device=dev)
+    out = {}
+
+    def run(name, fn, nbytes):
+        fn()
+        ts = []
+        for _ in range(5):
+            fn()
+            ts.append(ctx.kernel_times()[name][0])
+        ms = float(np.median(ts))
+        out[name] = {"ms": round(ms, 4), "achieved_GBs": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes": nbytes}
+
+    ctx.enable_timing(True)
+    run("window_sums", lambda: ctx.window_sums(fragN, fragFM, rp), 12 * n * F * S + 12 * n * S)  # 48*S B/region at F=11 (+outputs)
+    _, FM = ctx.window_sums(None, fragFM, rp)
+    del fragN, fragFM
+    o = torch.empty_like(FM)
+    run("offsets", lambda: ctx.offsets(FM, np.ones(S), 0.5, out=o), 16 * n * S)
+    nk = 5 * n
+    keys = torch.unique(torch.randint(0, 2 ** 40, (nk,), dtype=torch.int64, device=dev, generator=g))
+    vals = torch.randint(1, 100, (keys.numel(),), dtype=torch.int32, device=dev, generator=g)
+    qk = keys[torch.randint(0, keys.numel(), (n * F,), device=dev, generator=g)]
+    qk = torch.sort(torch.where(torch.rand(n * F, device=dev, generator=g) < 0.5, qk + 1, qk)).values  # RU is keyed by baitID
+    bait, oe = (qk >> 32).to(torch.int32), (qk & 0xFFFFFFFF).to(torch.int32)
+    run("count_join", lambda: ctx.count_join(bait, oe, keys, vals), 12 * n * F + 12 * keys.numel())
+    ctx.enable_timing(False)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +97,7 @@ def main():
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-kernels", action="store_true", help="skip the window-sum / offsets / count-join side measurement")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     args = ap.parse_args()
 
@@ -150,6 +189,8 @@ def main():
         "kernels_ms": {k: [round(v[0] / args.steps, 4), v[1] // args.steps] for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
         "fit_status": int(sc["status"]),
     }
+    if rank == 0 and world == 1 and not args.no_hbm_kernels:
+        result["hbm_kernels"] = hbm_kernels(ctx, torch, n, S)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = 1  # DESeq2 as Chicdiff calls it is single-threaded
         v1, dt1 = cpu_baseline(S, args.theta, args.cpu_sample_rows, cores)

@@ -267,14 +267,53 @@ void launch_row_lgm(const int32_t *counts, int64_t n, int S, double *lgm, hipStr
     row_lgm_kernel<<<kRedBlocks, 256, 0, st>>>(counts, n, S, lgm);
 }
 
-// a4: offsets.  One thread per row; the row's S values are re-read from L1/L2, so HBM sees
-// one read of FullMean and one write of the result.
+// a4: offsets.  One thread per row.  For S <= 16 the row lives in registers (one HBM read, one write);
+// larger S re-reads the row from L1/L2.  log() keeps R's semantics for NA/0/negative inputs, the
+// common positive-finite case takes the cheaper flog().
+__device__ __forceinline__ double rlog(double x) { return (x > 0.0 && x < 1.7e308) ? flog(x) : log(x); }
+
+__global__ __launch_bounds__(256) void offsets16_kernel(const double *__restrict__ fm, const double *__restrict__ sf,
+                                                        int64_t n, int S, double theta, int mix,
+                                                        double *__restrict__ out) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = j < S ? fm[(int64_t)j * n + i] : 1.0;
+        double sl = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < S) sl += rlog(v[j]);
+        const double gmean = exp(sl / S);
+        bool anyna = false;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < S) {
+                v[j] = v[j] / gmean;
+                anyna |= (v[j] != v[j]);
+            }
+        double sl2 = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < S) {
+                if (anyna) v[j] = sf[j];
+                if (mix) {
+                    v[j] = v[j] * (1 - theta) + sf[j] * theta;
+                    sl2 += rlog(v[j]);
+                }
+            }
+        const double g2 = mix ? exp(sl2 / S) : 1.0;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < S) out[(int64_t)j * n + i] = mix ? v[j] / g2 : v[j];
+    }
+}
+
 __global__ __launch_bounds__(256) void offsets_kernel(const double *__restrict__ fm, const double *__restrict__ sf,
                                                       int64_t n, int S, double theta, int mix,
                                                       double *__restrict__ out) {
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double sl = 0;
-        for (int j = 0; j < S; j++) sl += log(fm[(int64_t)j * n + i]);
+        for (int j = 0; j < S; j++) sl += rlog(fm[(int64_t)j * n + i]);
         const double gmean = exp(sl / S);
         bool anyna = false;
         for (int j = 0; j < S; j++) {
@@ -286,7 +325,7 @@ __global__ __launch_bounds__(256) void offsets_kernel(const double *__restrict__
             double sl2 = 0;
             for (int j = 0; j < S; j++) {
                 const double m3 = anyna ? sf[j] : fm[(int64_t)j * n + i] / gmean;
-                sl2 += log(m3 * (1 - theta) + sf[j] * theta);
+                sl2 += rlog(m3 * (1 - theta) + sf[j] * theta);
             }
             g2 = exp(sl2 / S);
         }
@@ -301,54 +340,195 @@ void launch_offsets(const double *fm, const double *sf_dev, int64_t n, int S, do
                     hipStream_t st) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    offsets_kernel<<<(unsigned)blocks, 256, 0, st>>>(fm, sf_dev, n, S, theta, mix, out);
+    if (S <= 16)
+        offsets16_kernel<<<(unsigned)blocks, 256, 0, st>>>(fm, sf_dev, n, S, theta, mix, out);
+    else
+        offsets_kernel<<<(unsigned)blocks, 256, 0, st>>>(fm, sf_dev, n, S, theta, mix, out);
 }
 
-// a2: window sums, one thread per (region, sample)
+// a2: window sums.  A block owns 256 consecutive regions of one sample; their fragments are one
+// contiguous range (regions are contiguous fragment windows), which the block streams into LDS
+// with coalesced loads; each thread then adds up its own window from LDS, in fragment order
+// (sequential fp64 sum = the order sum() sees after setkey(otherEndID)).  Windows whose span does
+// not fit the staging buffer (never for RUexpand <= 5) take the direct path.
+constexpr int kWinCap = 256 * 12;  // staged fragments per block (F <= 11 for the default RUexpand = 5)
 __global__ __launch_bounds__(256) void window_sums_kernel(const int32_t *__restrict__ fragN,
                                                           const double *__restrict__ fragFM, int64_t nfrag, int S,
                                                           const int64_t *__restrict__ rptr, int64_t n,
                                                           int32_t *__restrict__ N, double *__restrict__ FM) {
+    __shared__ int32_t s_n[kWinCap];
+    __shared__ double s_f[kWinCap];
     const int j = blockIdx.y;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t lo = rptr[i], hi = rptr[i + 1];
-        if (fragN) {
-            int32_t s = 0;
-            for (int64_t f = lo; f < hi; f++) s += fragN[(int64_t)j * nfrag + f];
-            N[(int64_t)j * n + i] = s;
-        }
-        if (fragFM) {
-            double s = 0;
-            for (int64_t f = lo; f < hi; f++) s += fragFM[(int64_t)j * nfrag + f];
-            FM[(int64_t)j * n + i] = s;
+    const int64_t nblk = (n + 255) / 256;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t i0 = blk * 256, i1 = (i0 + 256 < n) ? i0 + 256 : n;
+        const int64_t f0 = rptr[i0], f1 = rptr[i1];
+        const int64_t i = i0 + threadIdx.x;
+        const bool staged = (f1 - f0) <= kWinCap;
+        int64_t lo = 0, hi = 0;
+        if (i < i1) { lo = rptr[i]; hi = rptr[i + 1]; }
+        if (staged) {
+            __syncthreads();  // previous iteration's readers are done with the buffers
+            // all 12 loads of a thread are issued before the first LDS store (memory-level parallelism)
+            const int span = (int)(f1 - f0);
+            if (fragN) {
+                int32_t v[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const int e = threadIdx.x + k * 256;
+                    v[k] = e < span ? fragN[(int64_t)j * nfrag + f0 + e] : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const int e = threadIdx.x + k * 256;
+                    if (e < span) s_n[e] = v[k];
+                }
+            }
+            if (fragFM) {
+                double v[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const int e = threadIdx.x + k * 256;
+                    v[k] = e < span ? fragFM[(int64_t)j * nfrag + f0 + e] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const int e = threadIdx.x + k * 256;
+                    if (e < span) s_f[e] = v[k];
+                }
+            }
+            __syncthreads();
+            if (i < i1) {
+                if (fragN) {
+                    int32_t s = 0;
+                    for (int64_t f = lo; f < hi; f++) s += s_n[f - f0];
+                    N[(int64_t)j * n + i] = s;
+                }
+                if (fragFM) {
+                    double s = 0;
+                    for (int64_t f = lo; f < hi; f++) s += s_f[f - f0];
+                    FM[(int64_t)j * n + i] = s;
+                }
+            }
+        } else if (i < i1) {
+            if (fragN) {
+                int32_t s = 0;
+                for (int64_t f = lo; f < hi; f++) s += fragN[(int64_t)j * nfrag + f];
+                N[(int64_t)j * n + i] = s;
+            }
+            if (fragFM) {
+                double s = 0;
+                for (int64_t f = lo; f < hi; f++) s += fragFM[(int64_t)j * nfrag + f];
+                FM[(int64_t)j * n + i] = s;
+            }
         }
     }
 }
 void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfrag, int S, const int64_t *rptr,
                         int64_t n, int32_t *N, double *FM, hipStream_t st) {
     int64_t blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;  // x S samples in grid.y: >> 256 CUs
     window_sums_kernel<<<dim3((unsigned)blocks, S), 256, 0, st>>>(fragN, fragFM, nfrag, S, rptr, n, N, FM);
 }
 
-// a1: count join by binary search in the sample's sorted key table
+// a1: count join.  RU is keyed by baitID (chicdiff.R:425), so the 1024 queries of a block fall in a
+// narrow key range: the block (2048 queries) finds that range with two binary searches on its min/max query,
+// streams the keys/values of the range into LDS (coalesced, read once) and resolves every query
+// there; a block whose range does not fit (unsorted callers) searches global memory, restricted
+// to the range.  Results do not depend on the path taken.
+constexpr int kJoinQ = 2048, kJoinCap = 4096;
+__device__ __forceinline__ int64_t lower_bound_g(const int64_t *keys, int64_t lo, int64_t hi, int64_t key) {
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// lower_bound over keys[lo, hi) by all 256 threads of the block: 256-ary search, 3 rounds for 10^7 keys
+// instead of 23 dependent loads by one thread.  Every thread returns the same value.
+__device__ __forceinline__ int64_t block_lower_bound(const int64_t *__restrict__ keys, int64_t lo, int64_t hi, int64_t target) {
+    while (hi - lo > 256) {
+        const int64_t step = (hi - lo + 255) / 256;
+        const int64_t pos = lo + (int64_t)threadIdx.x * step;
+        const int c = __syncthreads_count(pos < hi && keys[pos] < target);  // monotone in threadIdx.x
+        const int64_t nlo = c > 0 ? lo + (int64_t)(c - 1) * step + 1 : lo;
+        const int64_t pc = lo + (int64_t)c * step;
+        hi = pc < hi ? pc : hi;  // the answer is in [nlo, hi] (it may be `hi` itself)
+        lo = nlo;
+    }
+    const int64_t pos = lo + threadIdx.x;
+    const int c = __syncthreads_count(pos < hi && keys[pos] < target);
+    return lo + c;
+}
+
 __global__ __launch_bounds__(256) void count_join_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
                                                          int64_t nru, const int64_t *__restrict__ keys,
                                                          const int32_t *__restrict__ vals, int64_t nkeys,
                                                          int32_t *__restrict__ out) {
-    for (int64_t r = blockIdx.x * 256 + threadIdx.x; r < nru; r += (int64_t)gridDim.x * 256) {
-        const int64_t key = ((int64_t)bait[r] << 32) | (uint32_t)oe[r];
-        int64_t lo = 0, hi = nkeys;
-        while (lo < hi) {
-            const int64_t mid = lo + ((hi - lo) >> 1);
-            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    __shared__ int64_t s_keys[kJoinCap];
+    __shared__ int32_t s_vals[kJoinCap];
+    __shared__ int64_t s_red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nblk = (nru + kJoinQ - 1) / kJoinQ;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t q0 = blk * kJoinQ;
+        int64_t q[8];
+        int64_t kmin = INT64_MAX, kmax = INT64_MIN;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int64_t r = q0 + threadIdx.x + k * 256;
+            q[k] = INT64_MIN;
+            if (r < nru) {
+                q[k] = ((int64_t)bait[r] << 32) | (uint32_t)oe[r];
+                kmin = q[k] < kmin ? q[k] : kmin;
+                kmax = q[k] > kmax ? q[k] : kmax;
+            }
         }
-        out[r] = (lo < nkeys && keys[lo] == key) ? vals[lo] : 0;
+        for (int off = 32; off > 0; off >>= 1) {
+            const int64_t a = __shfl_down(kmin, off), c = __shfl_down(kmax, off);
+            kmin = a < kmin ? a : kmin;
+            kmax = c > kmax ? c : kmax;
+        }
+        __syncthreads();  // previous iteration done with the shared buffers
+        if (lane == 0) { s_red[0][wave] = kmin; s_red[1][wave] = kmax; }
+        __syncthreads();
+        int64_t mn = s_red[0][0], mx = s_red[1][0];
+        for (int w = 1; w < 4; w++) { mn = s_red[0][w] < mn ? s_red[0][w] : mn; mx = s_red[1][w] > mx ? s_red[1][w] : mx; }
+        const int64_t lo = block_lower_bound(keys, 0, nkeys, mn);
+        int64_t hi = block_lower_bound(keys, lo, nkeys, mx);
+        if (hi < nkeys && keys[hi] == mx) hi++;
+        const int w = (int)(hi - lo);
+        if (hi - lo <= kJoinCap) {
+            for (int e = threadIdx.x; e < w; e += 256) {
+                s_keys[e] = keys[lo + e];
+                s_vals[e] = vals[lo + e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int64_t r = q0 + threadIdx.x + k * 256;
+                if (r >= nru) continue;
+                int a = 0, c = w;
+                while (a < c) {
+                    const int mid = (a + c) >> 1;
+                    if (s_keys[mid] < q[k]) a = mid + 1; else c = mid;
+                }
+                out[r] = (a < w && s_keys[a] == q[k]) ? s_vals[a] : 0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int64_t r = q0 + threadIdx.x + k * 256;
+                if (r >= nru) continue;
+                const int64_t a = lower_bound_g(keys, lo, hi, q[k]);
+                out[r] = (a < hi && keys[a] == q[k]) ? vals[a] : 0;
+            }
+        }
     }
 }
 void launch_count_join(const int32_t *bait, const int32_t *oe, int64_t nru, const int64_t *keys, const int32_t *vals,
                        int64_t nkeys, int32_t *out, hipStream_t st) {
-    int64_t blocks = (nru + 255) / 256;
+    int64_t blocks = (nru + kJoinQ - 1) / kJoinQ;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     count_join_kernel<<<(unsigned)blocks, 256, 0, st>>>(bait, oe, nru, keys, vals, nkeys, out);

@@ -172,7 +172,14 @@ def test_count_join(ctx, oracle):
     vals = rng.integers(1, 500, len(keys)).astype(np.int32)
     t = lambda a: torch.as_tensor(a).to(ctx.device)
     got = ctx.count_join(t(bait), t(oe), t(keys), t(vals)).cpu().numpy()
-    assert np.array_equal(got, oracle.count_join(bait, oe, keys, vals))
+    ref = oracle.count_join(bait, oe, keys, vals)
+    assert np.array_equal(got, ref)                      # unsorted queries: global-memory search path
+    order = np.argsort((bait.astype(np.int64) << 32) | oe, kind="stable")
+    got2 = ctx.count_join(t(bait[order]), t(oe[order]), t(keys), t(vals)).cpu().numpy()
+    assert np.array_equal(got2, ref[order])              # RU keyed by baitID: LDS key-window path
+    assert (got2 == 0).any() and (got2 > 0).any()
+    e = ctx.count_join(t(bait[:5]), t(oe[:5]), t(keys[:0]), t(vals[:0])).cpu().numpy()
+    assert np.array_equal(e, np.zeros(5, dtype=np.int32))  # empty count table: every N is 0
 
 
 def test_theta_grid(ctx, oracle):
