@@ -76,6 +76,7 @@ void chicdiff_hip_default_opts(chicdiff_nbglm_opts *o) {
     o->minmu = 0.5;
     o->outlierSD = 2.0;
     o->dispPriorVar = NAN;
+    o->trendCoef[0] = o->trendCoef[1] = NAN;
 }
 
 int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
@@ -328,6 +329,8 @@ static Opts make_opts(const chicdiff_nbglm_opts *in, int S) {
     r.minDisp = o.minDisp; r.dispTol = o.dispTol; r.kappa0 = o.kappa0; r.betaTol = o.betaTol; r.minmu = o.minmu;
     r.outlierSD = o.outlierSD; r.dispPriorVarIn = o.dispPriorVar; r.maxit = o.maxit; r.betaMaxit = o.betaMaxit;
     r.maxDisp = S > 10 ? (double)S : 10.0;
+    r.trendIn[0] = o.trendCoef[0];
+    r.trendIn[1] = o.trendCoef[1];
     return r;
 }
 
@@ -350,7 +353,12 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_disp_gene(d_counts, d_nf, d, w, o, st);
     }
     // trend: fit_driver.h runs batches of IRLS passes and polls the finished flag between batches
-    {
+    if (o.trendIn[0] == o.trendIn[0] && o.trendIn[1] == o.trendIn[1]) {  // caller-supplied dispersion function
+        launch_trend_init(d, w, o, st);
+        HIPCHK(c, hipMemcpyAsync(w.sc->coefs, o.trendIn, sizeof(double) * 2, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));  // o.trendIn lives on this frame
+        c->h_sc->failed = 0;
+    } else {
         Scope t(c, "trend_fit");
         HipBackend be{c, d, o, SelArgs{}};
         const int trc = drive_trend(be);

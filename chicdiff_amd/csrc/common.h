@@ -29,7 +29,7 @@ struct FitWork {
 };
 
 struct Opts {
-    double minDisp, dispTol, kappa0, betaTol, minmu, outlierSD, dispPriorVarIn, maxDisp;
+    double minDisp, dispTol, kappa0, betaTol, minmu, outlierSD, dispPriorVarIn, maxDisp, trendIn[2];
     int32_t maxit, betaMaxit;
 };
 

@@ -34,7 +34,8 @@ EXPORTS = [
 class Opts(C.Structure):
     _fields_ = [("minDisp", C.c_double), ("dispTol", C.c_double), ("kappa0", C.c_double),
                 ("maxit", C.c_int32), ("betaMaxit", C.c_int32), ("betaTol", C.c_double),
-                ("minmu", C.c_double), ("outlierSD", C.c_double), ("dispPriorVar", C.c_double)]
+                ("minmu", C.c_double), ("outlierSD", C.c_double), ("dispPriorVar", C.c_double),
+                ("trendCoef", C.c_double * 2)]
 
 
 OUT_DOUBLE = ["baseMean", "baseVar", "dispGeneEst", "dispFit", "dispMAP", "dispersion", "log2FoldChange",
@@ -109,7 +110,10 @@ def default_opts(**kw) -> Opts:
     o = Opts()
     load_library().chicdiff_hip_default_opts(C.byref(o))
     for k, v in kw.items():
-        setattr(o, k, v)
+        if k == "trendCoef":
+            o.trendCoef[0], o.trendCoef[1] = float(v[0]), float(v[1])
+        else:
+            setattr(o, k, v)
     return o
 
 

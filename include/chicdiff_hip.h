@@ -72,6 +72,7 @@ typedef struct {
     double minmu;        /* 0.5  */
     double outlierSD;    /* 2.0  */
     double dispPriorVar; /* NaN = estimate; DESeq2's estimateDispersionsMAP(dispPriorVar=) */
+    double trendCoef[2]; /* NaN = fit; else use alpha(mu) = c0 + c1/mu as given (DESeq2: dispersionFunction<-) */
 } chicdiff_nbglm_opts;
 void chicdiff_hip_default_opts(chicdiff_nbglm_opts *opts);
 

@@ -31,8 +31,8 @@ def test_struct_layouts_match_header(lib):
     o = hip.default_opts()
     assert (o.minDisp, o.dispTol, o.kappa0, o.maxit, o.betaMaxit, o.betaTol, o.minmu, o.outlierSD) == \
         (1e-8, 1e-6, 1.0, 100, 100, 1e-8, 0.5, 2.0)
-    assert o.dispPriorVar != o.dispPriorVar  # NaN = estimate
-    assert C.sizeof(hip.Opts) == 64 and C.sizeof(hip.Out) == 21 * 8 and C.sizeof(hip.Scalars) == 56
+    assert o.dispPriorVar != o.dispPriorVar and o.trendCoef[0] != o.trendCoef[0]  # NaN = estimate
+    assert C.sizeof(hip.Opts) == 80 and C.sizeof(hip.Out) == 21 * 8 and C.sizeof(hip.Scalars) == 56
 
 
 def test_product_path_fails_loudly_without_gpu(lib):
