@@ -223,7 +223,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
         c->ws = nullptr;
     }
     const size_t nd = align256(sizeof(double) * (size_t)n), ni = align256(sizeof(int32_t) * (size_t)n);
-    const size_t n_double_arrays = 15 + 1 /*lgm*/, n_int_arrays = 5;
+    const size_t n_double_arrays = 15 + 1 /*lgm*/, n_int_arrays = 6;
     const size_t partials = align256(sizeof(double) * ((size_t)kRedBlocks * 72 + 128));
     const size_t hist = align256(sizeof(double) * (size_t)kMaxS * 2 * kSelBins);
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
@@ -238,7 +238,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     takeD(w.baseMean); takeD(w.baseVar); takeD(w.gm0); takeD(w.gm1); takeD(w.rough); takeD(w.binit0); takeD(w.binit1);
     takeD(w.crow); takeD(w.dispGene); takeD(w.dispFit); takeD(w.dispMAP); takeD(w.disp); takeD(w.beta0); takeD(w.beta1);
     takeD(w.resid); takeD(c->d_lgm);
-    takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter);
+    takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter); takeI(w.optimConv);
     w.partials = (double *)p; p += partials;
     w.hist = (double *)p; p += hist;
     w.sc = (FitScalars *)p; p += align256(sizeof(FitScalars));
@@ -396,6 +396,10 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         {
             Scope t(c, "wald_irls");
             launch_wald_irls(d_counts, d_nf, d, w, o, st);
+        }
+        {
+            Scope t(c, "wald_optim");
+            launch_wald_optim(d_counts, d_nf, d, w, o, st);
         }
         Scope t(c, "wald_final");
         launch_wald_final(d_counts, d_nf, d, w, o, out, st);

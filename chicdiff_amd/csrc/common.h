@@ -21,7 +21,7 @@ struct FitDims {
 struct FitWork {
     double *baseMean, *baseVar, *gm0, *gm1, *rough, *binit0, *binit1, *crow;
     double *dispGene, *dispFit, *dispMAP, *disp, *beta0, *beta1, *resid;
-    int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter;
+    int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter, *optimConv;
     double *partials;             // kRedBlocks x 72 doubles
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
     unsigned long long *queue;    // work-queue heads
@@ -46,6 +46,7 @@ void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_wald_optim(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                        const chicdiff_nbglm_out &out, hipStream_t st);
 void launch_wald_intercept(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,

@@ -185,6 +185,76 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
     }
 }
 
+// Fallback for rows whose IRLS diverged or ran out of iterations.  DESeq2 hands them to
+// optim(L-BFGS-B, bounds +-30) on the log2-scale negative log posterior (fitNbinomGLMsOptim); what is
+// reproduced here is that optimiser's target — the posterior mode inside the box — by damped Fisher
+// scoring with backtracking on the same objective, started from the least-squares start values.
+// A handful of rows per million (single extreme count outliers): one thread per row is plenty.
+__device__ __forceinline__ double optim_objective(const int32_t *__restrict__ counts, const double *__restrict__ nf,
+                                                  int64_t n, int64_t i, int S, uint64_t gmask, double alpha, double size,
+                                                  double la, double crow, double lam, double b0, double b1) {
+    double f = 0.5 * lam * (b0 * b0 + b1 * b1) - crow;
+    const double E0 = exp(b0), E1 = exp(b0 + b1);
+    for (int j = 0; j < S; j++) {
+        const double y = (double)counts[(int64_t)j * n + i];
+        const double mu = nf[(int64_t)j * n + i] * (((gmask >> j) & 1) ? E1 : E0);
+        const double ma = alpha * mu, t = 1.0 + ma;
+        f += (size + y) * flog1p_from(ma, t, rcp(t));
+        if (y > 0) f -= y * (la + flog(mu));
+    }
+    return f;
+}
+__global__ __launch_bounds__(256) void wald_optim_kernel(const int32_t *__restrict__ counts, const double *__restrict__ nf,
+                                                         FitDims d, FitWork w, Opts o) {
+    const int64_t n = d.n;
+    const int S = d.S;
+    const double lam = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
+    const double bound = 30.0 * 0.69314718055994530942;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int flag = -1;  // not attempted
+        if (!w.allZero[i] && !(w.betaIter[i] < o.betaMaxit)) {
+            const double alpha = w.disp[i], size = rcp(alpha), la = flog(alpha), crow = w.crow[i];
+            double b0 = w.binit0[i], b1 = w.binit1[i];
+            double f = optim_objective(counts, nf, n, i, S, d.gmask, alpha, size, la, crow, lam, b0, b1);
+            bool converged = false;
+            for (int it = 0; it < 200 && !converged; it++) {
+                double g0 = lam * b0, g1 = lam * b1, wA = 0, wB = 0;
+                const double E0 = exp(b0), E1 = exp(b0 + b1);
+                for (int j = 0; j < S; j++) {
+                    const bool g = (d.gmask >> j) & 1;
+                    const double y = (double)counts[(int64_t)j * n + i];
+                    const double mu = nf[(int64_t)j * n + i] * (g ? E1 : E0);
+                    const double rt = rcp(fma(alpha, mu, 1.0));
+                    const double sc = (y - mu) * rt, wj = mu * rt;
+                    g0 -= sc;
+                    if (g) { g1 -= sc; wB += wj; } else wA += wj;
+                }
+                const double m00 = wA + wB + lam, m01 = wB, m11 = wB + lam, det = m00 * m11 - m01 * m01;
+                const double d0 = -(m11 * g0 - m01 * g1) / det, d1 = -(m00 * g1 - m01 * g0) / det;
+                double t = 1.0;
+                bool moved = false;
+                for (int h = 0; h < 40; h++, t *= 0.5) {
+                    const double n0 = fmin(fmax(b0 + t * d0, -bound), bound), n1 = fmin(fmax(b1 + t * d1, -bound), bound);
+                    const double fn = optim_objective(counts, nf, n, i, S, d.gmask, alpha, size, la, crow, lam, n0, n1);
+                    if (fn < f) {
+                        if (f - fn < 1e-13 * (fabs(f) + 1.0)) converged = true;
+                        b0 = n0; b1 = n1; f = fn; moved = true;
+                        break;
+                    }
+                }
+                if (!moved) converged = true;
+            }
+            w.beta0[i] = b0;
+            w.beta1[i] = b1;
+            flag = converged ? 1 : 0;
+        }
+        w.optimConv[i] = flag;
+    }
+}
+void launch_wald_optim(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
+    wald_optim_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w, o);
+}
+
 __device__ __forceinline__ int trim_lo(int n) {
     // trimratio c(1/3, 1/4, 1/8) on bins (0,3.5], (3.5,23.5], (23.5,Inf)
     const double tr = n <= 3 ? 1.0 / 3 : (n <= 23 ? 1.0 / 4 : 1.0 / 8);
@@ -233,7 +303,8 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
             const double alpha = w.disp[i], size = rcp(alpha);
             const double b0 = w.beta0[i], b1 = w.beta1[i];
             biter = w.betaIter[i];
-            bconv = biter < o.betaMaxit;
+            const int oc = w.optimConv[i];  // -1 IRLS converged, else the optim fallback ran (1 = reached the mode)
+            bconv = (biter < o.betaMaxit) || oc == 1;
             const double E0 = exp(b0), E1 = exp(b0 + b1);
             const double la = flog(alpha);
             double wA = 0, wB = 0, ll = w.crow[i], m = 0;
@@ -245,10 +316,12 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
                 const double mu = fmax(muf, o.minmu);
                 const double wj = mu * rcp(fma(alpha, mu, 1.0));
                 if (g) wB += wj; else wA += wj;
-                // log dnbinom(y; size, mu) = crow_j - (size+y) log1p(alpha mu) + y log(alpha mu)
-                const double ma = alpha * muf, t = 1.0 + ma;
+                // log dnbinom(y; size, mu) = crow_j - (size+y) log1p(alpha mu) + y log(alpha mu); DESeq2's optim
+                // path evaluates it after flooring mu, the IRLS path before
+                const double mul = oc >= 0 ? mu : muf;
+                const double ma = alpha * mul, t = 1.0 + ma;
                 ll -= (size + y) * flog1p_from(ma, t, rcp(t));
-                if (y > 0) ll += y * (la + flog(muf));
+                if (y > 0) ll += y * (la + flog(mul));
                 if (want_cooks) {
                     const double q = y / nfj;
                     s_q[j * T + tid] = q;

@@ -341,6 +341,56 @@ static fitbeta_res fit_beta_row(const double *y, const double *nf, const int32_t
     return r;
 }
 
+/* A5 fallback.  DESeq2 re-fits rows whose IRLS did not converge with optim(method = "L-BFGS-B",
+ * lower = -30, upper = 30) on the log2-scale negative log posterior (fitNbinomGLMsOptim):
+ *   -sum_j dnbinom(k_j; mu = nf_j 2^(x_j p), size = 1/alpha, log) - sum_k dnorm(p_k; 0, sd = 1/sqrt(lambda), log).
+ * L-BFGS-B itself (R's lbfgsb.c with finite-difference gradients) is not restated: what is
+ * reproduced is its target, the posterior mode inside the box, found here by a damped Fisher-scoring
+ * iteration with backtracking on the same objective (agrees with R's optimum to optim's own
+ * tolerance, factr = 1e7).  Natural-log scale internally; returns 1 when a mode was reached. */
+static double optim_objective(const double *y, const double *nf, const int32_t *g, int S, double alpha, double lam,
+                              double b0, double b1) {
+    double f = 0.5 * lam * (b0 * b0 + b1 * b1);
+    for (int j = 0; j < S; j++) {
+        double mu = nf[j] * exp(b0 + (g[j] ? b1 : 0.0));
+        f -= oracle_dnbinom_mu_log(y[j], 1.0 / alpha, mu);
+    }
+    return f;
+}
+static int beta_optim_row(const double *y, const double *nf, const int32_t *g, int S, double alpha, double lam,
+                          double *b0io, double *b1io) {
+    const double bound = 30.0 * M_LN2; /* +-30 on the log2 scale */
+    double b0 = *b0io, b1 = *b1io;
+    double f = optim_objective(y, nf, g, S, alpha, lam, b0, b1);
+    int converged = 0;
+    for (int it = 0; it < 200 && !converged; it++) {
+        double g0 = lam * b0, g1 = lam * b1, wA = 0, wB = 0;
+        for (int j = 0; j < S; j++) {
+            double mu = nf[j] * exp(b0 + (g[j] ? b1 : 0.0));
+            double sc = (y[j] - mu) / (1.0 + alpha * mu), w = mu / (1.0 + alpha * mu);
+            g0 -= sc;
+            if (g[j]) { g1 -= sc; wB += w; } else wA += w;
+        }
+        double m00 = wA + wB + lam, m01 = wB, m11 = wB + lam, det = m00 * m11 - m01 * m01;
+        double d0 = -(m11 * g0 - m01 * g1) / det, d1 = -(m00 * g1 - m01 * g0) / det;
+        double t = 1.0;
+        int moved = 0;
+        for (int h = 0; h < 40; h++, t *= 0.5) {
+            double n0 = fmin(fmax(b0 + t * d0, -bound), bound), n1 = fmin(fmax(b1 + t * d1, -bound), bound);
+            double fn = optim_objective(y, nf, g, S, alpha, lam, n0, n1);
+            if (fn < f) {
+                if (f - fn < 1e-13 * (fabs(f) + 1.0)) converged = 1;
+                b0 = n0; b1 = n1; f = fn; moved = 1;
+                break;
+            }
+        }
+        if (!moved) converged = 1; /* no descent left at working precision: at the mode (or pinned to the box) */
+    }
+    *b0io = b0;
+    *b1io = b1;
+    return converged;
+}
+
 /* R mean(x, trim): drop floor(n*trim) from each end of the sorted values */
 static double trimmed_mean(double *v, int n, double trim) {
     qsort(v, (size_t)n, sizeof(double), cmp_double);
@@ -582,12 +632,22 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
         lA /= cellsize[0];
         lB /= cellsize[1];
         fitbeta_res fb = fit_beta_row(y, nfr, g, S, alpha, lA, lB - lA, lambda, o.betaTol, o.betaMaxit, o.minmu);
-        int bconv = fb.iter < o.betaMaxit;
-        if (!bconv || !(fb.v0 > 0) || !(fb.v1 > 0) || isnan(fb.b0) || isnan(fb.b1)) any_nonconv |= 1;
+        int bconv = fb.iter < o.betaMaxit, used_optim = 0;
+        if (!bconv || isnan(fb.b0) || isnan(fb.b1)) {
+            used_optim = 1;
+            /* fitNbinomGLMsOptim: start from the LS start values, store the optimum whatever happens */
+            double ob0 = lA, ob1 = lB - lA;
+            bconv = beta_optim_row(y, nfr, g, S, alpha, lambda, &ob0, &ob1);
+            fitbeta_res fo = fit_beta_row(y, nfr, g, S, alpha, ob0, ob1, lambda, o.betaTol, 0, o.minmu); /* covariance at the optimum */
+            fo.iter = fb.iter;
+            fb = fo;
+        }
+        if (!bconv || !(fb.v0 > 0) || !(fb.v1 > 0)) any_nonconv |= 1;
         double ll = 0, muf[MAXS];
         for (int j = 0; j < S; j++) {
-            muf[j] = nfr[j] * exp(fb.b0 + (g[j] ? fb.b1 : 0.0)); /* no minmu floor here */
-            ll += oracle_dnbinom_mu_log(y[j], 1.0 / alpha, muf[j]);
+            muf[j] = nfr[j] * exp(fb.b0 + (g[j] ? fb.b1 : 0.0)); /* no minmu floor here ... */
+            /* ... except on the optim path, where DESeq2 evaluates logLike after flooring mu_row */
+            ll += oracle_dnbinom_mu_log(y[j], 1.0 / alpha, used_optim ? fmax(muf[j], o.minmu) : muf[j]);
             if (out->mu) out->mu[(int64_t)j * n + i] = muf[j];
         }
         double B0 = LOG2E * fb.b0, B1 = LOG2E * fb.b1;
