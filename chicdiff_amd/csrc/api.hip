@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -358,6 +359,12 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         HIPCHK(c, hipMemcpyAsync(w.sc->coefs, o.trendIn, sizeof(double) * 2, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));  // o.trendIn lives on this frame
         c->h_sc->failed = 0;
+    } else if (!c->allreduce && !getenv("CHICDIFF_TREND_MULTILAUNCH")) {
+        Scope t(c, "trend_fit");  // single rank: one persistent launch (LDS-resident rows, grid barrier per IRLS pass)
+        launch_trend_persistent(d, w, o, st);
+        HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (c->h_sc->failed == 3) return fail(c, CHICDIFF_E_HIP, "trend fit: grid barrier timed out");
     } else {
         Scope t(c, "trend_fit");
         HipBackend be{c, d, o, SelArgs{}};

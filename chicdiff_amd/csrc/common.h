@@ -39,6 +39,7 @@ void launch_prep_finish(FitDims d, FitWork w, hipStream_t st);          // parti
 void launch_xim(FitDims d, FitWork w, hipStream_t st);                  // colsum -> xim
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_disp_map(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st);  // single rank: whole trend fit, one launch
 void launch_trend_init(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st, bool fused_step);  // pass + reduce (+ step when single rank)
 void launch_trend_step(FitDims d, FitWork w, Opts o, hipStream_t st);   // consumes sums, advances the state machine

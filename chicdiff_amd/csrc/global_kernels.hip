@@ -85,6 +85,116 @@ __global__ __launch_bounds__(256) void trend_reduce_kernel(FitWork w, int nblk, 
 }
 __global__ void trend_step_kernel(FitWork w) { trend_step(w.sc, w.partials + (size_t)kRedBlocks * 72); }
 
+// ---- single-rank fast path: the whole trend fit in ONE persistent launch ------------------------------
+// One 1024-thread workgroup per CU; each owns a contiguous block of rows and keeps their
+// (baseMean, dispGeneEst) pairs in LDS (2 M rows = 125 KB per CU of the 160 KB), so the ~20 IRLS passes
+// of glm.fit read HBM once instead of 20 times and need no kernel boundary: per pass every workgroup
+// publishes 8 partial sums, a grid barrier (monotonic counter, agent-scope release/acquire, cdna guide
+// G16) follows, and every workgroup adds the partials in the same fixed order and advances its own copy
+// of the state machine (fit_state.h) — identical in all workgroups, no broadcast needed.
+constexpr int kTpBlocks = 256, kTpThreads = 1024, kTpCap = 8000;  // rows cached per workgroup (2 x 64 000 B of LDS)
+
+__device__ __forceinline__ bool grid_sync(unsigned int *ctr, unsigned int target) {
+    __shared__ int ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < (1 << 24)) {
+            __builtin_amdgcn_s_sleep(4);
+            spins++;
+        }
+        ok = spins < (1 << 24);  // a bounded spin: a lost workgroup must not hang the device
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+__global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d, FitWork w, double minDisp) {
+    __shared__ double s_bm[kTpCap], s_y[kTpCap];
+    __shared__ double red[kTrendSums][16];
+    __shared__ FitScalars st;  // only the trend fields are used
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t per = (d.n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = (r0 + per < d.n) ? r0 + per : d.n;
+    const int64_t nrows = r1 > r0 ? r1 - r0 : 0;
+    const int ncache = nrows < kTpCap ? (int)nrows : kTpCap;
+    for (int k = tid; k < ncache; k += kTpThreads) {
+        const int64_t i = r0 + k;
+        const double y = w.dispGene[i];
+        const bool use = !w.allZero[i] && (y > 100 * minDisp);  // useForFit
+        s_bm[k] = w.baseMean[i];
+        s_y[k] = use ? y : NAN;
+    }
+    if (tid == 0) trend_init(&st);
+    __syncthreads();
+    unsigned int *ctr = reinterpret_cast<unsigned int *>(w.queue + 8);
+    double *slots = w.partials;  // [2][gridDim.x][kTrendSums], double-buffered by pass parity
+    bool alive = true;
+    for (unsigned int pass = 0; pass < 11 * 27 + 16; pass++) {
+        if (st.finished) break;
+        double v[kTrendSums] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = tid; k < ncache; k += kTpThreads) {
+            const double y = s_y[k];
+            if (y == y) trend_row(&st, s_bm[k], y, v);
+        }
+        for (int64_t i = r0 + kTpCap + tid; i < r1; i += kTpThreads) {  // rows beyond the LDS cache stream from HBM
+            const double y = w.dispGene[i];
+            if (!w.allZero[i] && (y > 100 * minDisp)) trend_row(&st, w.baseMean[i], y, v);
+        }
+#pragma unroll
+        for (int k = 0; k < kTrendSums; k++) {
+            double x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if (lane == 0) red[k][wave] = x;
+        }
+        __syncthreads();
+        double *mine = slots + ((size_t)(pass & 1) * gridDim.x + blockIdx.x) * kTrendSums;
+        if (tid < kTrendSums) {
+            double acc = 0;
+            for (int q = 0; q < kTpThreads / 64; q++) acc += red[tid][q];
+            mine[tid] = acc;
+        }
+        alive = grid_sync(ctr, (pass + 1) * gridDim.x);
+        if (!alive) break;
+        // every workgroup: fixed-order sum of all partials (wave k sums quantity k: 64 lanes x strided
+        // partials, then a shuffle tree — the same order in every workgroup), then the same state-machine step
+        const double *all = slots + (size_t)(pass & 1) * gridDim.x * kTrendSums;
+        if (wave < kTrendSums) {
+            double acc = 0;
+            for (unsigned int b = lane; b < gridDim.x; b += 64) acc += all[(size_t)b * kTrendSums + wave];
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+            if (lane == 0) red[wave][0] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double sums[kTrendSums];
+            for (int k = 0; k < kTrendSums; k++) sums[k] = red[k][0];
+            trend_step(&st, sums);
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        FitScalars *sc = w.sc;
+        sc->coefs[0] = st.coefs[0]; sc->coefs[1] = st.coefs[1];
+        sc->b[0] = st.b[0]; sc->b[1] = st.b[1];
+        sc->devold = st.devold;
+        sc->inner_it = st.inner_it; sc->outer_it = st.outer_it; sc->phase = st.phase;
+        sc->conv = st.conv;
+        sc->failed = alive ? (st.finished ? st.failed : 2) : 3;  // 3: grid barrier timed out
+        sc->finished = 1;
+    }
+}
+void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
+    (void)hipMemsetAsync(w.queue + 8, 0, 8, st);
+    trend_persistent_kernel<<<kTpBlocks, kTpThreads, 0, st>>>(d, w, o.minDisp);
+}
+
 void launch_trend_init(FitDims, FitWork w, Opts, hipStream_t st) { trend_init_kernel<<<1, 1, 0, st>>>(w); }
 constexpr int kTrendBlocks = 512;
 void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st, bool fused_step) {

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
                 A.w.beta0[row] = b0;
                 A.w.beta1[row] = b1;
                 A.w.betaIter[row] = iter_out;
+                if (iter_out >= o.betaMaxit) atomicAdd(A.w.queue + 16, 1ull);  // rows for the optim fallback (rare)
                 need = true;
             }
         }
@@ -210,8 +211,13 @@ __global__ __launch_bounds__(256) void wald_optim_kernel(const int32_t *__restri
     const int S = d.S;
     const double lam = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
     const double bound = 30.0 * 0.69314718055994530942;
+    const bool any = w.queue[16] != 0;  // no row left by the IRLS: only the flags are written
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         int flag = -1;  // not attempted
+        if (!any) {
+            w.optimConv[i] = flag;
+            continue;
+        }
         if (!w.allZero[i] && !(w.betaIter[i] < o.betaMaxit)) {
             const double alpha = w.disp[i], size = rcp(alpha), la = flog(alpha), crow = w.crow[i];
             double b0 = w.binit0[i], b1 = w.binit1[i];
