@@ -103,6 +103,35 @@ void launch_prep_finish(FitDims d, FitWork w, hipStream_t st) { colsum_finish_ke
 void launch_xim(FitDims d, FitWork w, hipStream_t st) { xim_kernel<<<1, 64, 0, st>>>(d, w); }
 
 // ------------------------------------------------------------------------------------------
+// Start values of the two line searches, one thread per row, so that the queue refill inside the
+// search kernels is pure data movement.
+//   gene-wise (A2.3-2.4): alpha_init = clamp(min(roughDisp, momentsDisp)); rough[] <- alpha_init, resid[] <- log
+//   MAP (A4): dispFit, prior mean log(dispFit), start log(dispGeneEst > 0.1 dispFit ? dispGeneEst : dispFit),
+//             outlier flag log(dispGeneEst) > log(dispFit) + outlierSD * sqrt(varLogDispEsts)
+template <bool MAP>
+__global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Opts o) {
+    const FitScalars *sc = w.sc;
+    const double xim = sc->xim, c0 = sc->coefs[0], c1 = sc->coefs[1];
+    const double out_thr = MAP ? o.outlierSD * sqrt(sc->varLogDispEsts) : 0.0;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+        if (w.allZero[i]) continue;
+        const double bm = w.baseMean[i];
+        if (!MAP) {
+            const double moments = (w.baseVar[i] - xim * bm) / (bm * bm);
+            const double a0 = fmin(fmax(o.minDisp, fmin(w.rough[i], moments)), o.maxDisp);
+            w.rough[i] = a0;
+            w.resid[i] = log(a0);
+        } else {
+            const double dg = w.dispGene[i], df = c0 + c1 / bm;
+            const double ldf = log(df);
+            w.dispFit[i] = df;
+            w.resid[i] = ldf;
+            w.rough[i] = dg > 0.1 * df ? log(dg) : ldf;
+            w.outlier[i] = log(dg) > ldf + out_thr;
+        }
+    }
+}
+
 constexpr int kChunk = 64;   // rows a wave takes from the global queue per atomic
 enum Phase : int { PH_NEED = 0, PH_INIT = 1, PH_SEARCH = 2, PH_GRID1 = 3, PH_GRID2 = 4, PH_DONE = 5 };
 
@@ -199,8 +228,9 @@ __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c,
 __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int S, uint64_t gmask,
                                            bool p2, double gm0, double gm1, double minmu, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
-                                           double &lp, double &dlp, const LogEntry *lt) {
+                                           double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
     const RowConsts c = row_consts(a, lt);
+    alpha_out = c.alpha;
     // per-tick table (LDS, [entry][lane]): P_n and H_n for n = 0..nr
     {
         double P = 1.0, H = 0.0, zz = c.r;
@@ -243,20 +273,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     const double glo = log(1e-8), ghi = log(o.maxDisp), gstep = (ghi - glo) / 19.0;
     FitScalars *sc = A.w.sc;
     // fit-wide scalars (uniform)
-    const double xim = sc->xim;
-    double c0 = 0, c1 = 0, prior_isig = 0, out_thr = 0;
-    if (MAP) {
-        c0 = sc->coefs[0];
-        c1 = sc->coefs[1];
-        prior_isig = 1.0 / sc->dispPriorVar;
-        out_thr = o.outlierSD * sqrt(sc->varLogDispEsts);
-    }
+    const double prior_isig = MAP ? 1.0 / sc->dispPriorVar : 0.0;
     unsigned long long *queue = A.w.queue + (MAP ? 1 : 0);
 
     int phase = PH_NEED, iter = 0, iacc = 0, gt = 0, gbi = 0;
     int64_t row = -1;
     double a = 0, lp = 0, dlp = 0, kappa = 0, init_lp = 0, a0 = 0, gm0 = 0, gm1 = 0, prior_mean = 0;
-    double gbest = 0, ghat = 0, dgene = 0, a_new = 0;
+    double gbest = 0, ghat = 0, dgene = 0, a_new = 0, alpha_cur = 0;
+    int is_outlier = 0;
     bool queue_empty = false;
     unsigned long long chunk_next = 0, chunk_end = 0;
     const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -265,6 +289,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
 
     for (;;) {
         // ---- refill: lanes without a row pull the next ones from the queue -----------------
+#pragma unroll 1
         for (int attempt = 0; attempt < 4; attempt++) {
             const unsigned long long needmask = __ballot(phase == PH_NEED);
             if (!needmask) break;
@@ -314,17 +339,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     }
                     gm0 = A.w.gm0[r];
                     gm1 = A.w.gm1[r];
-                    const double bm = A.w.baseMean[r];
-                    if (!MAP) {
-                        const double moments = (A.w.baseVar[r] - xim * bm) / (bm * bm);
-                        a0 = fmin(fmax(o.minDisp, fmin(A.w.rough[r], moments)), o.maxDisp);
-                        a = log(a0);
+                    if (!MAP) {  // start values come from disp_init_kernel
+                        a0 = A.w.rough[r];
+                        a = A.w.resid[r];
                     } else {
                         dgene = A.w.dispGene[r];
-                        const double df = c0 + c1 / bm;
-                        A.w.dispFit[r] = df;
-                        prior_mean = log(df);
-                        a = log(dgene > 0.1 * df ? dgene : df);
+                        prior_mean = A.w.resid[r];
+                        a = A.w.rough[r];
+                        is_outlier = A.w.outlier[r];
                     }
                     phase = PH_INIT;
                 }
@@ -355,14 +377,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         }
 
         // ---- evaluate -------------------------------------------------------------------------
-        double l_new = 0, dl_new = 0;
+        double l_new = 0, dl_new = 0, alpha_new = 0;
         const bool active = phase != PH_DONE && phase != PH_NEED;
         // (A "drain mode" that regrouped a straggler wave's lanes as 4-16 lanes per remaining row cut the
         // tail by ~0.3 ms at 2 M rows but summed the samples in tree order, so results were no longer
         // bit-reproducible from run to run; removed in favour of determinism.)
         if (active)
             eval_point(s_nf, s_y, s_tab, lane, S, gmask, p2, gm0, gm1, o.minmu, a_eval, MAP, prior_mean, prior_isig, l_new,
-                       dl_new, s_logtab);
+                       dl_new, alpha_new, s_logtab);
 
         // ---- advance the per-lane state machine ---------------------------------------------
         bool finished = false;  // line search over: decide between result and grid fallback
@@ -372,6 +394,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             lp = l_new;
             dlp = dl_new;
             init_lp = l_new;
+            alpha_cur = alpha_new;  // exp(a), kept so that finishing needs no further exp()
             kappa = o.kappa0;
             iter = 0;
             iacc = 0;
@@ -382,6 +405,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             if (theta_kappa <= theta_hat_kappa) {
                 iacc++;
                 a = a_new;
+                alpha_cur = alpha_new;
                 const double change = l_new - lp;
                 if (change < o.dispTol) {
                     lp = l_new;
@@ -401,14 +425,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             if (finished) {
                 bool grid;
                 if (!MAP) {
-                    double dd = fmin(exp(a), o.maxDisp);
+                    double dd = fmin(alpha_cur, o.maxDisp);
                     if (lp < init_lp + fabs(init_lp) / 1e6) dd = a0;  // noIncrease: keep alpha_init
                     const bool conv = (iter < o.maxit) && (iter != 1);
                     grid = !conv && dd > o.minDisp * 10;
                     result = dd;
                 } else {
                     grid = !(iter < o.maxit);
-                    result = exp(a);
+                    result = alpha_cur;
                 }
                 if (grid) {
                     phase = PH_GRID1;
@@ -445,10 +469,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                 A.w.dispGene[row] = dd;
                 A.w.geneIter[row] = iter;
             } else {
-                const bool outl = log(dgene) > prior_mean + out_thr;
                 A.w.dispMAP[row] = dd;
-                A.w.disp[row] = outl ? dgene : dd;
-                A.w.outlier[row] = outl;
+                A.w.disp[row] = is_outlier ? dgene : dd;
                 A.w.mapIter[row] = iter;
             }
             phase = PH_NEED;
@@ -459,6 +481,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
 
 static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                         hipStream_t st) {
+    if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o);
+    else disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o);
     DispArgs A{counts, nf, d, w, o, nullptr};
     const char *stamp_file = getenv("CHICDIFF_DISP_STAMPS");
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
