@@ -28,6 +28,53 @@ namespace cd {
 // ------------------------------------------------------------------------------------------
 // prep: per-row moments of the normalised counts (getBaseMeansAndVariances, roughDispEstimate,
 // linearModelMu group means).  One thread per row, sample-major loads are coalesced.
+// per-row statistics from the normalised counts q_j = k_j / nf_j (shared by both variants)
+__device__ __forceinline__ void prep_store(FitDims d, FitWork w, int64_t i, double s, double g0, double g1, double v,
+                                           double est, int64_t tot) {
+    w.baseMean[i] = s / d.S;
+    w.baseVar[i] = v / (d.S - 1);
+    w.gm0[i] = g0;
+    w.gm1[i] = g1;
+    w.rough[i] = fmax(est / (d.S - d.p), 0.0);
+    w.allZero[i] = (tot == 0);
+}
+
+// S <= 16: the row's q_j live in registers — one read of counts and offsets, one division per sample
+__global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__ counts,
+                                                     const double *__restrict__ nf, FitDims d, FitWork w) {
+    const int64_t n = d.n;
+    const int S = d.S;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double q[16];
+        double s = 0, g0 = 0, g1 = 0;
+        int64_t tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            q[j] = 0;
+            if (j < S) {
+                const int32_t k = counts[(int64_t)j * n + i];
+                q[j] = (double)k / nf[(int64_t)j * n + i];
+                tot += k;
+                s += q[j];
+                if ((d.gmask >> j) & 1) g1 += q[j]; else g0 += q[j];
+            }
+        }
+        const double bm = s / S;
+        g0 /= d.nA;
+        if (d.p == 2) g1 /= d.nB;
+        const double m0 = fmax(1.0, g0), m1 = fmax(1.0, g1);
+        double v = 0, est = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < S) {
+                v += (q[j] - bm) * (q[j] - bm);
+                const double mj = ((d.gmask >> j) & 1) ? m1 : m0;
+                est += ((q[j] - mj) * (q[j] - mj) - mj) / (mj * mj);
+            }
+        prep_store(d, w, i, s, g0, g1, v, est, tot);
+    }
+}
+
 __global__ __launch_bounds__(256) void prep_kernel(const int32_t *__restrict__ counts,
                                                    const double *__restrict__ nf, FitDims d, FitWork w) {
     const int64_t n = d.n;
@@ -53,12 +100,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const int32_t *__restrict__ c
             const double mj = ((d.gmask >> j) & 1) ? m1 : m0;
             est += ((q - mj) * (q - mj) - mj) / (mj * mj);
         }
-        w.baseMean[i] = bm;
-        w.baseVar[i] = v / (S - 1);
-        w.gm0[i] = g0;
-        w.gm1[i] = g1;
-        w.rough[i] = fmax(est / (S - d.p), 0.0);
-        w.allZero[i] = (tot == 0);
+        prep_store(d, w, i, s, g0, g1, v, est, tot);
     }
 }
 
@@ -80,12 +122,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const double *__restrict__ 
     if (threadIdx.x == 0) w.partials[(int64_t)j * gridDim.x + blockIdx.x] = red[0];
 }
 
+// one wave per column: strided fixed-order sum of the block partials, then a shuffle tree
 __global__ void colsum_finish_kernel(FitDims d, FitWork w, int nblk) {
-    const int j = threadIdx.x;
-    if (j > d.S) return;
+    const int j = blockIdx.x, lane = threadIdx.x;
     double s = 0;
-    for (int b = 0; b < nblk; b++) s += w.partials[(int64_t)j * nblk + b];
-    if (j < d.S) w.sc->colsum[j] = s; else w.sc->nnz = s;
+    for (int b = lane; b < nblk; b += 64) s += w.partials[(int64_t)j * nblk + b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) {
+        if (j < d.S) w.sc->colsum[j] = s; else w.sc->nnz = s;
+    }
 }
 
 __global__ void xim_kernel(FitDims d, FitWork w) {
@@ -95,11 +140,13 @@ __global__ void xim_kernel(FitDims d, FitWork w) {
     w.sc->xim = x / d.S;
 }
 
+constexpr int kColsumBlocks = 512;  // per column; (S+1) x 512 partials fit the 1024 x 72 partials buffer for S <= 64
 void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts, hipStream_t st) {
-    prep_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
-    colsum_kernel<<<dim3(64, d.S + 1), 256, 0, st>>>(nf, d, w);
+    if (d.S <= 16) prep16_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
+    else prep_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
+    colsum_kernel<<<dim3(kColsumBlocks, d.S + 1), 256, 0, st>>>(nf, d, w);
 }
-void launch_prep_finish(FitDims d, FitWork w, hipStream_t st) { colsum_finish_kernel<<<1, 128, 0, st>>>(d, w, 64); }
+void launch_prep_finish(FitDims d, FitWork w, hipStream_t st) { colsum_finish_kernel<<<d.S + 1, 64, 0, st>>>(d, w, kColsumBlocks); }
 void launch_xim(FitDims d, FitWork w, hipStream_t st) { xim_kernel<<<1, 64, 0, st>>>(d, w); }
 
 // ------------------------------------------------------------------------------------------
