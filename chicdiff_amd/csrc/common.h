@@ -67,6 +67,7 @@ struct SelArgs {
 };
 void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st);     // digit histograms for the live prefixes
 void launch_sel_step(SelArgs a, FitWork w, hipStream_t st);     // pick bins, extend prefixes
+void launch_sel_shortcut(SelArgs a, FitWork w, hipStream_t st); // single rank: gather the candidates left after two rounds, finish by sorting
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st);   // prefixes -> values; median into sc
 
 void launch_gather_sf(FitWork w, int S, double *d_sf, hipStream_t st);  // select results -> sf[S]

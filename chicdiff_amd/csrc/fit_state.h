@@ -47,6 +47,8 @@ struct FitScalars {
     double sel_rank[kMaxS * 2];  // remaining 0-based rank inside the current prefix
     double sel_count[kMaxS];     // population per column
     double sel_value[kMaxS * 2]; // selected order statistics
+    uint32_t sel_cnt[kMaxS * 2]; // single-rank shortcut: candidates left after two rounds, per (column, slot)
+    int32_t sel_fast_done, _pad2; // 1 = the shortcut resolved every order statistic of the running select
 };
 
 // order-preserving map double -> uint64 (NaN never passed in)

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(SelArgs a, FitWork w, int
     __shared__ unsigned int h[2][kSelBins];
     const int col = blockIdx.y;
     const FitScalars *sc = w.sc;
+    if (!sel_first_round(a.shift) && sc->sel_fast_done) return;  // the shortcut already has the answers
     for (int k = threadIdx.x; k < 2 * kSelBins; k += 256) (&h[0][0])[k] = 0;
     __syncthreads();
     const bool first = sel_first_round(a.shift);  // first round: every key, whatever an earlier select left behind
@@ -277,6 +278,8 @@ __global__ __launch_bounds__(256) void sel_step_kernel(SelArgs a, FitWork w, int
     const int col = blockIdx.x;
     FitScalars *sc = w.sc;
     const bool first = sel_first_round(a.shift);
+    if (!first && sc->sel_fast_done) return;
+    if (first && col == 0 && threadIdx.x == 0) sc->sel_fast_done = 0;  // (read again only after later launches)
     const uint64_t p0 = first ? 0 : sc->sel_prefix[2 * col], p1 = first ? 0 : sc->sel_prefix[2 * col + 1];
     double rank0 = sc->sel_rank[2 * col], rank1 = sc->sel_rank[2 * col + 1];
     const int nb = 1 << bits, per = (nb + 255) / 256;
@@ -324,6 +327,69 @@ __global__ __launch_bounds__(256) void sel_step_kernel(SelArgs a, FitWork w, int
     }
 }
 
+// ---- single-rank shortcut: after two rounds (24 of 64 key bits fixed) only a handful of keys share
+// the live prefixes; gather them and finish in one block per column instead of four more passes over
+// all the data.  Exact and order-independent (a sort), so results equal the six-round path bit for bit.
+constexpr int kSelCap = 4096;  // candidates per (column, slot): the histogram buffer holds exactly that many
+__global__ __launch_bounds__(256) void sel_compact_kernel(SelArgs a, FitWork w) {
+    const int col = blockIdx.y;
+    FitScalars *sc = w.sc;
+    const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
+    const bool same = p0 == p1;
+    uint64_t *cand = reinterpret_cast<uint64_t *>(w.hist) + (size_t)col * 2 * kSelCap;
+    uint64_t key;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        if (!sel_key(a, sc, col, i, key)) continue;
+        int slot = -1;
+        if (sel_match(key, p0, 40)) slot = 0;
+        else if (!same && sel_match(key, p1, 40)) slot = 1;
+        if (slot < 0) continue;
+        const unsigned pos = atomicAdd(&sc->sel_cnt[2 * col + slot], 1u);
+        if (pos < (unsigned)kSelCap) cand[(size_t)slot * kSelCap + pos] = key;
+    }
+}
+__global__ __launch_bounds__(256) void sel_small_kernel(SelArgs a, FitWork w) {
+    __shared__ uint64_t s_k[kSelCap];
+    FitScalars *sc = w.sc;
+    bool fits = true;
+    for (int q = 0; q < 2 * a.ncol; q++) fits &= sc->sel_cnt[q] <= (unsigned)kSelCap;  // same verdict in every block
+    if (!fits) return;  // the remaining radix rounds take over
+    const int col = blockIdx.x;
+    const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
+    const uint64_t *cand = reinterpret_cast<const uint64_t *>(w.hist) + (size_t)col * 2 * kSelCap;
+    uint64_t result[2] = {p0, p1};
+    for (int slot = 0; slot < 2; slot++) {
+        const int hslot = (slot == 1 && p0 != p1) ? 1 : 0;
+        const int m = (int)sc->sel_cnt[2 * col + hslot];
+        if (m == 0) continue;  // empty population: prefixes stay as they are (median NaN via sel_count)
+        int len = 64;
+        while (len < m) len <<= 1;
+        __syncthreads();
+        for (int e = threadIdx.x; e < len; e += 256) s_k[e] = e < m ? cand[(size_t)hslot * kSelCap + e] : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= len; k <<= 1)  // bitonic sort, ascending
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int e = threadIdx.x; e < len; e += 256) {
+                    const int p = e ^ j;
+                    if (p > e) {
+                        const uint64_t x = s_k[e], y = s_k[p];
+                        const bool up = (e & k) == 0;
+                        if ((x > y) == up) { s_k[e] = y; s_k[p] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        const int r = (int)sc->sel_rank[2 * col + slot];  // rank inside the prefix (set by the second round)
+        result[slot] = s_k[r < m ? r : m - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sc->sel_prefix[2 * col] = result[0];
+        sc->sel_prefix[2 * col + 1] = result[1];
+        if (col == 0) sc->sel_fast_done = 1;
+    }
+}
+
 __global__ void sel_finish_kernel(SelArgs a, FitWork w) {
     const int c = threadIdx.x;
     if (c >= a.ncol) return;
@@ -355,6 +421,11 @@ void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st) {
 void launch_sel_step(SelArgs a, FitWork w, hipStream_t st) {
     const int bits = sel_bits(a.shift);
     sel_step_kernel<<<a.ncol, 256, 0, st>>>(a, w, bits);
+}
+void launch_sel_shortcut(SelArgs a, FitWork w, hipStream_t st) {
+    (void)hipMemsetAsync(w.sc->sel_cnt, 0, sizeof(uint32_t) * 2 * a.ncol, st);
+    sel_compact_kernel<<<dim3(sel_blocks(a.n), a.ncol), 256, 0, st>>>(a, w);
+    sel_small_kernel<<<a.ncol, 256, 0, st>>>(a, w);
 }
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st) { sel_finish_kernel<<<1, 64, 0, st>>>(a, w); }
 
