@@ -7,7 +7,8 @@ histograms, deviance sums).  This module turns a ``torch.distributed`` process g
 C callback of ``include/chicdiff_hip.h`` (``chicdiff_allreduce_fn``).
 
 The buffer the library passes is device memory on the GPU path (backend ``nccl`` = RCCL over
-xGMI) and host memory in the CPU test harness (backend ``gloo``); ``memory`` says which.
+xGMI) and host memory in the CPU test harness (backend ``gloo``); ``memory`` says which
+(``device_via_host`` stages a device buffer through the host so that gloo can carry it).
 """
 from __future__ import annotations
 
@@ -41,8 +42,8 @@ class AllReduceHook:
         import torch
         import torch.distributed as dist
 
-        if memory not in ("device", "host"):
-            raise ValueError("memory must be 'device' or 'host'")
+        if memory not in ("device", "host", "device_via_host"):
+            raise ValueError("memory must be 'device', 'host' or 'device_via_host'")
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.calls = 0
@@ -54,6 +55,16 @@ class AllReduceHook:
                 count = int(count)
                 if memory == "device":
                     t = torch.as_tensor(_RawDevice(int(ptr), count), device=device)
+                elif memory == "device_via_host":
+                    # device buffer, CPU-side transport (gloo): several ranks may share one GPU this way,
+                    # which RCCL does not allow — used to test the sharded HIP path on a single-GPU box
+                    t = torch.as_tensor(_RawDevice(int(ptr), count), device=device)
+                    h = t.cpu()  # synchronises with the stream the library enqueued on (torch's current stream)
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                    t.copy_(h)
+                    self.calls += 1
+                    self.doubles += count
+                    return 0
                 else:
                     buf = (C.c_double * count).from_address(int(ptr))
                     t = torch.from_numpy(np.frombuffer(buf, dtype=np.float64))  # shares the memory

@@ -172,11 +172,11 @@ class HipContext:
         k = self.lib.chicdiff_hip_kernel_times(self.h, buf, 32)
         return {buf[i].name.decode(): (buf[i].ms, buf[i].launches) for i in range(min(k, 32))}
 
-    def set_process_group(self, group=None):
+    def set_process_group(self, group=None, memory="device"):
         """Route the library's sum-all-reduces through torch.distributed (backend nccl = RCCL)."""
         from .dist import AllReduceHook
 
-        self._hook = AllReduceHook(group, memory="device", device=self.device)
+        self._hook = AllReduceHook(group, memory=memory, device=self.device)
         self._check(self.lib.chicdiff_hip_set_allreduce(self.h, self._hook.fn, None, self._hook.world, self._hook.rank))
 
     def to_device(self, a, dtype):

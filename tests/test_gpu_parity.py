@@ -464,3 +464,60 @@ def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     r = rel(p2[ok], p1[ok])
     print("permutation: max rel", r.max(), "frac within 1e-9", np.mean(r < 1e-9))
     assert np.array_equal(np.isnan(p1), np.isnan(p2)) and np.mean(r < 1e-9) > 0.999 and r.max() < 1e-4
+
+
+def _two_rank_worker(rank, world, port, n, S, q):
+    import os
+    import torch.distributed as dist
+    from chicdiff_amd import hip
+    from chicdiff_amd.dist import shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = synth.make(n, S, fragments=2)
+        fm = d["fragFullMean"].reshape(n, 2, S).sum(axis=1)
+        lo, hi = shard_bounds(n, world, rank)
+        c = hip.HipContext(0)
+        c.set_process_group(memory="device_via_host")
+        dk, dF = c.to_device(d["counts"][lo:hi], np.int32), c.to_device(fm[lo:hi], np.float64)
+        out, sc = c.wald_test(dk, dF, d["group"], theta=0.5)
+        assert c._hook.error is None and c._hook.calls > 20
+        q.put((rank, lo, hi, {k: v.cpu().numpy() for k, v in out.items()}, sc["trendCoef"], sc["sizeFactors"], sc["dispPriorVar"]))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_one_gpu_match_single_rank(ctx):
+    """world_size 2 on the real kernels: two processes share the one GPU of this box (RCCL forbids that,
+    so the hook stages the device buffers through gloo), each fits its half of the rows, every global
+    statistic goes through the all-reduce hook; the concatenated result must match the one-rank fit."""
+    import socket
+    import torch.multiprocessing as mp
+    n, S = 30000, 8
+    d = synth.make(n, S, fragments=2)
+    fm = d["fragFullMean"].reshape(n, 2, S).sum(axis=1)
+    ref, sc0 = ctx.wald_test(ctx.to_device(d["counts"], np.int32), ctx.to_device(fm, np.float64), d["group"], theta=0.5)
+    ref = {k: v.cpu().numpy() for k, v in ref.items()}
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_two_rank_worker, args=(r, 2, port, n, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.allclose(res[0][4], sc0["trendCoef"], rtol=1e-10) and np.array_equal(res[0][4], res[1][4])
+    assert np.allclose(res[0][5], sc0["sizeFactors"], rtol=1e-13) and np.array_equal(res[0][5], res[1][5])
+    for k in ref:
+        got = np.concatenate([res[0][3][k], res[1][3][k]])
+        assert np.array_equal(np.isnan(got), np.isnan(ref[k])), k
+        ok = ~np.isnan(ref[k])
+        r = rel(got[ok], ref[k][ok])
+        print(k, "2-rank vs 1-rank: max rel", r.max(), "within 1e-9:", np.mean(r < 1e-9))
+        assert np.mean(r < 1e-9) > 0.999 and r.max() < 1e-4, k
