@@ -50,11 +50,17 @@ class AllReduceHook:
         self.doubles = 0
         self.error = None
 
+        views = {}  # (ptr, count) -> tensor view; the library reuses a few workspace buffers for every fit
+
         def cb(_user, ptr, count):
             try:
                 count = int(count)
                 if memory == "device":
-                    t = torch.as_tensor(_RawDevice(int(ptr), count), device=device)
+                    t = views.get((ptr, count))
+                    if t is None:
+                        if len(views) > 256:
+                            views.clear()
+                        t = views[(ptr, count)] = torch.as_tensor(_RawDevice(int(ptr), count), device=device)
                 elif memory == "device_via_host":
                     # device buffer, CPU-side transport (gloo): several ranks may share one GPU this way,
                     # which RCCL does not allow — used to test the sharded HIP path on a single-GPU box

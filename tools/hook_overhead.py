@@ -13,8 +13,13 @@ def bench(tag):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): ctx.wald_test(dk, dfm, d["group"], theta=0.5, outputs=out)
     torch.cuda.synchronize(); print(tag, "ms/step", (time.perf_counter() - t0) / 10 * 1e3)
+    ctx.enable_timing(True); ctx.wald_test(dk, dfm, d["group"], theta=0.5, outputs=out)
+    print("   ", {k: round(v[0], 3) for k, v in sorted(ctx.kernel_times().items(), key=lambda kv: -kv[1][0])}); ctx.enable_timing(False)
+    t0 = time.perf_counter()
+    for _ in range(10): ctx.wald_test(dk, dfm, d["group"], theta=0.5, outputs=out)
+    print("    host enqueue ms/step", (time.perf_counter() - t0) / 10 * 1e3); torch.cuda.synchronize()
 bench("no hook")
 ctx.set_process_group()
 bench("torch hook (1-rank RCCL)")
-print("collectives per step", ctx._hook.calls / 12, "doubles per step", ctx._hook.doubles / 12)
+print("collectives per step", ctx._hook.calls / 23, "doubles per step", ctx._hook.doubles / 23)
 dist.destroy_process_group()
