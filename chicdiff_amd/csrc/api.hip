@@ -294,11 +294,12 @@ struct HipBackend {
         sa.shift = shift;
         launch_sel_step(sa, c->w, c->stream);
     }
-    void sel_shortcut(const SelSpec &) {
-        if (c->allreduce || getenv("CHICDIFF_SELECT_SIXROUNDS")) return;  // sharded: candidates live on other ranks too
+    bool sel_shortcut(const SelSpec &) {
+        if (c->allreduce || getenv("CHICDIFF_SELECT_SIXROUNDS")) return false;  // sharded: candidates live on other ranks too
         Scope t(c, "select_shortcut");
         sa.shift = 40;
         launch_sel_shortcut(sa, c->w, c->stream);
+        return true;
     }
     void sel_finish(const SelSpec &) { launch_sel_finish(sa, c->w, c->stream); }
 };

@@ -189,6 +189,7 @@ struct DispArgs {
     FitWork w;
     Opts o;
     unsigned long long *stamps;  // diagnostic only (CHICDIFF_DISP_STAMPS=file): per wave start / queue-empty / exit
+    int spread;                  // 0 = row-per-lane evaluation only (CHICDIFF_DISP_NOSPREAD=1, for the bit-identity test)
 };
 
 // log posterior of a = log(alpha) and its derivative for one row held in LDS (A2.6).
@@ -225,20 +226,28 @@ struct Acc {  // sums over samples
     double pm = 1.0;  // product of the samples' shift products (mantissas) ...
     int pe = 0;       // ... and of their binary exponents
 };
-// one sample's terms; P = prod_{i<n}(r+i), H = sum_{i<n} 1/(r+i) for n = min(y, nr)
-__device__ __forceinline__ void sample_terms(Acc &acc, const RowConsts &c, double nfj, int yi, bool g, double gm0,
-                                             double gm1, double minmu, double P, double H, const LogEntry *lt) {
+// One sample's contribution as five finished values, and the step that folds them into the row sums.
+// The library is compiled with -ffp-contract=off and every fused operation is written out, so the two
+// evaluation layouts below (row per lane / samples across lanes) produce the same bits: both call
+// sample_values() on the same inputs and both fold the S results in sample order with accumulate().
+struct SampleVals {
+    double wj, pm, tll, tsd;
+    int pe;
+};
+// P = prod_{i<n}(r+i), H = sum_{i<n} 1/(r+i) for n = min(y, nr)
+__device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double nfj, int yi, bool g, double gm0, double gm1,
+                                                    double minmu, double P, double H, const LogEntry *lt) {
+    SampleVals v;
     const double y = (double)yi;
     const double mu = fmax(nfj * (g ? gm1 : gm0), minmu);
     const double ma = mu * c.alpha;
     const double t = 1.0 + ma;
     const double rt = rcp(t);
     const double L = tlog1p_from(ma, t, rt, lt);
-    const double wj = mu * rt;  // 1 / (1/mu + alpha)
-    if (g) { acc.wB += wj; acc.dB -= wj * wj; } else { acc.wA += wj; acc.dA -= wj * wj; }
+    v.wj = mu * rt;  // 1 / (1/mu + alpha)
     double dlg = 0.0, ddg = H;
-    acc.pe += __builtin_amdgcn_frexp_exp(P);
-    acc.pm *= __builtin_amdgcn_frexp_mant(P);
+    v.pe = __builtin_amdgcn_frexp_exp(P);
+    v.pm = __builtin_amdgcn_frexp_mant(P);
     if (yi > c.nr) {
         const double z = y + c.r;
         double lgz, dgz;
@@ -246,8 +255,16 @@ __device__ __forceinline__ void sample_terms(Acc &acc, const RowConsts &c, doubl
         dlg = lgz - c.lgS0;
         ddg += dgz - c.dgS0;
     }
-    acc.ll += dlg - y * (L - c.a) - c.r * L;
-    acc.sd += L - ddg - ma * rt + y * c.alpha * rt;
+    v.tll = fma(-c.r, L, fma(-y, L - c.a, dlg));          // dlg - y (L - a) - r L
+    v.tsd = fma(y * c.alpha, rt, fma(-ma, rt, L - ddg));  // L - ddg - ma/t + y alpha/t
+    return v;
+}
+__device__ __forceinline__ void accumulate(Acc &acc, const SampleVals &v, bool g) {
+    if (g) { acc.wB += v.wj; acc.dB = fma(-v.wj, v.wj, acc.dB); } else { acc.wA += v.wj; acc.dA = fma(-v.wj, v.wj, acc.dA); }
+    acc.pe += v.pe;
+    acc.pm *= v.pm;
+    acc.ll += v.tll;
+    acc.sd += v.tsd;
 }
 __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c, bool p2, bool use_prior,
                                              double prior_mean, double prior_isig, double &lp, double &dlp,
@@ -295,10 +312,71 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
     for (int j = 0; j < S; j++) {
         const int yi = s_y[j * 64 + lane];
         const int n = yi < c.nr ? yi : c.nr;
-        sample_terms(acc, c, s_nf[j * 64 + lane], yi, (gmask >> j) & 1, gm0, gm1, minmu, s_tab[n * 64 + lane],
-                     s_tab[(11 + n) * 64 + lane], lt);
+        const bool g = (gmask >> j) & 1;
+        accumulate(acc, sample_values(c, s_nf[j * 64 + lane], yi, g, gm0, gm1, minmu, s_tab[n * 64 + lane], s_tab[(11 + n) * 64 + lane], lt), g);
     }
     finish_point(acc, c, p2, use_prior, prior_mean, prior_isig, lp, dlp, lt);
+}
+
+// Samples-across-lanes evaluation for the end of the launch.  Once the queue is empty every wave is left
+// with a dozen rows that still need up to ~130 serial evaluations (flat likelihoods: DESeq2's step size
+// decays faster than the search converges, then the grid takes over), and a row-per-lane tick costs the same
+// ~1600 instructions whether 64 lanes or one are busy.  When at most 64/G rows are live (G = 2^lg >= S), the
+// g-th live row is evaluated by lanes G*g .. G*g+G-1, one sample each: every lane rebuilds the row
+// constants (same instructions, no extra cost in SIMD), walks its own prefix product, computes its sample's
+// five values, then every lane of the group folds the S results in sample order (so each holds the row's
+// sums) and the owning lane picks the result up.  Same functions, same operand values, same order of the
+// floating-point operations as eval_point(): the bits do not depend on which layout evaluated a tick,
+// hence not on the schedule (tests/test_gpu_parity.py::test_line_search_layouts_agree_bit_for_bit).
+// Gain at 2 M rows: 1 % of the gene-wise launch at S = 8, 4 % at S = 4, 10 % at S = 16.
+// (Measured and dropped: handing the stragglers to a second, densely packed launch — a wave's tick takes
+// ~5 us alone or with a neighbour on its SIMD, the tail is bound by the ~130 serial ticks, not by issue.)
+__device__ __forceinline__ void eval_point_spread(const double *s_nf, const int *s_y, int lane, int S, int lg, uint64_t gmask,
+                                                  bool p2, double minmu, unsigned long long actmask, bool active, double a_eval,
+                                                  double gm0, double gm1, bool use_prior, double prior_mean, double prior_isig,
+                                                  double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
+    const int grp = lane >> lg, jj = lane & ((1 << lg) - 1);
+    // owner of group g = the g-th live lane (wave-uniform walk over the set bits)
+    int owner = 0, nact = 0;
+    for (unsigned long long m = actmask; m; m &= m - 1ull, nact++)
+        if (grp == nact) owner = __ffsll((long long)m) - 1;
+    const bool has = grp < nact;
+    const double a_o = __shfl(a_eval, owner);
+    const double gm0_o = __shfl(gm0, owner), gm1_o = __shfl(gm1, owner);
+    const double pm_o = use_prior ? __shfl(prior_mean, owner) : 0.0;
+    const RowConsts c = row_consts(a_o, lt);
+    const bool mine = has && jj < S;
+    const int yi = mine ? s_y[jj * 64 + owner] : 0;
+    const double nfj = mine ? s_nf[jj * 64 + owner] : 1.0;
+    double P = 1.0, H = 0.0;
+    {
+        const int n = yi < c.nr ? yi : c.nr;
+        double zz = c.r;
+        for (int i = 0; i < n; i++) {  // the same recurrence as the table of eval_point(), stopped at entry n
+            P *= zz;
+            H += rcp(zz);
+            zz += 1.0;
+        }
+    }
+    const SampleVals v = sample_values(c, nfj, yi, (gmask >> jj) & 1, gm0_o, gm1_o, minmu, P, H, lt);
+    Acc acc;
+    const int base = grp << lg;
+    for (int j = 0; j < S; j++) {
+        SampleVals u;
+        u.wj = __shfl(v.wj, base + j);
+        u.pm = __shfl(v.pm, base + j);
+        u.tll = __shfl(v.tll, base + j);
+        u.tsd = __shfl(v.tsd, base + j);
+        u.pe = __shfl(v.pe, base + j);
+        accumulate(acc, u, (gmask >> j) & 1);
+    }
+    double lp_g, dlp_g;
+    finish_point(acc, c, p2, use_prior, pm_o, prior_isig, lp_g, dlp_g, lt);
+    // an active lane's group is its rank among the active lanes
+    const int src = (active ? __popcll(actmask & ((1ull << lane) - 1ull)) : 0) << lg;
+    lp = __shfl(lp_g, src);
+    dlp = __shfl(dlp_g, src);
+    alpha_out = __shfl(c.alpha, src);
 }
 
 template <bool MAP, int MINW>
@@ -318,6 +396,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     const Opts o = A.o;
     const double min_log_alpha = log(o.minDisp / 10.0);
     const double glo = log(1e-8), ghi = log(o.maxDisp), gstep = (ghi - glo) / 19.0;
+    int spread_lg = A.spread ? 1 : -1;  // log2(lanes per row) of the samples-across-lanes layout; -1 = never
+    while (spread_lg >= 0 && (1 << spread_lg) < S) spread_lg++;
     FitScalars *sc = A.w.sc;
     // fit-wide scalars (uniform)
     const double prior_isig = MAP ? 1.0 / sc->dispPriorVar : 0.0;
@@ -426,12 +506,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         // ---- evaluate -------------------------------------------------------------------------
         double l_new = 0, dl_new = 0, alpha_new = 0;
         const bool active = phase != PH_DONE && phase != PH_NEED;
-        // (A "drain mode" that regrouped a straggler wave's lanes as 4-16 lanes per remaining row cut the
-        // tail by ~0.3 ms at 2 M rows but summed the samples in tree order, so results were no longer
-        // bit-reproducible from run to run; removed in favour of determinism.)
-        if (active)
+        const unsigned long long actmask = __ballot(active);
+        if (queue_empty && spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) {
+            eval_point_spread(s_nf, s_y, lane, S, spread_lg, gmask, p2, o.minmu, actmask, active, a_eval, gm0, gm1, MAP,
+                              prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab);
+        } else if (active) {
             eval_point(s_nf, s_y, s_tab, lane, S, gmask, p2, gm0, gm1, o.minmu, a_eval, MAP, prior_mean, prior_isig, l_new,
                        dl_new, alpha_new, s_logtab);
+        }
 
         // ---- advance the per-lane state machine ---------------------------------------------
         bool finished = false;  // line search over: decide between result and grid fallback
@@ -530,7 +612,7 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
                         hipStream_t st) {
     if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o);
     else disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o);
-    DispArgs A{counts, nf, d, w, o, nullptr};
+    DispArgs A{counts, nf, d, w, o, nullptr, getenv("CHICDIFF_DISP_NOSPREAD") ? 0 : 1};
     const char *stamp_file = getenv("CHICDIFF_DISP_STAMPS");
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks

@@ -13,7 +13,7 @@
 //   void sel_hist(const SelSpec&, int shift);   // digit histograms for the live prefixes (first round: all keys)
 //   void sel_step(const SelSpec&, int shift);   // first round also derives the populations and ranks
 //   void sel_finish(const SelSpec&);
-//   void sel_shortcut(const SelSpec&);          // optional work after the second round (may be a no-op)
+//   bool sel_shortcut(const SelSpec&);          // optional: finish after the second round; true = rounds 3-6 not needed
 #pragma once
 #include "fit_state.h"
 
@@ -54,7 +54,7 @@ int drive_select(B &be, const SelSpec &a) {
         be.sel_hist(a, kSelShifts[r]);
         if (be.allreduce(be.hist(), (int64_t)a.ncol * 2 * kSelBins)) return -1;
         be.sel_step(a, kSelShifts[r]);
-        if (r == 1) be.sel_shortcut(a);  // single-rank HIP backend: finish from the few candidates left
+        if (r == 1 && be.sel_shortcut(a)) break;  // single-rank HIP backend: finishes from the few candidates left
     }
     be.sel_finish(a);
     return 0;

@@ -390,6 +390,52 @@ __global__ __launch_bounds__(256) void sel_small_kernel(SelArgs a, FitWork w) {
     }
 }
 
+// The shortcut's own fallback: more than kSelCap candidates share 24 key bits with a median (massive ties).
+// One block per column runs the four remaining radix rounds by itself — slow (one block scans all n), but
+// it keeps the host from launching those rounds every time just in case.
+__global__ __launch_bounds__(1024) void sel_tail_kernel(SelArgs a, FitWork w) {
+    __shared__ unsigned int h[2][kSelBins];
+    __shared__ uint64_t s_pre[2];
+    __shared__ double s_rank[2];
+    FitScalars *sc = w.sc;
+    if (sc->sel_fast_done) return;
+    const int col = blockIdx.x;
+    if (threadIdx.x < 2) {
+        s_pre[threadIdx.x] = sc->sel_prefix[2 * col + threadIdx.x];
+        s_rank[threadIdx.x] = sc->sel_rank[2 * col + threadIdx.x];
+    }
+    for (int r = 2; r < 6; r++) {
+        const int shift = kSelShifts[r], bits = sel_bits(shift), hi = shift + bits;
+        for (int k = threadIdx.x; k < 2 * kSelBins; k += 1024) (&h[0][0])[k] = 0;
+        __syncthreads();
+        const uint64_t p0 = s_pre[0], p1 = s_pre[1], mask = (1ull << bits) - 1ull;
+        const bool same = p0 == p1;
+        uint64_t key;
+        for (int64_t i = threadIdx.x; i < a.n; i += 1024) {
+            if (!sel_key(a, sc, col, i, key)) continue;
+            const unsigned dig = (unsigned)((key >> shift) & mask);
+            if (sel_match(key, p0, hi)) atomicAdd(&h[0][dig], 1u);
+            else if (!same && sel_match(key, p1, hi)) atomicAdd(&h[1][dig], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {  // fit_state.h sel_pick, on the block's own histogram
+            const int slot = threadIdx.x, hslot = (slot == 1 && !same) ? 1 : 0;
+            const double rank = s_rank[slot];
+            const int nb = 1 << bits;
+            double cum = 0;
+            int b = 0;
+            for (; b < nb - 1; b++) {
+                if (cum + (double)h[hslot][b] > rank) break;
+                cum += (double)h[hslot][b];
+            }
+            s_pre[slot] = (slot ? p1 : p0) | ((uint64_t)b << shift);
+            s_rank[slot] = rank - cum;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) sc->sel_prefix[2 * col + threadIdx.x] = s_pre[threadIdx.x];
+}
+
 __global__ void sel_finish_kernel(SelArgs a, FitWork w) {
     const int c = threadIdx.x;
     if (c >= a.ncol) return;
@@ -426,6 +472,7 @@ void launch_sel_shortcut(SelArgs a, FitWork w, hipStream_t st) {
     (void)hipMemsetAsync(w.sc->sel_cnt, 0, sizeof(uint32_t) * 2 * a.ncol, st);
     sel_compact_kernel<<<dim3(sel_blocks(a.n), a.ncol), 256, 0, st>>>(a, w);
     sel_small_kernel<<<a.ncol, 256, 0, st>>>(a, w);
+    sel_tail_kernel<<<a.ncol, 1024, 0, st>>>(a, w);
 }
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st) { sel_finish_kernel<<<1, 64, 0, st>>>(a, w); }
 

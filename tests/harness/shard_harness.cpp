@@ -102,7 +102,7 @@ struct CpuBackend {
             }
         }
     }
-    void sel_shortcut(const SelSpec &) {}  // the sharded path always runs all six rounds
+    bool sel_shortcut(const SelSpec &) { return false; }  // the sharded path always runs all six rounds
     void sel_finish(const SelSpec &a) {
         for (int c = 0; c < a.ncol; c++) {
             const double med = sel_median(&sc, c);
