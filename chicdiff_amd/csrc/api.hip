@@ -37,9 +37,9 @@ struct chicdiff_hip_ctx {
     size_t ws_bytes = 0;
     FitWork w{};
     double *d_sf = nullptr;   // kMaxS doubles
-    double *d_lgm = nullptr;  // n doubles (size factors)
     double *d_nf_tmp = nullptr;
     FitScalars *h_sc = nullptr;  // pinned
+    double *h_sf = nullptr;      // pinned, kMaxS
     // timing
     bool timing = false;
     std::vector<KTimer> timers;
@@ -93,6 +93,7 @@ int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
     c->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_sc, sizeof(FitScalars))) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->h_sf, sizeof(double) * kMaxS)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_sf, sizeof(double) * kMaxS)) != hipSuccess) {
         fail(nullptr, CHICDIFF_E_HIP, "context setup: %s", hipGetErrorString(e));
         delete c;
@@ -111,6 +112,7 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->h_sc) (void)hipHostFree(c->h_sc);
+    if (c->h_sf) (void)hipHostFree(c->h_sf);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -224,7 +226,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
         c->ws = nullptr;
     }
     const size_t nd = align256(sizeof(double) * (size_t)n), ni = align256(sizeof(int32_t) * (size_t)n);
-    const size_t n_double_arrays = 15 + 1 /*lgm*/, n_int_arrays = 6;
+    const size_t n_double_arrays = 15, n_int_arrays = 6;
     const size_t partials = align256(sizeof(double) * ((size_t)kRedBlocks * 72 + 128));
     const size_t hist = align256(sizeof(double) * (size_t)kMaxS * 2 * kSelBins);
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
@@ -238,7 +240,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     FitWork &w = c->w;
     takeD(w.baseMean); takeD(w.baseVar); takeD(w.gm0); takeD(w.gm1); takeD(w.rough); takeD(w.binit0); takeD(w.binit1);
     takeD(w.crow); takeD(w.dispGene); takeD(w.dispFit); takeD(w.dispMAP); takeD(w.disp); takeD(w.beta0); takeD(w.beta1);
-    takeD(w.resid); takeD(c->d_lgm);
+    takeD(w.resid);
     takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter); takeI(w.optimConv);
     w.partials = (double *)p; p += partials;
     w.hist = (double *)p; p += hist;
@@ -365,13 +367,9 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_trend_init(d, w, o, st);
         HIPCHK(c, hipMemcpyAsync(w.sc->coefs, o.trendIn, sizeof(double) * 2, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));  // o.trendIn lives on this frame
-        c->h_sc->failed = 0;
     } else if (!c->allreduce && !getenv("CHICDIFF_TREND_MULTILAUNCH")) {
         Scope t(c, "trend_fit");  // single rank: one persistent launch (LDS-resident rows, grid barrier per IRLS pass)
-        launch_trend_persistent(d, w, o, st);
-        HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        if (c->h_sc->failed == 3) return fail(c, CHICDIFF_E_HIP, "trend fit: grid barrier timed out");
+        launch_trend_persistent(d, w, o, st);  // no host round trip: `failed` comes back with the final scalars
     } else {
         Scope t(c, "trend_fit");
         HipBackend be{c, d, o, SelArgs{}};
@@ -381,7 +379,6 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         if (trc == -2) return fail(c, CHICDIFF_E_NUMERIC, "trend state machine did not finish");
     }
     int status = 0;
-    if (c->h_sc->failed) status |= CHICDIFF_ST_TREND_FAILED;
     // MAD of the log residuals
     launch_dispfit_resid(d, w, o, st);
     SelArgs sa{};
@@ -437,6 +434,8 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     HIPCHK(c, hipMemcpyAsync(hs, sums_of(w), sizeof hs, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
+    if (c->h_sc->failed == 3) return fail(c, CHICDIFF_E_HIP, "trend fit: grid barrier timed out");
+    if (c->h_sc->failed) status |= CHICDIFF_ST_TREND_FAILED;
     if (scalars) {
         const FitScalars *s = c->h_sc;
         scalars->trendCoef[0] = s->coefs[0];
@@ -521,13 +520,12 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const dou
 // size factors -> c->d_sf (device) ; no host synchronisation
 static int size_factors_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S) {
     Scope t(c, "size_factors");
-    launch_row_lgm(d_counts, n, S, c->d_lgm, c->stream);
+    launch_row_ratio(d_counts, n, S, c->d_nf_tmp, c->stream);  // the offsets buffer is free until the size factors exist
     SelArgs sa{};
     sa.mode = SEL_SIZEFACTOR;
     sa.ncol = S;
     sa.n = n;
-    sa.counts = d_counts;
-    sa.lgm = c->d_lgm;
+    sa.ratio = c->d_nf_tmp;
     sa.S = S;
     int rc = run_select(c, sa);
     if (rc) return rc;
@@ -573,10 +571,16 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
         Scope t(c, "offsets");
         launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, c->d_nf_tmp, c->stream);
     }
-    if (sf_host) HIPCHK(c, hipMemcpyAsync(sf_host, c->d_sf, sizeof(double) * S, hipMemcpyDeviceToHost, c->stream));
-    rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(opts, S), d_out, scalars);
+    HIPCHK(c, hipMemcpyAsync(c->h_sf, c->d_sf, sizeof(double) * S, hipMemcpyDeviceToHost, c->stream));  // pinned: no stall
+    rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(opts, S), d_out, scalars);  // ends with a stream sync
     timing_collect(c);
-    return rc;
+    if (rc) return rc;
+    for (int j = 0; j < S; j++) {
+        if (!(c->h_sf[j] == c->h_sf[j]))
+            return fail(c, CHICDIFF_E_NUMERIC, "every gene contains at least one zero, cannot compute log geometric means");
+        if (sf_host) sf_host[j] = c->h_sf[j];
+    }
+    return CHICDIFF_OK;
 }
 
 int chicdiff_hip_offsets_dev(chicdiff_hip_ctx *c, const double *d_fullMean, const double *sf_host, int64_t n, int32_t S,

@@ -60,8 +60,7 @@ struct SelArgs {
     int ncol;               // columns selected simultaneously (1, or S for size factors)
     int64_t n;
     const double *resid;    // SEL_RESID / SEL_ABSDEV: residuals (NaN = excluded)
-    const int32_t *counts;  // SEL_SIZEFACTOR
-    const double *lgm;      // SEL_SIZEFACTOR: row log geometric means (-inf/NaN = excluded)
+    const double *ratio;    // SEL_SIZEFACTOR: log(count) - row log geometric mean, S x n (NaN = excluded)
     int S;
     int shift;              // bit position of the current digit
 };
@@ -71,7 +70,7 @@ void launch_sel_shortcut(SelArgs a, FitWork w, hipStream_t st); // single rank: 
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st);   // prefixes -> values; median into sc
 
 void launch_gather_sf(FitWork w, int S, double *d_sf, hipStream_t st);  // select results -> sf[S]
-void launch_row_lgm(const int32_t *counts, int64_t n, int S, double *lgm, hipStream_t st);
+void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, hipStream_t st);  // keys of the size-factor medians
 void launch_offsets(const double *fullMean, const double *sf_dev, int64_t n, int S, double theta, int mix,
                     double *out, hipStream_t st);
 void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfrag, int S, const int64_t *rptr,

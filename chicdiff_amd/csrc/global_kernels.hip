@@ -230,10 +230,8 @@ void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st) {
 __device__ __forceinline__ bool sel_key(const SelArgs &a, const FitScalars *sc, int col, int64_t i, uint64_t &key) {
     double x;
     if (a.mode == SEL_SIZEFACTOR) {
-        const double lg = a.lgm[i];
-        const int32_t k = a.counts[(int64_t)col * a.n + i];
-        if (!isfinite(lg) || k <= 0) return false;
-        x = log((double)k) - lg;
+        x = a.ratio[(int64_t)col * a.n + i];  // log(k) - loggeomean, NaN = excluded (row_ratio_kernel)
+        if (x != x) return false;
     } else {
         x = a.resid[i];
         if (x != x) return false;
@@ -482,17 +480,44 @@ __global__ void gather_sf_kernel(FitWork w, int S, double *sf) {
 }
 void launch_gather_sf(FitWork w, int S, double *d_sf, hipStream_t st) { gather_sf_kernel<<<1, 64, 0, st>>>(w, S, d_sf); }
 
-// a5 helper: row log geometric means, loggeomeans <- rowMeans(log(counts))
-__global__ __launch_bounds__(256) void row_lgm_kernel(const int32_t *__restrict__ counts, int64_t n, int S,
-                                                      double *__restrict__ lgm) {
+// a5 helper: the keys of the size-factor medians, computed once: ratio[j][i] = log(counts[j][i]) -
+// rowMeans(log(counts))[i] for rows without a zero count (estimateSizeFactorsForMatrix uses only rows with
+// a finite log geometric mean, and only positive counts), NaN otherwise.  The select passes then stream
+// 8 B per element instead of recomputing a log.
+__global__ __launch_bounds__(256) void row_ratio_kernel(const int32_t *__restrict__ counts, int64_t n, int S,
+                                                        double *__restrict__ ratio) {
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double s = 0;
-        for (int j = 0; j < S; j++) s += log((double)counts[(int64_t)j * n + i]);  // log(0) = -inf
-        lgm[i] = s / S;
+        for (int j = 0; j < S; j++) {
+            const double l = log((double)counts[(int64_t)j * n + i]);  // log(0) = -inf
+            ratio[(int64_t)j * n + i] = l;
+            s += l;
+        }
+        const double lg = s / S;
+        const bool use = isfinite(lg);
+        for (int j = 0; j < S; j++) ratio[(int64_t)j * n + i] = use ? ratio[(int64_t)j * n + i] - lg : NAN;
     }
 }
-void launch_row_lgm(const int32_t *counts, int64_t n, int S, double *lgm, hipStream_t st) {
-    row_lgm_kernel<<<kRedBlocks, 256, 0, st>>>(counts, n, S, lgm);
+__global__ __launch_bounds__(256) void row_ratio16_kernel(const int32_t *__restrict__ counts, int64_t n, int S,
+                                                          double *__restrict__ ratio) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double l[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) l[j] = j < S ? log((double)counts[(int64_t)j * n + i]) : 0.0;
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < S) s += l[j];  // sample order, as the loop above
+        const double lg = s / S;
+        const bool use = isfinite(lg);
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < S) ratio[(int64_t)j * n + i] = use ? l[j] - lg : NAN;
+    }
+}
+void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, hipStream_t st) {
+    if (S <= 16) row_ratio16_kernel<<<kRedBlocks * 2, 256, 0, st>>>(counts, n, S, ratio);
+    else row_ratio_kernel<<<kRedBlocks, 256, 0, st>>>(counts, n, S, ratio);
 }
 
 // a4: offsets.  One thread per row.  For S <= 16 the row lives in registers (one HBM read, one write);
