@@ -63,13 +63,15 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
         g0 /= d.nA;
         if (d.p == 2) g1 /= d.nB;
         const double m0 = fmax(1.0, g0), m1 = fmax(1.0, g1);
+        const double i0 = 1.0 / (m0 * m0), i1 = 1.0 / (m1 * m1);  // two divisions per row instead of one per sample
         double v = 0, est = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++)
             if (j < S) {
                 v += (q[j] - bm) * (q[j] - bm);
-                const double mj = ((d.gmask >> j) & 1) ? m1 : m0;
-                est += ((q[j] - mj) * (q[j] - mj) - mj) / (mj * mj);
+                const bool g = (d.gmask >> j) & 1;
+                const double mj = g ? m1 : m0;
+                est += ((q[j] - mj) * (q[j] - mj) - mj) * (g ? i1 : i0);
             }
         prep_store(d, w, i, s, g0, g1, v, est, tot);
     }

@@ -23,20 +23,28 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
     const int S = d.S;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         if (w.allZero[i]) continue;
-        const LgrCtx cs = lgr_make(rcp(w.disp[i])), c1 = lgr_one();
-        double lA = 0, lB = 0, c = 0;
+        const double alpha = w.disp[i], la = flog(alpha);
+        const LgrCtx cs = lgr_make(rcp(alpha)), c1 = lgr_one();
+        double lA = 0, lB = 0, c = 0, cst = 0;
         for (int j = 0; j < S; j++) {
             const int yi = counts[(int64_t)j * n + i];
-            const double l = flog((double)yi / nf[(int64_t)j * n + i] + 0.1);
+            const double nfj = nf[(int64_t)j * n + i];
+            const double l = flog((double)yi / nfj + 0.1);
             if ((d.gmask >> j) & 1) lB += l; else lA += l;
-            // lgamma(y+size) - lgamma(size) - lgamma(y+1): the mu-independent part of log dnbinom
-            if (yi > 0) c += lgr_eval(cs, yi) - lgr_eval(c1, yi);
+            if (yi > 0) {
+                // lgamma(y+size) - lgamma(size) - lgamma(y+1): the mu-independent part of log dnbinom
+                c += lgr_eval(cs, yi) - lgr_eval(c1, yi);
+                // sum_j y_j (log alpha + log nf_j): with mu = nf e^eta the rest of sum_j y_j log(alpha mu_j) is
+                // eta_A sum_A y + eta_B sum_B y, so the IRLS ticks need no log(mu)
+                cst = fma((double)yi, la + flog(nfj), cst);
+            }
         }
         lA /= d.nA;
         lB /= d.nB;
         w.binit0[i] = lA;
         w.binit1[i] = lB - lA;
         w.crow[i] = c;
+        w.rough[i] = cst;  // (the line-search start values are no longer needed)
     }
 }
 
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
     unsigned long long chunk_next = 0, chunk_end = 0;
     int64_t row = -1;
     int k = 0;
-    double b0 = 0, b1 = 0, alpha = 0, size = 0, crow = 0, dev_old = 0, la = 0;
+    double b0 = 0, b1 = 0, alpha = 0, size = 0, crow = 0, dev_old = 0, syA = 0, syB = 0;
 
     for (;;) {
         for (int attempt = 0; attempt < 4; attempt++) {
@@ -107,14 +115,18 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
                     A.w.betaIter[r] = 0;
                 } else {
                     row = r;
+                    int iyA = 0, iyB = 0;
                     for (int j = 0; j < S; j++) {
+                        const int yi = A.counts[(int64_t)j * n + r];
                         s_nf[j * 64 + lane] = A.nf[(int64_t)j * n + r];
-                        s_y[j * 64 + lane] = A.counts[(int64_t)j * n + r];
+                        s_y[j * 64 + lane] = yi;
+                        if ((gmask >> j) & 1) iyB += yi; else iyA += yi;
                     }
+                    syA = (double)iyA;
+                    syB = (double)iyB;
                     alpha = A.w.disp[r];
                     size = 1.0 / alpha;
-                    la = tlog(alpha, s_logtab);
-                    crow = A.w.crow[r];
+                    crow = A.w.crow[r] + A.w.rough[r];  // + sum_j y_j (log alpha + log nf_j), from wald_prep
                     b0 = A.w.binit0[r];
                     b1 = A.w.binit1[r];
                     k = 0;
@@ -126,8 +138,11 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
         if (__ballot(!done) == 0ull) break;
         if (!need && !done) {  // lanes without a row sit this tick out; the wave as a whole goes on
 
-            const double E0 = exp(b0), E1 = exp(b0 + b1);
-            double wA = 0, wB = 0, zA = 0, zB = 0, D = 0;
+            // z_j = eta_j + (y_j - mu_j)/mu_j and w_j = mu_j/(1 + alpha mu_j) give w_j z_j = w_j (eta_j - 1) + y_j/(1 + alpha mu_j):
+            // no 1/mu, and eta is the group's constant unless mu was floored at minmu (rare, handled in the branch)
+            const double etaA = b0, etaB = b0 + b1;
+            const double E0 = exp(etaA), E1 = exp(etaB);
+            double wA = 0, wB = 0, uA = 0, uB = 0, Dl = 0, zcA = 0, zcB = 0, Dc = 0;
             for (int j = 0; j < S; j++) {
                 const double nfj = s_nf[j * 64 + lane];
                 const double y = (double)s_y[j * 64 + lane];
@@ -139,24 +154,28 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
                 const double t1 = 1.0 + ma;
                 const double rt = rcp(t1);
                 const double wj = mu * rt;
-                const double lmu = tlog(mu, s_logtab);
-                const double eta = floored ? lmu - tlog(nfj, s_logtab) : (g ? b0 + b1 : b0);
-                const double z = eta + (y - mu) * rcp(mu);
-                if (g) { wB += wj; zB += wj * z; } else { wA += wj; zA += wj * z; }
+                if (g) { wB += wj; uB = fma(y, rt, uB); } else { wA += wj; uA = fma(y, rt, uA); }
                 // -log dnbinom's mu-dependent part: (size+y) log1p(alpha mu) - y log(alpha mu)
-                double dj = (size + y) * tlog1p_from(ma, t1, rt, s_logtab);
-                if (y > 0) dj -= y * (la + lmu);
-                D += dj;
+                Dl = fma(size + y, tlog1p_from(ma, t1, rt, s_logtab), Dl);
+                if (floored) {  // eta_j = log(minmu) - log(nf_j) instead of the group's eta
+                    const double de = (tlog(o.minmu, s_logtab) - tlog(nfj, s_logtab)) - (g ? etaB : etaA);
+                    if (g) zcB = fma(wj, de, zcB); else zcA = fma(wj, de, zcA);
+                    Dc = fma(-y, de, Dc);  // log mu_j = log nf_j + eta_group + de
+                }
             }
+            const double zA = fma(etaA - 1.0, wA, uA) + zcA, zB = fma(etaB - 1.0, wB, uB) + zcB;
+            const double D = (Dl - fma(etaA, syA, etaB * syB)) + Dc;  // `crow` carries the per-row constant
             bool stop = false;
             int iter_out = k;
             if (k >= 1) {
                 const double dev = 2.0 * (D - crow);
-                const double conv_test = fabs(dev - dev_old) / (fabs(dev) + 0.1);
-                if (conv_test != conv_test) {
+                // DESeq2: conv_test = |dev - dev_old| / (|dev| + 0.1); NaN -> give up, < tol (from the 2nd step on) -> done.
+                // Compared without the division.
+                const double diff = fabs(dev - dev_old), scale = fabs(dev) + 0.1;
+                if (!(diff == diff) || !(scale == scale) || (isinf(diff) && isinf(scale))) {  // the quotient would be NaN
                     stop = true;
                     iter_out = o.betaMaxit;
-                } else if (k >= 2 && conv_test < o.betaTol) {
+                } else if (k >= 2 && diff < o.betaTol * scale) {
                     stop = true;
                 } else if (k >= o.betaMaxit) {
                     stop = true;
@@ -166,9 +185,9 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
             if (!stop) {
                 const double m00 = wA + wB + lambda, m01 = wB, m11 = wB + lambda;
                 const double r0 = zA + zB, r1 = zB;
-                const double det = m00 * m11 - m01 * m01;
-                b0 = (m11 * r0 - m01 * r1) / det;
-                b1 = (m00 * r1 - m01 * r0) / det;
+                const double idet = rcp(fma(m00, m11, -(m01 * m01)));
+                b0 = fma(m11, r0, -(m01 * r1)) * idet;
+                b1 = fma(m00, r1, -(m01 * r0)) * idet;
                 k++;
                 if (fabs(b0) > 30.0 || fabs(b1) > 30.0) {
                     stop = true;
@@ -191,14 +210,15 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
 // reproduced here is that optimiser's target — the posterior mode inside the box — by damped Fisher
 // scoring with backtracking on the same objective, started from the least-squares start values.
 // A handful of rows per million (single extreme count outliers): one thread per row is plenty.
-__device__ __forceinline__ double optim_objective(const int32_t *__restrict__ counts, const double *__restrict__ nf,
-                                                  int64_t n, int64_t i, int S, uint64_t gmask, double alpha, double size,
-                                                  double la, double crow, double lam, double b0, double b1) {
+// counts / offsets of the row are read as y[j * stride], f[j * stride] (global memory, or the LDS copy below)
+__device__ __forceinline__ double optim_objective(const int32_t *y_, const double *f_, int64_t stride, int S, uint64_t gmask,
+                                                  double alpha, double size, double la, double crow, double lam, double b0,
+                                                  double b1) {
     double f = 0.5 * lam * (b0 * b0 + b1 * b1) - crow;
     const double E0 = exp(b0), E1 = exp(b0 + b1);
     for (int j = 0; j < S; j++) {
-        const double y = (double)counts[(int64_t)j * n + i];
-        const double mu = nf[(int64_t)j * n + i] * (((gmask >> j) & 1) ? E1 : E0);
+        const double y = (double)y_[j * stride];
+        const double mu = f_[j * stride] * (((gmask >> j) & 1) ? E1 : E0);
         const double ma = alpha * mu, t = 1.0 + ma;
         f += (size + y) * flog1p_from(ma, t, rcp(t));
         if (y > 0) f -= y * (la + flog(mu));
@@ -206,12 +226,17 @@ __device__ __forceinline__ double optim_objective(const int32_t *__restrict__ co
     return f;
 }
 __global__ __launch_bounds__(256) void wald_optim_kernel(const int32_t *__restrict__ counts, const double *__restrict__ nf,
-                                                         FitDims d, FitWork w, Opts o) {
+                                                         FitDims d, FitWork w, Opts o, int lds_rows) {
     const int64_t n = d.n;
     const int S = d.S;
     const double lam = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
     const double bound = 30.0 * 0.69314718055994530942;
     const bool any = w.queue[16] != 0;  // no row left by the IRLS: only the flags are written
+    // the few hundred serial objective evaluations of a fallback row read the row from LDS, not from L2
+    extern __shared__ double s_optim[];  // [S][256] offsets, then [S][256] counts (empty when S is too large)
+    const bool in_lds = lds_rows != 0;
+    double *s_f = s_optim + threadIdx.x;
+    int32_t *s_y = reinterpret_cast<int32_t *>(s_optim + (size_t)S * 256) + threadIdx.x;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         int flag = -1;  // not attempted
         if (!any) {
@@ -220,16 +245,28 @@ __global__ __launch_bounds__(256) void wald_optim_kernel(const int32_t *__restri
         }
         if (!w.allZero[i] && !(w.betaIter[i] < o.betaMaxit)) {
             const double alpha = w.disp[i], size = rcp(alpha), la = flog(alpha), crow = w.crow[i];
+            const int32_t *y_ = counts + i;
+            const double *f_ = nf + i;
+            int64_t stride = n;
+            if (in_lds) {
+                for (int j = 0; j < S; j++) {
+                    s_f[j * 256] = nf[(int64_t)j * n + i];
+                    s_y[j * 256] = counts[(int64_t)j * n + i];
+                }
+                y_ = s_y;
+                f_ = s_f;
+                stride = 256;
+            }
             double b0 = w.binit0[i], b1 = w.binit1[i];
-            double f = optim_objective(counts, nf, n, i, S, d.gmask, alpha, size, la, crow, lam, b0, b1);
+            double f = optim_objective(y_, f_, stride, S, d.gmask, alpha, size, la, crow, lam, b0, b1);
             bool converged = false;
             for (int it = 0; it < 200 && !converged; it++) {
                 double g0 = lam * b0, g1 = lam * b1, wA = 0, wB = 0;
                 const double E0 = exp(b0), E1 = exp(b0 + b1);
                 for (int j = 0; j < S; j++) {
                     const bool g = (d.gmask >> j) & 1;
-                    const double y = (double)counts[(int64_t)j * n + i];
-                    const double mu = nf[(int64_t)j * n + i] * (g ? E1 : E0);
+                    const double y = (double)y_[j * stride];
+                    const double mu = f_[j * stride] * (g ? E1 : E0);
                     const double rt = rcp(fma(alpha, mu, 1.0));
                     const double sc = (y - mu) * rt, wj = mu * rt;
                     g0 -= sc;
@@ -241,7 +278,7 @@ __global__ __launch_bounds__(256) void wald_optim_kernel(const int32_t *__restri
                 bool moved = false;
                 for (int h = 0; h < 40; h++, t *= 0.5) {
                     const double n0 = fmin(fmax(b0 + t * d0, -bound), bound), n1 = fmin(fmax(b1 + t * d1, -bound), bound);
-                    const double fn = optim_objective(counts, nf, n, i, S, d.gmask, alpha, size, la, crow, lam, n0, n1);
+                    const double fn = optim_objective(y_, f_, stride, S, d.gmask, alpha, size, la, crow, lam, n0, n1);
                     if (fn < f) {
                         if (f - fn < 1e-13 * (fabs(f) + 1.0)) converged = true;
                         b0 = n0; b1 = n1; f = fn; moved = true;
@@ -258,7 +295,9 @@ __global__ __launch_bounds__(256) void wald_optim_kernel(const int32_t *__restri
     }
 }
 void launch_wald_optim(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
-    wald_optim_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w, o);
+    const size_t lds = (size_t)d.S * 256 * 12;
+    const int lds_rows = lds <= 48 * 1024;
+    wald_optim_kernel<<<kRedBlocks, 256, lds_rows ? lds : 0, st>>>(counts, nf, d, w, o, lds_rows);
 }
 
 __device__ __forceinline__ int trim_lo(int n) {
