@@ -35,6 +35,8 @@ struct chicdiff_hip_ctx {
     int cap_S = 0;
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    char *aux = nullptr;  // scratch of the post-processing entry points (sort / scan temporaries)
+    size_t aux_bytes = 0;
     FitWork w{};
     double *d_sf = nullptr;   // kMaxS doubles
     double *d_nf_tmp = nullptr;
@@ -110,6 +112,7 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->aux) (void)hipFree(c->aux);
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->h_sc) (void)hipHostFree(c->h_sc);
     if (c->h_sf) (void)hipHostFree(c->h_sf);
@@ -249,6 +252,20 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     c->d_nf_tmp = (double *)p;
     c->cap_n = n;
     c->cap_S = S;
+    return CHICDIFF_OK;
+}
+
+static int ensure_aux(chicdiff_hip_ctx *c, size_t bytes) {
+    if (c->aux_bytes >= bytes) return CHICDIFF_OK;
+    if (c->aux) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->aux));
+        c->aux = nullptr;
+        c->aux_bytes = 0;
+    }
+    hipError_t e = hipMalloc((void **)&c->aux, bytes);
+    if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "scratch of %zu bytes: %s", bytes, hipGetErrorString(e));
+    c->aux_bytes = bytes;
     return CHICDIFF_OK;
 }
 
@@ -706,5 +723,94 @@ extern "C" int chicdiff_hip_fragment_background_dev(chicdiff_hip_ctx *c, const i
     timing_collect(c);
     (void)hipFree(d_df);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_HIP, "fragment_background: %s", hipGetErrorString(e));
+    return CHICDIFF_OK;
+}
+
+// ---- f1 / f3 / f4 (post_kernels.hip) ------------------------------------------------------------------------
+extern "C" int chicdiff_hip_bh_adjust_dev(chicdiff_hip_ctx *c, const double *d_p, int64_t n, double *d_padj) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (n < 0 || n >= (1ll << 32) || (n > 0 && (!d_p || !d_padj))) return fail(c, CHICDIFF_E_INVALID, "bh_adjust: bad arguments");
+    if (n == 0) return CHICDIFF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_aux(c, bh_workspace_bytes(n));
+    if (rc) return rc;
+    timing_reset(c);
+    {
+        Scope t(c, "bh_adjust");
+        if (launch_bh_adjust(d_p, n, d_padj, c->aux, c->stream)) return fail(c, CHICDIFF_E_HIP, "bh_adjust: sort/scan failed");
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return CHICDIFF_OK;
+}
+
+extern "C" int chicdiff_hip_ihw_apply_dev(chicdiff_hip_ctx *c, const double *d_avDist, const double *d_pvalue, int64_t n,
+                                          const double *breaks_host, const double *avWeights_host, int32_t ngroups,
+                                          int32_t *d_group, double *d_weight, double *d_wp, double *d_wpadj) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_avDist || !d_pvalue || !breaks_host || !avWeights_host || !d_wpadj || n < 1 || n >= (1ll << 32) || ngroups < 1 || ngroups > 256)
+        return fail(c, CHICDIFF_E_INVALID, "ihw_apply: bad arguments");
+    for (int k = 0; k < ngroups; k++)
+        if (!(breaks_host[k] < breaks_host[k + 1])) return fail(c, CHICDIFF_E_INVALID, "ihw_apply: breaks must be strictly ascending ('breaks' are not unique)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bhb = bh_workspace_bytes(n), ihwb = (ihw_workspace_bytes() + 255) / 256 * 256, col = (sizeof(double) * (size_t)n + 255) / 256 * 256;
+    int rc = ensure_aux(c, bhb + ihwb + 2 * col);
+    if (rc) return rc;
+    double *partials = (double *)(c->aux + bhb);
+    double *weight = d_weight ? d_weight : (double *)(c->aux + bhb + ihwb);
+    double *wp = d_wp ? d_wp : (double *)(c->aux + bhb + ihwb + col);
+    timing_reset(c);
+    {
+        Scope t(c, "ihw_apply");
+        launch_ihw_apply(d_avDist, d_pvalue, n, breaks_host, avWeights_host, ngroups, d_group, weight, wp, partials, c->stream);
+        if (launch_bh_adjust(wp, n, d_wpadj, c->aux, c->stream)) return fail(c, CHICDIFF_E_HIP, "ihw_apply: sort/scan failed");
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return CHICDIFF_OK;
+}
+
+extern "C" int chicdiff_hip_region_universe_count_dev(chicdiff_hip_ctx *c, const int32_t *d_bait, const int32_t *d_oe, int64_t n,
+                                                      int32_t RUexpand, const int32_t *d_chr_of, int32_t maxfrag,
+                                                      int64_t *d_region_ptr, int32_t *d_minOE, int32_t *d_maxOE,
+                                                      int64_t *total_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_bait || !d_oe || !d_chr_of || !d_region_ptr || !total_host || n < 1 || RUexpand < 0 || RUexpand > (1 << 20) || maxfrag < 1)
+        return fail(c, CHICDIFF_E_INVALID, "region_universe: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t scan = ru_scan_bytes(n);
+    int rc = ensure_aux(c, 256 + scan);
+    if (rc) return rc;
+    int *bad = (int *)c->aux;
+    timing_reset(c);
+    {
+        Scope t(c, "region_universe");
+        if (launch_ru_count(d_bait, d_oe, n, RUexpand, d_chr_of, maxfrag, d_region_ptr, d_minOE, d_maxOE, bad, c->aux + 256, scan, c->stream))
+            return fail(c, CHICDIFF_E_HIP, "region_universe: scan failed");
+    }
+    int h_bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(total_host, d_region_ptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    if (h_bad) return fail(c, CHICDIFF_E_INVALID, "region_universe: Invalid parameters (a peak with baitID == oeID)");
+    return CHICDIFF_OK;
+}
+
+extern "C" int chicdiff_hip_region_universe_fill_dev(chicdiff_hip_ctx *c, const int32_t *d_bait, const int32_t *d_oe, int64_t n,
+                                                     int32_t RUexpand, const int32_t *d_chr_of, int32_t maxfrag,
+                                                     const int64_t *d_region_ptr, int32_t *d_ru_bait, int32_t *d_ru_region,
+                                                     int32_t *d_ru_oe) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_bait || !d_oe || !d_chr_of || !d_region_ptr || !d_ru_bait || !d_ru_region || !d_ru_oe || n < 1 || RUexpand < 0 || maxfrag < 1)
+        return fail(c, CHICDIFF_E_INVALID, "region_universe: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    {
+        Scope t(c, "region_universe");
+        launch_ru_fill(d_bait, d_oe, n, RUexpand, d_chr_of, maxfrag, d_region_ptr, d_ru_bait, d_ru_region, d_ru_oe, c->stream);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
     return CHICDIFF_OK;
 }

@@ -81,6 +81,17 @@ void launch_fragment_background(const int32_t *bait, const int32_t *oe, int64_t 
                                 const int64_t *midsum, int32_t S, const double *sj, const double *si, const int32_t *tblb,
                                 const int32_t *tlb, const double *T, int32_t ntblb, int32_t ntlb, const double *distfun_dev,
                                 double *bmean, double *tmean, double *fullmean, hipStream_t st);
+// post_kernels.hip
+size_t bh_workspace_bytes(int64_t n);
+int launch_bh_adjust(const double *p, int64_t n, double *padj, char *ws, hipStream_t st);
+size_t ihw_workspace_bytes();
+void launch_ihw_apply(const double *avDist, const double *pvalue, int64_t n, const double *breaks, const double *weights,
+                      int ng, int32_t *group, double *weight, double *wp, double *partials, hipStream_t st);
+size_t ru_scan_bytes(int64_t n);
+int launch_ru_count(const int32_t *bait, const int32_t *oe, int64_t n, int s, const int32_t *chr_of, int maxfrag,
+                    int64_t *region_ptr, int32_t *minOE, int32_t *maxOE, int *bad, void *tmp, size_t tmp_bytes, hipStream_t st);
+void launch_ru_fill(const int32_t *bait, const int32_t *oe, int64_t n, int s, const int32_t *chr_of, int maxfrag,
+                    const int64_t *region_ptr, int32_t *ru_bait, int32_t *ru_region, int32_t *ru_oe, hipStream_t st);
 void launch_math_selftest(int op, const double *x, int64_t n, double *out, hipStream_t st);
 void launch_pvalues(const double *stat, int64_t n, double *p, hipStream_t st);
 

@@ -25,7 +25,8 @@ EXPORTS = [
     "chicdiff_hip_create", "chicdiff_hip_destroy", "chicdiff_hip_last_error", "chicdiff_hip_set_stream",
     "chicdiff_hip_set_allreduce", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
-    "chicdiff_hip_fragment_background_dev",
+    "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
+    "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
     "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
@@ -90,6 +91,10 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_count_join_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp]
     L.chicdiff_hip_fragment_background_dev.argtypes = [vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32,
                                                        C.POINTER(dbl), vp, vp, vp]
+    L.chicdiff_hip_bh_adjust_dev.argtypes = [vp, vp, i64, vp]
+    L.chicdiff_hip_ihw_apply_dev.argtypes = [vp, vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl), i32, vp, vp, vp, vp]
+    L.chicdiff_hip_region_universe_count_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, C.POINTER(i64)]
+    L.chicdiff_hip_region_universe_fill_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, vp]
     L.chicdiff_hip_nbglm_fit_dev.argtypes = [vp, vp, vp, i64, i32, C.POINTER(i32), C.POINTER(Opts), C.POINTER(Out),
                                              C.POINTER(Scalars)]
     L.chicdiff_hip_nbglm_fit.argtypes = L.chicdiff_hip_nbglm_fit_dev.argtypes
@@ -237,6 +242,51 @@ class HipContext:
             d_si.data_ptr(), d_tblb.data_ptr(), d_tlb.data_ptr(), d_T.data_ptr(), d_T.shape[1], d_T.shape[2],
             df.ctypes.data_as(C.POINTER(C.c_double)), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr()))
         return outs
+
+    # -- f1 / f3: BH and the IHW application side ----------------------------------------------
+    def bh_adjust(self, d_p):
+        """p.adjust(p, "BH") on a device vector (NaN = NA)."""
+        torch = self.torch
+        assert d_p.dtype == torch.float64 and d_p.is_contiguous()
+        out = torch.empty_like(d_p)
+        self._check(self.lib.chicdiff_hip_bh_adjust_dev(self.h, d_p.data_ptr(), d_p.numel(), out.data_ptr()))
+        return out
+
+    def ihw_apply(self, d_avDist, d_pvalue, breaks, avWeights):
+        """chicdiff.R:2038-2049: returns dict(group, weight, weighted_pvalue, weighted_padj) of device tensors."""
+        torch = self.torch
+        n = d_avDist.numel()
+        b = np.ascontiguousarray(breaks, dtype=np.float64)
+        w = np.ascontiguousarray(avWeights, dtype=np.float64)
+        assert len(b) == len(w) + 1 and d_pvalue.numel() == n
+        group = torch.empty(n, dtype=torch.int32, device=self.device)
+        weight, wp, wpadj = (torch.empty(n, dtype=torch.float64, device=self.device) for _ in range(3))
+        P = C.POINTER(C.c_double)
+        self._check(self.lib.chicdiff_hip_ihw_apply_dev(self.h, d_avDist.data_ptr(), d_pvalue.data_ptr(), n, b.ctypes.data_as(P),
+                                                        w.ctypes.data_as(P), len(w), group.data_ptr(), weight.data_ptr(),
+                                                        wp.data_ptr(), wpadj.data_ptr()))
+        return dict(group=group, weight=weight, weighted_pvalue=wp, weighted_padj=wpadj)
+
+    # -- f4: region universe ---------------------------------------------------------------------
+    def region_universe(self, d_bait, d_oe, RUexpand, d_chr_of):
+        """getRegionUniverse window mode (chicdiff.R:353-426).  d_chr_of: int32 (maxfrag + 1,), -1 = not on the map.
+        Returns dict(region_ptr, minOE, maxOE, baitID, regionID, otherEndID); the RU rows are in
+        (regionID, otherEndID) order."""
+        torch = self.torch
+        n = d_bait.numel()
+        maxfrag = d_chr_of.numel() - 1
+        ptr = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        mn, mx = (torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(2))
+        total = C.c_int64(0)
+        self._check(self.lib.chicdiff_hip_region_universe_count_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), n, int(RUexpand),
+                                                                    d_chr_of.data_ptr(), maxfrag, ptr.data_ptr(), mn.data_ptr(),
+                                                                    mx.data_ptr(), C.byref(total)))
+        rb, rr, ro = (torch.empty(max(total.value, 1), dtype=torch.int32, device=self.device)[: total.value] for _ in range(3))
+        if total.value:
+            self._check(self.lib.chicdiff_hip_region_universe_fill_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), n, int(RUexpand),
+                                                                       d_chr_of.data_ptr(), maxfrag, ptr.data_ptr(), rb.data_ptr(),
+                                                                       rr.data_ptr(), ro.data_ptr()))
+        return dict(region_ptr=ptr, minOE=mn, maxOE=mx, baitID=rb, regionID=rr, otherEndID=ro)
 
     # -- a6 + a7 ----------------------------------------------------------------------------
     def nbglm_fit(self, d_counts, d_nf, group, want=None, opts: Opts | None = None, outputs: dict | None = None):

@@ -147,6 +147,38 @@ int chicdiff_hip_fragment_background_dev(chicdiff_hip_ctx *ctx, const int32_t *d
                                          const double *distfun_host, double *d_bmean, double *d_tmean,
                                          double *d_fullmean);
 
+/* f1/f3 — p.adjust(p, method = "BH") (DESeq2 results() on the independent-filtering survivors; chicdiff.R:2049
+ * on the weighted p-values).  NaN = NA: not counted, stays NaN.  n < 2^32. */
+int chicdiff_hip_bh_adjust_dev(chicdiff_hip_ctx *ctx, const double *d_p, int64_t n, double *d_padj);
+
+/* f3 — application side of IHWcorrection (chicdiff.R:2038-2049), after ihw() has been trained in R:
+ *   group <- as.integer(cut(log(abs(avDist)), breaks)); avWeights <- distLookup$avWeights[group];
+ *   weight <- avWeights / mean(avWeights); weighted_pvalue <- pvalue / weight;
+ *   weighted_padj <- p.adjust(weighted_pvalue, "BH").
+ * breaks_host has ngroups + 1 ascending entries (chicdiff.R:2039), avWeights_host ngroups (<= 256).
+ * d_group gets 1-based codes, INT32_MIN (NA_integer_) outside the breaks; any output may be NULL except
+ * d_weighted_padj. */
+int chicdiff_hip_ihw_apply_dev(chicdiff_hip_ctx *ctx, const double *d_avDist, const double *d_pvalue, int64_t n,
+                               const double *breaks_host, const double *avWeights_host, int32_t ngroups,
+                               int32_t *d_group, double *d_weight, double *d_weighted_pvalue,
+                               double *d_weighted_padj);
+
+/* f4 — getRegionUniverse, window mode (chicdiff.R:353-426).  For peak i (regionID i + 1): the otherEndIDs
+ * .expandAvoidBait(baitID, oeID, RUexpand) (:353-367), kept when 1 <= ID <= maxfrag (:383-384) and on the bait's
+ * chromosome (:386-401).  d_chr_of[0 .. maxfrag]: chromosome code of each restriction-map ID (-1 = ID not on
+ * the map; entry 0 unused).  Two calls: _count fills d_region_ptr[n + 1] (CSR offsets), optional d_minOE /
+ * d_maxOE (INT32_MIN for an empty region) and *total_host = number of RU rows; _fill writes the rows in
+ * (regionID, otherEndID) order — RU.DT's own order is the stable sort of these rows by baitID after
+ * otherEndID (setkey, :389/:393).  baitID == oeID is the reference's stop("Invalid parameters"): E_INVALID. */
+int chicdiff_hip_region_universe_count_dev(chicdiff_hip_ctx *ctx, const int32_t *d_bait, const int32_t *d_oe, int64_t n,
+                                           int32_t RUexpand, const int32_t *d_chr_of, int32_t maxfrag,
+                                           int64_t *d_region_ptr, int32_t *d_minOE, int32_t *d_maxOE,
+                                           int64_t *total_host);
+int chicdiff_hip_region_universe_fill_dev(chicdiff_hip_ctx *ctx, const int32_t *d_bait, const int32_t *d_oe, int64_t n,
+                                          int32_t RUexpand, const int32_t *d_chr_of, int32_t maxfrag,
+                                          const int64_t *d_region_ptr, int32_t *d_ru_bait, int32_t *d_ru_region,
+                                          int32_t *d_ru_oe);
+
 /* a6 + a7 — estimateDispersions + nbinomWaldTest (chicdiff.R:1573-1574, 1602-1603, 1643-1644,
  * 1673-1674) for design ~condition (group[j] in {0,1}, both present) or ~1 (all group[j]==0).
  * d_nf = normalizationFactors (n x S).  `group` is a HOST array of S ints. */

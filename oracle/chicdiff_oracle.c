@@ -160,3 +160,59 @@ int oracle_fragment_background(const int32_t *bait, const int32_t *oe, int64_t n
     }
     return 0;
 }
+
+/* f3. Application side of IHWcorrection, chicdiff.R:2038-2049:
+ *   out$group  <- as.integer(cut(log(abs(out$avDist)), breaks))          (:2040; cut(): right-closed (b_k, b_k+1])
+ *   merge(out, distLookup[, c("group","avWeights")], all.x=TRUE)          (:2045; NA group -> NA weight)
+ *   out$weight <- out$avWeights / mean(out$avWeights)                     (:2046; no na.rm)
+ *   weighted_pvalue := pvalue / weight ; weighted_padj := p.adjust(., "BH")   (:2047-2049)
+ * group codes are 1-based, INT32_MIN = NA_integer_.  Pinned by the golden table's group / weight /
+ * weighted_pvalue / weighted_padj columns (tests/test_results_postprocessing.py). */
+int oracle_ihw_apply(const double *avDist, const double *pvalue, int64_t n, const double *breaks, const double *avWeights,
+                     int32_t ngroups, int32_t *group, double *weight, double *wp, double *wpadj) {
+    long double sum = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const double x = log(fabs(avDist[i]));
+        int g = -1;
+        if (!isnan(x))
+            for (int k = 0; k < ngroups; k++)
+                if (x > breaks[k] && x <= breaks[k + 1]) { g = k; break; }
+        if (group) group[i] = g >= 0 ? g + 1 : INT32_MIN;
+        weight[i] = g >= 0 ? avWeights[g] : NAN;
+        sum += weight[i];
+    }
+    const double mean = (double)(sum / (long double)n);
+    for (int64_t i = 0; i < n; i++) {
+        weight[i] = weight[i] / mean;
+        wp[i] = pvalue[i] / weight[i];
+    }
+    return oracle_bh_adjust(wp, n, wpadj);
+}
+
+/* f4. getRegionUniverse, window mode, chicdiff.R:353-426.  For peak i (regionID i+1) the candidate otherEndIDs
+ * are .expandAvoidBait(baitID, oeID, s) (:353-367; R's a:b counts down when a > b), kept when the ID is on the
+ * restriction map (the rmap join, :389-391, and `otherEndID <= maxfrag`, :384) and on the bait's chromosome
+ * (:399).  chr_of[0..maxfrag], -1 = not on the map.  Rows come out in (regionID, otherEndID) order; pass
+ * ru_* = NULL to count only.  Returns the number of rows, or -1 for baitID == oeID (the reference stops). */
+int64_t oracle_region_universe(const int32_t *bait, const int32_t *oe, int64_t n, int32_t s, const int32_t *chr_of,
+                               int32_t maxfrag, int64_t *region_ptr, int32_t *ru_bait, int32_t *ru_region, int32_t *ru_oe) {
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int b = bait[i], o = oe[i];
+        int a, e;
+        if (abs(b - o) > s + 1) { a = o - s; e = o + s; }
+        else if (o > b) { a = b + 2; e = o + s; }
+        else if (o < b) { a = o - s; e = b - 2; }
+        else return -1;
+        const int lo = a < e ? a : e, hi = a < e ? e : a;
+        if (region_ptr) region_ptr[i] = pos;
+        const int bc = (b >= 1 && b <= maxfrag) ? chr_of[b] : -1;
+        for (int id = lo; id <= hi; id++) {
+            if (id < 1 || id > maxfrag || bc < 0 || chr_of[id] != bc) continue;
+            if (ru_bait) { ru_bait[pos] = b; ru_region[pos] = (int32_t)(i + 1); ru_oe[pos] = id; }
+            pos++;
+        }
+    }
+    if (region_ptr) region_ptr[n] = pos;
+    return pos;
+}

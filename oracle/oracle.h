@@ -115,6 +115,14 @@ int oracle_fragment_background(const int32_t *bait, const int32_t *oe, int64_t n
 /* a9 helpers: BH adjustment (p.adjust(method="BH") on the non-NaN entries; NaN stays NaN) */
 int oracle_bh_adjust(const double *p, int64_t n, double *padj);
 
+/* f3: IHW application side, chicdiff.R:2038-2049 (see chicdiff_oracle.c) */
+int oracle_ihw_apply(const double *avDist, const double *pvalue, int64_t n, const double *breaks, const double *avWeights,
+                     int32_t ngroups, int32_t *group, double *weight, double *wp, double *wpadj);
+
+/* f4: getRegionUniverse window mode, chicdiff.R:353-426 (see chicdiff_oracle.c) */
+int64_t oracle_region_universe(const int32_t *bait, const int32_t *oe, int64_t n, int32_t s, const int32_t *chr_of,
+                               int32_t maxfrag, int64_t *region_ptr, int32_t *ru_bait, int32_t *ru_region, int32_t *ru_oe);
+
 #ifdef __cplusplus
 }
 #endif

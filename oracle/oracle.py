@@ -83,6 +83,9 @@ def lib():
         P64 = C.POINTER(C.c_int64)
         L.oracle_fragment_background.argtypes = [_PI, _PI, C.c_int64, C.c_int32, C.c_int32, P64, C.c_int32, _PD, _PD, _PI, _PI,
                                                  _PD, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD]
+        L.oracle_ihw_apply.argtypes = [_PD, _PD, C.c_int64, _PD, _PD, C.c_int32, _PI, _PD, _PD, _PD]
+        L.oracle_region_universe.restype = C.c_int64
+        L.oracle_region_universe.argtypes = [_PI, _PI, C.c_int64, C.c_int32, _PI, C.c_int32, P64, _PI, _PI, _PI]
         _lib = L
     return _lib
 
@@ -234,3 +237,35 @@ def fragment_background(bait, oe, id_min, midsum, sj, si, tblb, tlb, T, distfun)
     if rc:
         raise RuntimeError(f"oracle_fragment_background rc={rc}")
     return B, Tm, F
+
+
+def ihw_apply(avDist, pvalue, breaks, avWeights):
+    """chicdiff.R:2038-2049.  Returns group (1-based, INT32_MIN = NA), weight, weighted_pvalue, weighted_padj."""
+    d = np.ascontiguousarray(avDist, dtype=np.float64)
+    p = np.ascontiguousarray(pvalue, dtype=np.float64)
+    b = np.ascontiguousarray(breaks, dtype=np.float64)
+    w = np.ascontiguousarray(avWeights, dtype=np.float64)
+    n = len(d)
+    group = np.empty(n, dtype=np.int32)
+    weight, wp, wpadj = (np.empty(n) for _ in range(3))
+    rc = lib().oracle_ihw_apply(_pd(d), _pd(p), n, _pd(b), _pd(w), len(w), _pi(group), _pd(weight), _pd(wp), _pd(wpadj))
+    if rc:
+        raise RuntimeError(f"oracle_ihw_apply rc={rc}")
+    return group, weight, wp, wpadj
+
+
+def region_universe(bait, oe, RUexpand, chr_of):
+    """chicdiff.R:353-426.  chr_of[0..maxfrag] (-1 = ID not on the map).  Returns region_ptr (n+1) and the RU rows
+    (baitID, regionID, otherEndID) in (regionID, otherEndID) order."""
+    b = np.ascontiguousarray(bait, dtype=np.int32)
+    o = np.ascontiguousarray(oe, dtype=np.int32)
+    c = np.ascontiguousarray(chr_of, dtype=np.int32)
+    n, maxfrag = len(b), len(c) - 1
+    ptr = np.empty(n + 1, dtype=np.int64)
+    P64 = C.POINTER(C.c_int64)
+    total = lib().oracle_region_universe(_pi(b), _pi(o), n, int(RUexpand), _pi(c), maxfrag, ptr.ctypes.data_as(P64), None, None, None)
+    if total < 0:
+        raise ValueError("Invalid parameters (baitID == oeID)")
+    rb, rr, ro = (np.empty(total, dtype=np.int32) for _ in range(3))
+    lib().oracle_region_universe(_pi(b), _pi(o), n, int(RUexpand), _pi(c), maxfrag, ptr.ctypes.data_as(P64), _pi(rb), _pi(rr), _pi(ro))
+    return ptr, rb, rr, ro

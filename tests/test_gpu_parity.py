@@ -567,3 +567,91 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), f"{k}: two runs differ"
         assert np.array_equal(a[k], c[k], equal_nan=True), f"{k}: layouts differ in {np.sum(~((a[k] == c[k]) | (np.isnan(a[k]) & np.isnan(c[k]))))} rows"
+
+
+def test_bh_on_device(ctx, oracle):
+    """f1/f3: p.adjust(p, "BH") — device sort + suffix minimum against the oracle; NA, ties, p = 0/1, n = 1."""
+    import torch
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 777, 300000):
+        p = rng.uniform(size=n) ** 3
+        if n > 10:
+            p[rng.integers(0, n, n // 10)] = np.nan
+            p[rng.integers(0, n, n // 10)] = p[3]  # ties
+            p[5], p[6] = 0.0, 1.0
+        got = ctx.bh_adjust(torch.from_numpy(p).to(ctx.device)).cpu().numpy()
+        ref = oracle.bh_adjust(p)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.array_equal(got[ok], ref[ok]), n  # same operations in the same order: identical bits
+    allna = ctx.bh_adjust(torch.full((50,), float("nan"), dtype=torch.float64, device=ctx.device)).cpu().numpy()
+    assert np.all(np.isnan(allna))
+
+
+def test_ihw_application_on_device_reproduces_golden_table(ctx, golden, oracle):
+    """f3: chicdiff.R:2038-2049 on device against the reference's result table and against the oracle."""
+    import torch
+    from post_inputs import ihw_tables_from_golden
+    breaks, w = ihw_tables_from_golden(golden)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(ctx.device)
+    out = {k: v.cpu().numpy() for k, v in ctx.ihw_apply(dev(golden["avDist"]), dev(golden["pvalue"]), breaks, w).items()}
+    assert np.array_equal(out["group"], golden["group"])
+    for k in ("weight", "weighted_pvalue", "weighted_padj"):
+        assert np.allclose(out[k], golden[k], rtol=1e-13), k
+    # NA handling: a distance outside the breaks, an NA p-value
+    av = golden["avDist"][:1000].copy()
+    pv = golden["pvalue"][:1000].copy()
+    pv[7] = np.nan
+    ref = oracle.ihw_apply(av, pv, breaks, w)
+    got = ctx.ihw_apply(dev(av), dev(pv), breaks, w)
+    assert np.array_equal(got["group"].cpu().numpy(), ref[0])
+    assert np.allclose(got["weighted_padj"].cpu().numpy(), ref[3], rtol=1e-13, equal_nan=True)
+    av[3] = 0.5  # log|avDist| < 0: group NA -> mean(avWeights) NA -> everything NA
+    got = ctx.ihw_apply(dev(av), dev(pv), breaks, w)
+    assert got["group"][3].item() == np.iinfo(np.int32).min and torch.isnan(got["weighted_padj"]).all()
+    with pytest.raises(Exception):
+        ctx.ihw_apply(dev(av), dev(pv), breaks[::-1].copy(), w)
+
+
+@pytest.mark.parametrize("s", [5, 0, 12])
+def test_region_universe_on_device(ctx, oracle, s):
+    """f4: getRegionUniverse window mode, bit-exact against the oracle on the reference's chr19 fragment IDs."""
+    import torch
+    from post_inputs import region_universe_case
+    bait, oe, chr_of = region_universe_case()
+    dev = lambda a: torch.from_numpy(a).to(ctx.device)
+    got = ctx.region_universe(dev(bait), dev(oe), s, dev(chr_of))
+    ptr, rb, rr, ro = oracle.region_universe(bait, oe, s, chr_of)
+    assert np.array_equal(got["region_ptr"].cpu().numpy(), ptr)
+    for k, ref in (("baitID", rb), ("regionID", rr), ("otherEndID", ro)):
+        assert np.array_equal(got[k].cpu().numpy(), ref), k
+    ln = np.diff(ptr)
+    mn, mx = got["minOE"].cpu().numpy(), got["maxOE"].cpu().numpy()
+    nz = ln > 0
+    assert np.array_equal(mn[nz], np.minimum.reduceat(ro, ptr[:-1][nz])) and np.array_equal(mx[nz], np.maximum.reduceat(ro, ptr[:-1][nz]))
+    assert np.all(mn[~nz] == np.iinfo(np.int32).min)
+    with pytest.raises(Exception):
+        ctx.region_universe(dev(np.array([5, 9], np.int32)), dev(np.array([7, 9], np.int32)), s, dev(chr_of))
+
+
+def test_post_mirrors(ctx, golden, oracle):
+    """Host mirrors over the f3 / f4 entry points: getRegionUniverse returns RU.DT's own row order,
+    applyIHWweights builds the breaks the way chicdiff.R:2039 does."""
+    from chicdiff_amd import post
+    from post_inputs import region_universe_case, region_universe_literal
+    bait, oe, chr_of = region_universe_case(n=1500)
+    ids = np.nonzero(chr_of >= 0)[0]
+    ru = post.getRegionUniverse(ctx, bait, oe, 5, chr_of[ids].astype(str), ids)
+    lit = region_universe_literal(bait, oe, 5, chr_of)
+    got = np.stack([ru[k].cpu().numpy() for k in ("baitID", "regionID", "otherEndID")], axis=1)
+    assert np.array_equal(got, lit)
+    # distLookup with group ranges that touch: the breaks fall on the group boundaries of the golden table
+    g = golden["group"].astype(np.int64)
+    x = np.log(np.abs(golden["avDist"]))
+    ng = int(g.max())
+    edges = [0.5 * (x[g == k].max() + x[g == k + 1].min()) for k in range(1, ng)]
+    lo, hi = np.array([1.0] + edges), np.array(edges + [20.0])
+    w = np.array([np.unique(golden["avWeights"][g == k])[0] for k in range(1, ng + 1)])
+    out = post.applyIHWweights(ctx, golden["avDist"], golden["pvalue"], lo, hi, w)
+    assert np.array_equal(out["group"].cpu().numpy(), golden["group"])
+    assert np.allclose(out["weighted_padj"].cpu().numpy(), golden["weighted_padj"], rtol=1e-13)

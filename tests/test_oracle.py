@@ -313,3 +313,35 @@ def test_fragment_background_matches_numpy_restatement():
         inside = p[0] + p[1] * edge + p[2] * edge ** 2 + p[3] * edge ** 3
         lin = (p[4] + edge * p[5]) if edge == p[8] else (p[6] + edge * p[7])
         assert abs(inside - lin) < 1e-9
+
+
+def test_ihw_application_reproduces_golden_table(golden):
+    """f3: group cut, weight renormalisation, weighted p and BH of chicdiff.R:2038-2049 against the reference's
+    own result table (24 863 rows)."""
+    from post_inputs import ihw_tables_from_golden
+    breaks, w = ihw_tables_from_golden(golden)
+    group, weight, wp, wpadj = oracle.ihw_apply(golden["avDist"], golden["pvalue"], breaks, w)
+    assert np.array_equal(group, golden["group"])
+    assert np.allclose(weight, golden["weight"], rtol=1e-14)
+    assert np.allclose(wp, golden["weighted_pvalue"], rtol=1e-14)
+    assert np.allclose(wpadj, golden["weighted_padj"], rtol=1e-14)
+    # cut(): right-closed intervals, NA outside; one NA weight makes mean(avWeights), hence every weight, NA
+    g2, w2, _, _ = oracle.ihw_apply(np.array([np.exp(breaks[1]), 0.5, 1e9]), np.array([0.1, 0.2, 0.3]), breaks, w)
+    assert g2[0] == 1 and g2[1] == np.iinfo(np.int32).min and g2[2] == len(w) and np.all(np.isnan(w2))
+
+
+@pytest.mark.parametrize("s", [5, 0, 1, 12])
+def test_region_universe_matches_literal_restatement(s):
+    """f4: the oracle's getRegionUniverse against a statement-by-statement twin on the reference's chr19 fragment IDs."""
+    from post_inputs import region_universe_case, region_universe_literal
+    bait, oe, chr_of = region_universe_case()
+    ptr, rb, rr, ro = oracle.region_universe(bait, oe, s, chr_of)
+    lit = region_universe_literal(bait, oe, s, chr_of)
+    assert ptr[-1] == len(rb) == len(lit) > 0
+    # RU.DT's order: stable sort by otherEndID, then by baitID, of the region-ordered rows
+    o1 = np.argsort(ro, kind="stable")
+    o2 = o1[np.argsort(rb[o1], kind="stable")]
+    assert np.array_equal(np.stack([rb[o2], rr[o2], ro[o2]], axis=1), lit)
+    assert np.array_equal(np.diff(ptr), np.bincount(rr, minlength=len(bait) + 1)[1:])
+    with pytest.raises(ValueError):
+        oracle.region_universe(np.array([5], np.int32), np.array([5], np.int32), s, chr_of)
