@@ -814,3 +814,26 @@ extern "C" int chicdiff_hip_region_universe_fill_dev(chicdiff_hip_ctx *c, const 
     timing_collect(c);
     return CHICDIFF_OK;
 }
+
+extern "C" int chicdiff_hip_count_table_dev(chicdiff_hip_ctx *c, const int32_t *d_bait, const int32_t *d_oe, const int32_t *d_N,
+                                            int64_t nrows, const uint8_t *d_bait_in_RU, int32_t max_id, int64_t *d_keys,
+                                            int32_t *d_vals, int64_t *nkeys_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_bait || !d_oe || !d_N || !d_keys || !d_vals || !nkeys_host || nrows < 1 || nrows >= (1ll << 32) || (d_bait_in_RU && max_id < 0))
+        return fail(c, CHICDIFF_E_INVALID, "count_table: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_aux(c, ct_workspace_bytes(nrows));
+    if (rc) return rc;
+    timing_reset(c);
+    {
+        Scope t(c, "count_table");
+        if (launch_count_table(d_bait, d_oe, d_N, nrows, d_bait_in_RU, max_id, d_keys, d_vals, c->aux, c->stream))
+            return fail(c, CHICDIFF_E_HIP, "count_table: sort failed");
+    }
+    unsigned long long h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, c->aux, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    *nkeys_host = (int64_t)h;
+    return CHICDIFF_OK;
+}

@@ -87,6 +87,9 @@ int launch_bh_adjust(const double *p, int64_t n, double *padj, char *ws, hipStre
 size_t ihw_workspace_bytes();
 void launch_ihw_apply(const double *avDist, const double *pvalue, int64_t n, const double *breaks, const double *weights,
                       int ng, int32_t *group, double *weight, double *wp, double *partials, hipStream_t st);
+size_t ct_workspace_bytes(int64_t n);
+int launch_count_table(const int32_t *bait, const int32_t *oe, const int32_t *N, int64_t n, const uint8_t *keep, int32_t max_id,
+                       int64_t *keys_out, int32_t *vals_out, char *ws, hipStream_t st);
 size_t ru_scan_bytes(int64_t n);
 int launch_ru_count(const int32_t *bait, const int32_t *oe, int64_t n, int s, const int32_t *chr_of, int maxfrag,
                     int64_t *region_ptr, int32_t *minOE, int32_t *maxOE, int *bad, void *tmp, size_t tmp_bytes, hipStream_t st);

@@ -156,6 +156,46 @@ void launch_ihw_apply(const double *avDist, const double *pvalue, int64_t n, con
     ihw_weight_kernel<<<kIhwBlocks, 256, 0, st>>>(pvalue, n, partials + kIhwBlocks, weight, wp);
 }
 
+// ---- f2: chinput columns -> sorted key table of the count join (chicdiff.R:826-831, :849) -----------------------
+__global__ __launch_bounds__(256) void ct_keys_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe, int64_t n,
+                                                      const uint8_t *__restrict__ keep, int32_t max_id, uint64_t *keys,
+                                                      unsigned long long *count) {
+    __shared__ unsigned int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned int mine = 0;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int32_t b = bait[i];
+        const bool k = b >= 0 && (!keep || (b <= max_id && keep[b]));
+        keys[i] = k ? (((uint64_t)(uint32_t)b << 32) | (uint32_t)oe[i]) : ~0ull;  // dropped rows sort to the end
+        mine += k ? 1u : 0u;
+    }
+    atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(count, (unsigned long long)s_cnt);
+}
+size_t ct_workspace_bytes(int64_t n) {
+    size_t tmp = 0;
+    uint64_t *k = nullptr;
+    int32_t *v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, v, v, (size_t)n, 0, 64, (hipStream_t)0);
+    return 256 + ((size_t)n * 8 + 255) / 256 * 256 + tmp + 256;
+}
+int launch_count_table(const int32_t *bait, const int32_t *oe, const int32_t *N, int64_t n, const uint8_t *keep, int32_t max_id,
+                       int64_t *keys_out, int32_t *vals_out, char *ws, hipStream_t st) {
+    unsigned long long *count = (unsigned long long *)ws;
+    uint64_t *k0 = (uint64_t *)(ws + 256);
+    void *tmp = ws + 256 + ((size_t)n * 8 + 255) / 256 * 256;
+    size_t tmp_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, (uint64_t *)keys_out, N, vals_out, (size_t)n, 0, 64, st);
+    if (hipMemsetAsync(count, 0, 8, st) != hipSuccess) return 1;
+    int blocks = (int)((n + 2047) / 2048);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    ct_keys_kernel<<<blocks, 256, 0, st>>>(bait, oe, n, keep, max_id, k0, count);
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, (uint64_t *)keys_out, N, vals_out, (size_t)n, 0, 64, st) == hipSuccess ? 0 : 1;
+}
+
 // ---- region universe (chicdiff.R:353-426) ----------------------------------------------------------------
 // .expandAvoidBait(bait, oe, s): (oe-s):(oe+s) unless the bait is within s+1 fragments, then the range stops two
 // fragments short of the bait.  R's a:b counts down when a > b, so the set is [min(a,b), max(a,b)].

@@ -26,7 +26,7 @@ EXPORTS = [
     "chicdiff_hip_set_allreduce", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
-    "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev",
+    "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
     "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
@@ -91,6 +91,7 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_count_join_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp]
     L.chicdiff_hip_fragment_background_dev.argtypes = [vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32,
                                                        C.POINTER(dbl), vp, vp, vp]
+    L.chicdiff_hip_count_table_dev.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, vp, C.POINTER(i64)]
     L.chicdiff_hip_bh_adjust_dev.argtypes = [vp, vp, i64, vp]
     L.chicdiff_hip_ihw_apply_dev.argtypes = [vp, vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl), i32, vp, vp, vp, vp]
     L.chicdiff_hip_region_universe_count_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, C.POINTER(i64)]
@@ -242,6 +243,21 @@ class HipContext:
             d_si.data_ptr(), d_tblb.data_ptr(), d_tlb.data_ptr(), d_T.data_ptr(), d_T.shape[1], d_T.shape[2],
             df.ctypes.data_as(C.POINTER(C.c_double)), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr()))
         return outs
+
+    # -- f2: chinput columns -> key table of the count join -------------------------------------
+    def count_table(self, d_bait, d_oe, d_N, d_bait_in_RU=None):
+        """(keys, vals) of ``count_join`` from unsorted chinput columns; rows whose bait is not flagged in
+        ``d_bait_in_RU`` (uint8 per ID) are dropped (chicdiff.R:828-831, :849)."""
+        torch = self.torch
+        n = d_bait.numel()
+        keys = torch.empty(n, dtype=torch.int64, device=self.device)
+        vals = torch.empty(n, dtype=torch.int32, device=self.device)
+        nk = C.c_int64(0)
+        self._check(self.lib.chicdiff_hip_count_table_dev(
+            self.h, d_bait.data_ptr(), d_oe.data_ptr(), d_N.data_ptr(), n,
+            d_bait_in_RU.data_ptr() if d_bait_in_RU is not None else None,
+            d_bait_in_RU.numel() - 1 if d_bait_in_RU is not None else 0, keys.data_ptr(), vals.data_ptr(), C.byref(nk)))
+        return keys[: nk.value], vals[: nk.value]
 
     # -- f1 / f3: BH and the IHW application side ----------------------------------------------
     def bh_adjust(self, d_p):

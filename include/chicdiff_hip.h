@@ -147,6 +147,15 @@ int chicdiff_hip_fragment_background_dev(chicdiff_hip_ctx *ctx, const int32_t *d
                                          const double *distfun_host, double *d_bmean, double *d_tmean,
                                          double *d_fullmean);
 
+/* f2 (device part) — chinput columns -> the key table chicdiff_hip_count_join_dev searches:
+ * setkey(x, baitID); x <- x[J(baits)] (chicdiff.R:828-831: only rows whose bait is an RU bait) and
+ * setkey(temp, baitID, otherEndID) (:849).  d_bait_in_RU: one byte per ID 0..max_id (non-zero = keep) or NULL =
+ * keep every row.  d_keys / d_vals hold nrows entries; the first *nkeys_host are the table, ascending in
+ * (baitID << 32 | otherEndID).  Reading the chinput text stays host code. */
+int chicdiff_hip_count_table_dev(chicdiff_hip_ctx *ctx, const int32_t *d_bait, const int32_t *d_oe, const int32_t *d_N,
+                                 int64_t nrows, const uint8_t *d_bait_in_RU, int32_t max_id, int64_t *d_keys,
+                                 int32_t *d_vals, int64_t *nkeys_host);
+
 /* f1/f3 — p.adjust(p, method = "BH") (DESeq2 results() on the independent-filtering survivors; chicdiff.R:2049
  * on the weighted p-values).  NaN = NA: not counted, stays NaN.  n < 2^32. */
 int chicdiff_hip_bh_adjust_dev(chicdiff_hip_ctx *ctx, const double *d_p, int64_t n, double *d_padj);

@@ -269,3 +269,18 @@ def region_universe(bait, oe, RUexpand, chr_of):
     rb, rr, ro = (np.empty(total, dtype=np.int32) for _ in range(3))
     lib().oracle_region_universe(_pi(b), _pi(o), n, int(RUexpand), _pi(c), maxfrag, ptr.ctypes.data_as(P64), _pi(rb), _pi(rr), _pi(ro))
     return ptr, rb, rr, ro
+
+
+def count_table(bait, oe, N, bait_in_RU=None):
+    """f2: chicdiff.R:826-831 and :849 on the parsed chinput columns: keep rows whose bait is an RU bait
+    (x[J(baits)]), key by (baitID, otherEndID).  Returns keys (baitID << 32 | otherEndID, ascending) and N."""
+    b = np.asarray(bait, dtype=np.int64)
+    o = np.asarray(oe, dtype=np.int64)
+    v = np.asarray(N, dtype=np.int32)
+    if bait_in_RU is not None:
+        flags = np.asarray(bait_in_RU).astype(bool)
+        keep = (b < len(flags)) & flags[np.minimum(b, len(flags) - 1)]
+        b, o, v = b[keep], o[keep], v[keep]
+    keys = (b << 32) | o
+    order = np.argsort(keys, kind="stable")
+    return keys[order], v[order]

@@ -655,3 +655,26 @@ def test_post_mirrors(ctx, golden, oracle):
     out = post.applyIHWweights(ctx, golden["avDist"], golden["pvalue"], lo, hi, w)
     assert np.array_equal(out["group"].cpu().numpy(), golden["group"])
     assert np.allclose(out["weighted_padj"].cpu().numpy(), golden["weighted_padj"], rtol=1e-13)
+
+
+def test_count_table_feeds_count_join(ctx, oracle):
+    """f2: unsorted chinput columns -> key table (bait filter + sort) -> count join, bit-exact against the oracle."""
+    import torch
+    rng = np.random.default_rng(21)
+    nrows = 200000
+    pairs = rng.choice(3000 * 3000, nrows, replace=False)  # unique (baitID, otherEndID) pairs, as in a chinput
+    bait, oe = (pairs // 3000 + 1).astype(np.int32), (pairs % 3000 + 1).astype(np.int32)
+    N = rng.integers(1, 200, nrows).astype(np.int32)
+    in_ru = (rng.uniform(size=3002) < 0.3).astype(np.uint8)
+    dev = lambda a: torch.from_numpy(a).to(ctx.device)
+    for flags in (in_ru, None):
+        keys, vals = ctx.count_table(dev(bait), dev(oe), dev(N), dev(flags) if flags is not None else None)
+        rk, rv = oracle.count_table(bait, oe, N, flags)
+        assert np.array_equal(keys.cpu().numpy(), rk) and np.array_equal(vals.cpu().numpy(), rv)
+    keys, vals = ctx.count_table(dev(bait), dev(oe), dev(N), dev(in_ru))
+    qb, qo = rng.integers(1, 3001, 50000).astype(np.int32), rng.integers(1, 3001, 50000).astype(np.int32)
+    order = np.lexsort((qo, qb))
+    qb, qo = qb[order], qo[order]
+    got = ctx.count_join(dev(qb), dev(qo), keys, vals).cpu().numpy()
+    rk, rv = oracle.count_table(bait, oe, N, in_ru)
+    assert np.array_equal(got, oracle.count_join(qb, qo, rk, rv)) and (got > 0).sum() > 100
