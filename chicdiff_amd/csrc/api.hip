@@ -837,3 +837,35 @@ extern "C" int chicdiff_hip_count_table_dev(chicdiff_hip_ctx *c, const int32_t *
     *nkeys_host = (int64_t)h;
     return CHICDIFF_OK;
 }
+
+// ---- device memory for hosts without their own GPU arrays (the R shim) ---------------------------------------
+extern "C" int chicdiff_hip_malloc(chicdiff_hip_ctx *c, uint64_t bytes, void **d_ptr) {
+    if (!c || !d_ptr) return CHICDIFF_E_INVALID;
+    *d_ptr = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? (size_t)bytes : 1);
+    if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "device allocation of %llu bytes: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return CHICDIFF_OK;
+}
+extern "C" int chicdiff_hip_free(chicdiff_hip_ctx *c, void *d_ptr) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_ptr) return CHICDIFF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_ptr));
+    return CHICDIFF_OK;
+}
+extern "C" int chicdiff_hip_memcpy_h2d(chicdiff_hip_ctx *c, void *d_dst, const void *h_src, uint64_t bytes) {
+    if (!c || (bytes && (!d_dst || !h_src))) return c ? fail(c, CHICDIFF_E_INVALID, "memcpy_h2d: NULL pointer") : CHICDIFF_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CHICDIFF_OK;
+}
+extern "C" int chicdiff_hip_memcpy_d2h(chicdiff_hip_ctx *c, void *h_dst, const void *d_src, uint64_t bytes) {
+    if (!c || (bytes && (!h_dst || !d_src))) return c ? fail(c, CHICDIFF_E_INVALID, "memcpy_d2h: NULL pointer") : CHICDIFF_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CHICDIFF_OK;
+}

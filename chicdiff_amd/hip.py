@@ -27,6 +27,7 @@ EXPORTS = [
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
     "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
+    "chicdiff_hip_malloc", "chicdiff_hip_free", "chicdiff_hip_memcpy_h2d", "chicdiff_hip_memcpy_d2h",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
     "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
@@ -91,6 +92,10 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_count_join_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp]
     L.chicdiff_hip_fragment_background_dev.argtypes = [vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32,
                                                        C.POINTER(dbl), vp, vp, vp]
+    L.chicdiff_hip_malloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.chicdiff_hip_free.argtypes = [vp, vp]
+    L.chicdiff_hip_memcpy_h2d.argtypes = [vp, vp, vp, C.c_uint64]
+    L.chicdiff_hip_memcpy_d2h.argtypes = [vp, vp, vp, C.c_uint64]
     L.chicdiff_hip_count_table_dev.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, vp, C.POINTER(i64)]
     L.chicdiff_hip_bh_adjust_dev.argtypes = [vp, vp, i64, vp]
     L.chicdiff_hip_ihw_apply_dev.argtypes = [vp, vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl), i32, vp, vp, vp, vp]

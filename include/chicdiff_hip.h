@@ -61,6 +61,13 @@ int chicdiff_hip_set_stream(chicdiff_hip_ctx *ctx, void *hip_stream);
 int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, void *user,
                                int32_t world_size, int32_t rank);
 
+/* Device memory for hosts without a GPU array library of their own (the R shim): plain allocations on the
+ * context's device, copies ordered on the context's stream and complete on return. */
+int chicdiff_hip_malloc(chicdiff_hip_ctx *ctx, uint64_t bytes, void **d_ptr);
+int chicdiff_hip_free(chicdiff_hip_ctx *ctx, void *d_ptr);
+int chicdiff_hip_memcpy_h2d(chicdiff_hip_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int chicdiff_hip_memcpy_d2h(chicdiff_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+
 /* DESeq2 defaults that Chicdiff never overrides (chicdiff.R:1573-1574 pass no arguments). */
 typedef struct {
     double minDisp;      /* 1e-8 */

@@ -94,7 +94,86 @@ SEXP chicdiff_hip_fit(SEXP counts, SEXP nf, SEXP group, SEXP dispPriorVar) {
     return out;
 }
 
-static const R_CallMethodDef call_methods[] = {{"chicdiff_hip_fit", (DL_FUNC)&chicdiff_hip_fit, 4}, {NULL, NULL, 0}};
+/* Device buffers come from the library itself (chicdiff_hip_malloc / memcpy_*): no HIP headers needed here. */
+static void *to_device(chicdiff_hip_ctx *c, const void *h, size_t bytes) {
+    void *d = NULL;
+    if (chicdiff_hip_malloc(c, bytes, &d) || chicdiff_hip_memcpy_h2d(c, d, h, bytes)) {
+        chicdiff_hip_free(c, d);
+        Rf_error("chicdiff_hip: %s", chicdiff_hip_last_error(c));
+    }
+    return d;
+}
+
+/* .Call("chicdiff_hip_ihw_apply", avDist, pvalue, breaks, avWeights) -> list(group, weight, weighted_pvalue,
+ * weighted_padj): chicdiff.R:2038-2049 */
+SEXP chicdiff_hip_ihw_apply(SEXP avDist, SEXP pvalue, SEXP breaks, SEXP avWeights) {
+    if (!Rf_isReal(avDist) || !Rf_isReal(pvalue) || !Rf_isReal(breaks) || !Rf_isReal(avWeights) ||
+        XLENGTH(avDist) != XLENGTH(pvalue) || LENGTH(breaks) != LENGTH(avWeights) + 1)
+        Rf_error("chicdiff_hip_ihw_apply: bad arguments");
+    const R_xlen_t n = XLENGTH(avDist);
+    chicdiff_hip_ctx *c = ctx_or_error();
+    static const char *names[] = {"group", "weight", "weighted_pvalue", "weighted_padj"};
+    SEXP out = PROTECT(named_list(4, names));
+    SET_VECTOR_ELT(out, 0, Rf_allocVector(INTSXP, n));
+    for (int k = 1; k < 4; k++) SET_VECTOR_ELT(out, k, Rf_allocVector(REALSXP, n));
+    void *d_av = to_device(c, REAL(avDist), 8 * (size_t)n), *d_p = to_device(c, REAL(pvalue), 8 * (size_t)n);
+    void *d_out[4] = {NULL, NULL, NULL, NULL};
+    int rc = chicdiff_hip_malloc(c, 4 * (size_t)n, &d_out[0]);
+    for (int k = 1; k < 4 && !rc; k++) rc = chicdiff_hip_malloc(c, 8 * (size_t)n, &d_out[k]);
+    if (!rc)
+        rc = chicdiff_hip_ihw_apply_dev(c, d_av, d_p, (int64_t)n, REAL(breaks), REAL(avWeights), LENGTH(avWeights), d_out[0], d_out[1],
+                                        d_out[2], d_out[3]);
+    if (!rc) rc = chicdiff_hip_memcpy_d2h(c, INTEGER(VECTOR_ELT(out, 0)), d_out[0], 4 * (size_t)n); /* INT32_MIN is NA_integer_ */
+    for (int k = 1; k < 4 && !rc; k++) rc = chicdiff_hip_memcpy_d2h(c, REAL(VECTOR_ELT(out, k)), d_out[k], 8 * (size_t)n);
+    char msg[512] = "";
+    if (rc) strncpy(msg, chicdiff_hip_last_error(c), sizeof msg - 1);
+    chicdiff_hip_free(c, d_av);
+    chicdiff_hip_free(c, d_p);
+    for (int k = 0; k < 4; k++) chicdiff_hip_free(c, d_out[k]);
+    UNPROTECT(1);
+    if (rc) Rf_error("chicdiff_hip_ihw_apply: %s", msg);
+    return out;
+}
+
+/* .Call("chicdiff_hip_region_universe", baitID, oeID, RUexpand, chr_of) -> list(baitID, regionID, otherEndID)
+ * in (regionID, otherEndID) order: chicdiff.R:376-401; chr_of[ID + 1] = chromosome code of rmap ID (0-based
+ * vector of length maxfrag + 1, -1 = not on the map) */
+SEXP chicdiff_hip_region_universe(SEXP baitID, SEXP oeID, SEXP RUexpand, SEXP chr_of) {
+    if (!Rf_isInteger(baitID) || !Rf_isInteger(oeID) || !Rf_isInteger(chr_of) || XLENGTH(baitID) != XLENGTH(oeID))
+        Rf_error("chicdiff_hip_region_universe: bad arguments");
+    const R_xlen_t n = XLENGTH(baitID);
+    const int maxfrag = LENGTH(chr_of) - 1, s = Rf_asInteger(RUexpand);
+    chicdiff_hip_ctx *c = ctx_or_error();
+    void *d_b = to_device(c, INTEGER(baitID), 4 * (size_t)n), *d_o = to_device(c, INTEGER(oeID), 4 * (size_t)n);
+    void *d_chr = to_device(c, INTEGER(chr_of), 4 * (size_t)(maxfrag + 1)), *d_ptr = NULL, *d_rows[3] = {NULL, NULL, NULL};
+    int64_t total = 0;
+    int rc = chicdiff_hip_malloc(c, 8 * (size_t)(n + 1), &d_ptr);
+    if (!rc) rc = chicdiff_hip_region_universe_count_dev(c, d_b, d_o, (int64_t)n, s, d_chr, maxfrag, d_ptr, NULL, NULL, &total);
+    static const char *names[] = {"baitID", "regionID", "otherEndID"};
+    SEXP out = PROTECT(named_list(3, names));
+    for (int k = 0; k < 3 && !rc; k++) {
+        SET_VECTOR_ELT(out, k, Rf_allocVector(INTSXP, total));
+        rc = chicdiff_hip_malloc(c, 4 * (size_t)total, &d_rows[k]);
+    }
+    if (!rc && total > 0)
+        rc = chicdiff_hip_region_universe_fill_dev(c, d_b, d_o, (int64_t)n, s, d_chr, maxfrag, d_ptr, d_rows[0], d_rows[1], d_rows[2]);
+    for (int k = 0; k < 3 && !rc; k++) rc = chicdiff_hip_memcpy_d2h(c, INTEGER(VECTOR_ELT(out, k)), d_rows[k], 4 * (size_t)total);
+    char msg[512] = "";
+    if (rc) strncpy(msg, chicdiff_hip_last_error(c), sizeof msg - 1);
+    chicdiff_hip_free(c, d_b);
+    chicdiff_hip_free(c, d_o);
+    chicdiff_hip_free(c, d_chr);
+    chicdiff_hip_free(c, d_ptr);
+    for (int k = 0; k < 3; k++) chicdiff_hip_free(c, d_rows[k]);
+    UNPROTECT(1);
+    if (rc) Rf_error("chicdiff_hip_region_universe: %s", msg);
+    return out;
+}
+
+static const R_CallMethodDef call_methods[] = {{"chicdiff_hip_fit", (DL_FUNC)&chicdiff_hip_fit, 4},
+                                               {"chicdiff_hip_ihw_apply", (DL_FUNC)&chicdiff_hip_ihw_apply, 4},
+                                               {"chicdiff_hip_region_universe", (DL_FUNC)&chicdiff_hip_region_universe, 4},
+                                               {NULL, NULL, 0}};
 
 void R_init_chicdiffhip(DllInfo *dll) {
     R_registerRoutines(dll, NULL, call_methods, NULL, NULL);

@@ -20,7 +20,7 @@ def lib():
 def test_exports_match_header(lib):
     from chicdiff_amd import hip
     hdr = open(os.path.join(ROOT, "include", "chicdiff_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(chicdiff_hip_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(chicdiff_hip_[a-z0-9_]+)\s*\(", hdr)))
     assert declared == sorted(hip.EXPORTS)
     for sym in declared:
         assert hasattr(lib, sym), sym

@@ -678,3 +678,29 @@ def test_count_table_feeds_count_join(ctx, oracle):
     got = ctx.count_join(dev(qb), dev(qo), keys, vals).cpu().numpy()
     rk, rv = oracle.count_table(bait, oe, N, in_ru)
     assert np.array_equal(got, oracle.count_join(qb, qo, rk, rv)) and (got > 0).sum() > 100
+
+
+def test_c_abi_without_torch_arrays(ctx, oracle):
+    """What the R shim does: device buffers from the library's own malloc / memcpy entry points, no torch tensor
+    anywhere on the data path (size factors, then BH on a vector of p-values)."""
+    import ctypes as C
+    L, h = ctx.lib, ctx.h
+    d = synth.make(5000, 4)
+    counts = np.asfortranarray(d["counts"].astype(np.int32))  # n x S column-major, as INTEGER(mat) in R
+    dptr = C.c_void_p()
+    assert L.chicdiff_hip_malloc(h, counts.nbytes, C.byref(dptr)) == 0 and dptr.value
+    assert L.chicdiff_hip_memcpy_h2d(h, dptr, counts.ctypes.data, counts.nbytes) == 0
+    sf = np.empty(4)
+    assert L.chicdiff_hip_size_factors_dev(h, dptr, 5000, 4, sf.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    assert np.allclose(sf, oracle.size_factors(d["counts"]), rtol=1e-13)
+    assert L.chicdiff_hip_free(h, dptr) == 0
+    p = np.random.default_rng(2).uniform(size=4096)
+    dp, dq = C.c_void_p(), C.c_void_p()
+    assert L.chicdiff_hip_malloc(h, p.nbytes, C.byref(dp)) == 0 and L.chicdiff_hip_malloc(h, p.nbytes, C.byref(dq)) == 0
+    assert L.chicdiff_hip_memcpy_h2d(h, dp, p.ctypes.data, p.nbytes) == 0
+    assert L.chicdiff_hip_bh_adjust_dev(h, dp, len(p), dq) == 0
+    q = np.empty_like(p)
+    assert L.chicdiff_hip_memcpy_d2h(h, q.ctypes.data, dq, q.nbytes) == 0
+    assert np.array_equal(q, oracle.bh_adjust(p))
+    assert L.chicdiff_hip_free(h, dp) == 0 and L.chicdiff_hip_free(h, dq) == 0
+    assert L.chicdiff_hip_memcpy_h2d(h, None, p.ctypes.data, 8) != 0  # NULL device pointer: an error, not a crash
