@@ -144,8 +144,18 @@ def main():
     n, S = args.rows, args.samples
     d = synth.make(n, S, start=rank * n)
     ctx = hip.HipContext(local_rank)
+    collectives = "none (single rank)"
     if world > 1:
-        ctx.set_process_group()
+        try:  # the library's own RCCL communicator: ncclAllReduce issued from C++ on the fit's stream
+            if os.environ.get("CHICDIFF_BENCH_COLLECTIVES") == "torch":
+                raise RuntimeError("CHICDIFF_BENCH_COLLECTIVES=torch")
+            ctx.init_rccl()
+            collectives = "RCCL, called by the library (ncclAllReduce on device buffers)"
+        except Exception as e:  # same protocol through torch.distributed (one Python callback per collective)
+            if rank == 0:
+                print(f"direct RCCL unavailable ({e}); using the torch.distributed hook", file=sys.stderr)
+            ctx.set_process_group()
+            collectives = "RCCL through torch.distributed.all_reduce (host callback)"
     dk = ctx.to_device(d["counts"], np.int32)
     dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)  # region-level FullMean (window sums)
     group = d["group"]
@@ -208,7 +218,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic {n} interactions x {S} samples ({S // 2}v{S - S // 2}) per GPU, "
                                f"size factors + offsets(theta={args.theta}) + dispersions + Wald, design ~condition",
-                   "rows_per_gpu": n, "samples": S, "global_rows": world * n, "parallelism": f"rows-sharded x{world}"},
+                   "rows_per_gpu": n, "samples": S, "global_rows": world * n, "parallelism": f"rows-sharded x{world}",
+                   "collectives": collectives},
         "roofline": roofline,
         "kernels_ms": {k: [round(v[0] / args.steps, 4), v[1] // args.steps] for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
         "fit_status": int(sc["status"]),

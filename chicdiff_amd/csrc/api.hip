@@ -12,6 +12,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <string.h>
+
 #include "common.h"
 
 using namespace cd;
@@ -29,6 +32,11 @@ struct chicdiff_hip_ctx {
     chicdiff_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
     int world = 1, rank = 0;
+    // direct RCCL path (chicdiff_hip_rccl_init): librccl is dlopen'ed, never linked
+    void *rccl_lib = nullptr, *rccl_comm = nullptr;
+    int (*rccl_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*rccl_comm_destroy)(void *) = nullptr;
+    const char *(*rccl_error_string)(int) = nullptr;
     char err[512] = {0};
     // workspace
     int64_t cap_n = 0;
@@ -116,6 +124,7 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->h_sc) (void)hipHostFree(c->h_sc);
     if (c->h_sf) (void)hipHostFree(c->h_sf);
+    if (c->rccl_comm && c->rccl_comm_destroy) (void)c->rccl_comm_destroy(c->rccl_comm);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -131,6 +140,62 @@ int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *c, chicdiff_allreduce_fn fn, vo
         return fail(c, CHICDIFF_E_INVALID, "set_allreduce: bad arguments");
     c->allreduce = fn;
     c->allreduce_user = user;
+    c->world = world;
+    c->rank = rank;
+    return CHICDIFF_OK;
+}
+
+// ---- direct RCCL: the library calls ncclAllReduce itself on its own stream (no host callback per collective) ----
+struct RcclUniqueId { char internal[128]; };  // NCCL_UNIQUE_ID_BYTES
+static int rccl_open(chicdiff_hip_ctx *c, const char *path) {
+    if (c->rccl_lib) return CHICDIFF_OK;
+    void *h = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(c, CHICDIFF_E_COMM, "dlopen(%s): %s", path && path[0] ? path : "librccl.so", dlerror());
+    c->rccl_lib = h;
+    return CHICDIFF_OK;
+}
+static int rccl_allreduce_cb(void *user, void *dev_buf, int64_t count) {
+    chicdiff_hip_ctx *c = (chicdiff_hip_ctx *)user;
+    const int r = c->rccl_allreduce(dev_buf, dev_buf, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->rccl_comm, c->stream);
+    if (r != 0) {
+        fail(c, CHICDIFF_E_COMM, "ncclAllReduce: %s", c->rccl_error_string ? c->rccl_error_string(r) : "error");
+        return 1;
+    }
+    return 0;
+}
+int chicdiff_hip_rccl_unique_id(chicdiff_hip_ctx *c, const char *librccl_path, void *id128) {
+    if (!c || !id128) return CHICDIFF_E_INVALID;
+    int rc = rccl_open(c, librccl_path);
+    if (rc) return rc;
+    auto get = (int (*)(RcclUniqueId *))dlsym(c->rccl_lib, "ncclGetUniqueId");
+    if (!get) return fail(c, CHICDIFF_E_COMM, "librccl lacks ncclGetUniqueId");
+    const int r = get((RcclUniqueId *)id128);
+    if (r != 0) return fail(c, CHICDIFF_E_COMM, "ncclGetUniqueId failed (%d)", r);
+    return CHICDIFF_OK;
+}
+int chicdiff_hip_rccl_init(chicdiff_hip_ctx *c, const char *librccl_path, const void *id128, int32_t world, int32_t rank) {
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(c, CHICDIFF_E_INVALID, "rccl_init: bad arguments");
+    int rc = rccl_open(c, librccl_path);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    auto init = (int (*)(void **, int, RcclUniqueId, int))dlsym(c->rccl_lib, "ncclCommInitRank");
+    c->rccl_allreduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(c->rccl_lib, "ncclAllReduce");
+    c->rccl_comm_destroy = (int (*)(void *))dlsym(c->rccl_lib, "ncclCommDestroy");
+    c->rccl_error_string = (const char *(*)(int))dlsym(c->rccl_lib, "ncclGetErrorString");
+    if (!init || !c->rccl_allreduce || !c->rccl_comm_destroy) return fail(c, CHICDIFF_E_COMM, "librccl lacks ncclCommInitRank / ncclAllReduce / ncclCommDestroy");
+    if (c->rccl_comm) {
+        (void)c->rccl_comm_destroy(c->rccl_comm);
+        c->rccl_comm = nullptr;
+    }
+    RcclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    const int r = init(&c->rccl_comm, world, id, rank);
+    if (r != 0) {
+        c->rccl_comm = nullptr;
+        return fail(c, CHICDIFF_E_COMM, "ncclCommInitRank: %s", c->rccl_error_string ? c->rccl_error_string(r) : "error");
+    }
+    c->allreduce = rccl_allreduce_cb;
+    c->allreduce_user = c;
     c->world = world;
     c->rank = rank;
     return CHICDIFF_OK;
@@ -286,7 +351,8 @@ struct HipBackend {
     int err = 0;
     int world() const { return c->allreduce ? (c->world > 1 ? c->world : 2) : 1; }  // callback set => sharded protocol
     int allreduce(double *buf, int64_t n) { return do_allreduce(c, buf, n); }
-    double *sums() { return sums_of(c->w); }
+    double *sums() { return c->w.partials; }  // sharded: the per-block partials themselves are all-reduced (one launch fewer per pass)
+    int64_t sums_len() const { return (int64_t)trend_blocks() * kTrendSums; }
     double *hist() { return c->w.hist; }
     void trend_init() { launch_trend_init(d, c->w, o, c->stream); }
     void trend_pass(bool fused) {

@@ -41,8 +41,9 @@ void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWor
 void launch_disp_map(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st);  // single rank: whole trend fit, one launch
 void launch_trend_init(FitDims d, FitWork w, Opts o, hipStream_t st);
-void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st, bool fused_step);  // pass + reduce (+ step when single rank)
-void launch_trend_step(FitDims d, FitWork w, Opts o, hipStream_t st);   // consumes sums, advances the state machine
+int trend_blocks();                                                       // grid of the trend pass = rows of 8 partial sums
+void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st, bool fused_step);  // pass (+ reduce + step when single rank)
+void launch_trend_step(FitDims d, FitWork w, Opts o, hipStream_t st);   // fixed-order sum of the (all-reduced) partials + state machine step
 void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);

@@ -7,7 +7,8 @@
 // Backend concept:
 //   int  world() const;                       // ranks sharing the fit
 //   int  allreduce(double *buf, int64_t n);   // sum-all-reduce in place (backend memory); 0 = ok
-//   double *sums();  double *hist();          // backend buffers the driver hands to allreduce
+//   double *sums();  int64_t sums_len();      // per-pass trend partials handed to allreduce (HIP: one row of 8 per block)
+//   double *hist();                           // select histograms handed to allreduce
 //   void trend_init(); void trend_pass(bool fused_step); void trend_step();
 //   const FitScalars *sync_scalars();         // make the scalars host-visible (may block)
 //   void sel_hist(const SelSpec&, int shift);   // digit histograms for the live prefixes (first round: all keys)
@@ -36,8 +37,8 @@ int drive_trend(B &be) {
             const bool single = be.world() <= 1;
             be.trend_pass(single);  // single rank: the reducing block also advances the state machine
             if (!single) {
-                if (be.allreduce(be.sums(), kTrendSums)) return -1;
-                be.trend_step();
+                if (be.allreduce(be.sums(), be.sums_len())) return -1;
+                be.trend_step();  // sums the (all-reduced) partials in a fixed order and advances the state machine
             }
         }
         passes += batch;

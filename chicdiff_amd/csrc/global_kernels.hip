@@ -197,11 +197,12 @@ void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
 
 void launch_trend_init(FitDims, FitWork w, Opts, hipStream_t st) { trend_init_kernel<<<1, 1, 0, st>>>(w); }
 constexpr int kTrendBlocks = 512;
+int trend_blocks() { return kTrendBlocks; }
 void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st, bool fused_step) {
     trend_pass_kernel<<<kTrendBlocks, 256, 0, st>>>(d, w, o.minDisp);
-    trend_reduce_kernel<<<1, 256, 0, st>>>(w, kTrendBlocks, fused_step ? 1 : 0);
+    if (fused_step) trend_reduce_kernel<<<1, 256, 0, st>>>(w, kTrendBlocks, 1);
 }
-void launch_trend_step(FitDims, FitWork w, Opts, hipStream_t st) { trend_step_kernel<<<1, 1, 0, st>>>(w); }
+void launch_trend_step(FitDims, FitWork w, Opts, hipStream_t st) { trend_reduce_kernel<<<1, 256, 0, st>>>(w, kTrendBlocks, 1); }
 
 // residuals of log gene-wise estimates around the trend (rows with dispGeneEst >= 100*minDisp)
 __global__ __launch_bounds__(256) void resid_kernel(FitDims d, FitWork w, double minDisp) {

@@ -28,6 +28,7 @@ EXPORTS = [
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
     "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
     "chicdiff_hip_malloc", "chicdiff_hip_free", "chicdiff_hip_memcpy_h2d", "chicdiff_hip_memcpy_d2h",
+    "chicdiff_hip_rccl_unique_id", "chicdiff_hip_rccl_init",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
     "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
@@ -92,6 +93,8 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_count_join_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp]
     L.chicdiff_hip_fragment_background_dev.argtypes = [vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32,
                                                        C.POINTER(dbl), vp, vp, vp]
+    L.chicdiff_hip_rccl_unique_id.argtypes = [vp, C.c_char_p, vp]
+    L.chicdiff_hip_rccl_init.argtypes = [vp, C.c_char_p, vp, i32, i32]
     L.chicdiff_hip_malloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.chicdiff_hip_free.argtypes = [vp, vp]
     L.chicdiff_hip_memcpy_h2d.argtypes = [vp, vp, vp, C.c_uint64]
@@ -189,6 +192,44 @@ class HipContext:
 
         self._hook = AllReduceHook(group, memory=memory, device=self.device)
         self._check(self.lib.chicdiff_hip_set_allreduce(self.h, self._hook.fn, None, self._hook.world, self._hook.rank))
+
+    def init_rccl(self, group=None, librccl_path=None):
+        """Direct RCCL: the library makes its own communicator over the ranks of ``group`` and issues
+        ncclAllReduce itself (no Python callback per collective).  torch.distributed only carries the
+        128-byte unique id.  Uses the librccl torch itself loaded unless ``librccl_path`` says otherwise."""
+        import os
+
+        import torch.distributed as dist
+
+        torch = self.torch
+        if librccl_path is None:
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            librccl_path = cand if os.path.exists(cand) else "librccl.so"
+        path = librccl_path.encode()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = self.device if dist.get_backend(group) == "nccl" else "cpu"
+
+        def all_ok(ok: bool) -> bool:  # every rank must take the same branch, or the collectives that follow hang
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return bool(flag.item())
+
+        # phase 1, local: can this rank open librccl at all?  (every rank makes an id; only rank 0's is used)
+        ident = (C.c_char * 128)()
+        rc = self.lib.chicdiff_hip_rccl_unique_id(self.h, path, ident)
+        msg = self.lib.chicdiff_hip_last_error(self.h).decode() if rc else ""
+        if not all_ok(rc == 0):
+            raise ChicdiffHipError(f"librccl not usable on every rank ({msg or 'another rank failed'})")
+        # phase 2, collective: share rank 0's id, create the communicator
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        buf = (C.c_char * 128).from_buffer_copy(box[0])
+        rc = self.lib.chicdiff_hip_rccl_init(self.h, path, buf, world, rank)
+        msg = self.lib.chicdiff_hip_last_error(self.h).decode() if rc else ""
+        if not all_ok(rc == 0):
+            self.lib.chicdiff_hip_set_allreduce(self.h, C.cast(None, ALLREDUCE_FN), None, 1, 0)
+            raise ChicdiffHipError(f"ncclCommInitRank did not succeed on every rank ({msg or 'another rank failed'})")
+        self._hook = None
 
     def to_device(self, a, dtype):
         """(n, S) host array -> (S, n) contiguous device tensor (sample-major)."""

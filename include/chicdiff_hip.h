@@ -61,6 +61,15 @@ int chicdiff_hip_set_stream(chicdiff_hip_ctx *ctx, void *hip_stream);
 int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, void *user,
                                int32_t world_size, int32_t rank);
 
+/* Direct RCCL (backend of choice on one node: RCCL over xGMI).  The library dlopen()s librccl (librccl_path, or
+ * "librccl.so" when NULL/empty — pass the copy the host process already uses, e.g. torch's), creates its own
+ * communicator and from then on calls ncclAllReduce(ncclFloat64, ncclSum) itself, in place on its stream: no host
+ * callback per collective.  Rank 0 makes the 128-byte id with _unique_id and the host broadcasts it (any
+ * transport); every rank then calls _init, which replaces a callback set with chicdiff_hip_set_allreduce. */
+int chicdiff_hip_rccl_unique_id(chicdiff_hip_ctx *ctx, const char *librccl_path, void *id128);
+int chicdiff_hip_rccl_init(chicdiff_hip_ctx *ctx, const char *librccl_path, const void *id128, int32_t world_size,
+                           int32_t rank);
+
 /* Device memory for hosts without a GPU array library of their own (the R shim): plain allocations on the
  * context's device, copies ordered on the context's stream and complete on return. */
 int chicdiff_hip_malloc(chicdiff_hip_ctx *ctx, uint64_t bytes, void **d_ptr);

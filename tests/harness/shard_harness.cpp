@@ -39,6 +39,7 @@ struct CpuBackend {
     int world() const { return world_; }
     int allreduce(double *buf, int64_t cnt) { return world_ > 1 ? cb(user, buf, cnt) : 0; }
     double *sums() { return sums_.data(); }
+    int64_t sums_len() const { return cd::kTrendSums; }
     double *hist() { return hist_.data(); }
     void trend_init() { cd::trend_init(&sc); }
     void trend_pass(bool fused) {

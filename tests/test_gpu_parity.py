@@ -704,3 +704,85 @@ def test_c_abi_without_torch_arrays(ctx, oracle):
     assert np.array_equal(q, oracle.bh_adjust(p))
     assert L.chicdiff_hip_free(h, dp) == 0 and L.chicdiff_hip_free(h, dq) == 0
     assert L.chicdiff_hip_memcpy_h2d(h, None, p.ctypes.data, 8) != 0  # NULL device pointer: an error, not a crash
+
+
+def test_direct_rccl_single_rank_matches_hook(ctx):
+    """The library's own RCCL communicator (dlopen'ed librccl, ncclAllReduce issued from C++) against the
+    torch.distributed hook: same sharded protocol, same kernels, so identical bits.  World size 1 is what one
+    GPU allows; it still goes through ncclCommInitRank / ncclAllReduce."""
+    import socket
+    import torch.distributed as dist
+    from chicdiff_amd import hip
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        created = True
+    try:
+        d = synth.make(40000, 8)
+        c2 = hip.HipContext(0)
+        dk, dn = c2.to_device(d["counts"], np.int32), c2.to_device(d["nf"], np.float64)
+        c2.set_process_group()
+        a, sa = c2.nbglm_fit(dk, dn, d["group"])
+        a = {k: v.cpu().numpy().copy() for k, v in a.items()}
+        c2.init_rccl()
+        b, sb = c2.nbglm_fit(dk, dn, d["group"])
+        for k in a:
+            assert np.array_equal(a[k], b[k].cpu().numpy(), equal_nan=True), k
+        assert np.array_equal(sa["trendCoef"], sb["trendCoef"])
+        sf_a = c2.size_factors(dk)
+        assert np.all(np.isfinite(sf_a))
+        c2.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def _rccl_refusal_worker(rank, port, q):
+    import os
+    import torch.distributed as dist
+    from chicdiff_amd import hip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        c = hip.HipContext(0)
+        try:
+            c.init_rccl()
+            q.put((rank, "initialised"))
+        except hip.ChicdiffHipError as e:
+            q.put((rank, "raised " + str(e)))
+        c.set_process_group(memory="device_via_host")  # what bench.py falls back to (there: the nccl hook)
+        d = synth.make(2000, 4)
+        lo, hi = (0, 1000) if rank == 0 else (1000, 2000)
+        _, sc = c.nbglm_fit(c.to_device(d["counts"][lo:hi], np.int32), c.to_device(d["nf"][lo:hi], np.float64), d["group"])
+        q.put((rank, tuple(sc["trendCoef"])))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_rccl_failure_is_symmetric_and_falls_back():
+    """Two ranks on this box's one GPU: the unique id travels, the bootstrap connects, and RCCL refuses the
+    duplicate device.  init_rccl must then raise on BOTH ranks (a one-sided fallback would deadlock the next
+    collective) and the hook path must still work."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rccl_refusal_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(4)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    first = {r: m for r, m in got if isinstance(m, str)}
+    assert len(first) == 2 and all(m.startswith("raised") and "every rank" in m for m in first.values()), first
+    trends = [m for _, m in got if not isinstance(m, str)]
+    assert len(trends) == 2 and trends[0] == trends[1]

@@ -22,4 +22,6 @@ bench("no hook")
 ctx.set_process_group()
 bench("torch hook (1-rank RCCL)")
 print("collectives per step", ctx._hook.calls / 23, "doubles per step", ctx._hook.doubles / 23)
+ctx.init_rccl()
+bench("direct RCCL (1-rank communicator owned by the library)")
 dist.destroy_process_group()
