@@ -136,7 +136,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("CHICDIFF_BENCH_FORCE_DIST") == "1"  # rehearse the N > 1 code path with a 1-rank group
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -145,7 +146,7 @@ def main():
     d = synth.make(n, S, start=rank * n)
     ctx = hip.HipContext(local_rank)
     collectives = "none (single rank)"
-    if world > 1:
+    if dist is not None:
         try:  # the library's own RCCL communicator: ncclAllReduce issued from C++ on the fit's stream
             if os.environ.get("CHICDIFF_BENCH_COLLECTIVES") == "torch":
                 raise RuntimeError("CHICDIFF_BENCH_COLLECTIVES=torch")
