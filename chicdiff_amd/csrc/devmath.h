@@ -13,6 +13,16 @@
 
 namespace cd {
 
+// d = a*b + c as the three-address v_fma_f64.  For a Horner step whose addend is a loop-invariant constant held
+// in a VGPR the compiler emits v_mov_b64 (copy the constant) + v_fmac_f64 — two issue slots; in the line-search
+// kernels those copies were 17 % of the per-sample instructions.  (Scalar registers, where such constants
+// would cost nothing, are exhausted there.)  Plain asm, no side effects: still CSE'd and scheduled.
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // 1/x for normal, well-scaled x (no denormal / overflow handling): v_rcp_f64 + two Newton steps,
 // ~5 instructions against ~12 for the IEEE division expansion.  < 1 ulp.
 __device__ __forceinline__ double rcp(double x) {
@@ -73,9 +83,9 @@ __device__ __forceinline__ double tlog(double x, const LogEntry *tab) {
     const double r2 = r * r;
     // log1p(r) = r - r^2/2 + ... + r^9/9, Estrin-style to shorten the dependency chain
     const double p01 = fma(r, -0.5, 1.0);
-    const double p23 = fma(r, -0.25, 1.0 / 3.0);
-    const double p45 = fma(r, -1.0 / 6.0, 0.2);
-    const double p67 = fma(r, -0.125, 1.0 / 7.0);
+    const double p23 = fma3(r, -0.25, 1.0 / 3.0);
+    const double p45 = fma3(r, -1.0 / 6.0, 0.2);
+    const double p67 = fma3(r, -0.125, 1.0 / 7.0);
     double q = fma(r2, 1.0 / 9.0, p67);
     q = fma(r2, q, p45);
     q = fma(r2, q, p23);
@@ -98,19 +108,19 @@ __device__ __forceinline__ double flog1p_from(double u, double t, double rt) {
 //   digamma(z) = log z - 1/(2z) - dg_tail(1/z^2)
 __device__ __forceinline__ void stirling(double z, double lz, double zi, double &lg, double &dg) {
     const double z2 = zi * zi;
-    double s = fma(z2, 1.0 / 156.0, -691.0 / 360360.0);
-    s = fma(z2, s, 1.0 / 1188.0);
-    s = fma(z2, s, -1.0 / 1680.0);
-    s = fma(z2, s, 1.0 / 1260.0);
-    s = fma(z2, s, -1.0 / 360.0);
-    s = fma(z2, s, 1.0 / 12.0);
+    double s = fma3(z2, 1.0 / 156.0, -691.0 / 360360.0);
+    s = fma3(z2, s, 1.0 / 1188.0);
+    s = fma3(z2, s, -1.0 / 1680.0);
+    s = fma3(z2, s, 1.0 / 1260.0);
+    s = fma3(z2, s, -1.0 / 360.0);
+    s = fma3(z2, s, 1.0 / 12.0);
     lg = fma(z - 0.5, lz, -z) + 0.91893853320467274178 + s * zi;
-    double t = fma(z2, 1.0 / 12.0, -691.0 / 32760.0);
-    t = fma(z2, t, 1.0 / 132.0);
-    t = fma(z2, t, -1.0 / 240.0);
-    t = fma(z2, t, 1.0 / 252.0);
-    t = fma(z2, t, -1.0 / 120.0);
-    t = fma(z2, t, 1.0 / 12.0);
+    double t = fma3(z2, 1.0 / 12.0, -691.0 / 32760.0);
+    t = fma3(z2, t, 1.0 / 132.0);
+    t = fma3(z2, t, -1.0 / 240.0);
+    t = fma3(z2, t, 1.0 / 252.0);
+    t = fma3(z2, t, -1.0 / 120.0);
+    t = fma3(z2, t, 1.0 / 12.0);
     dg = fma(-0.5, zi, lz) - t * z2;
 }
 

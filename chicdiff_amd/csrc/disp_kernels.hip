@@ -262,7 +262,14 @@ __device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double n
     return v;
 }
 __device__ __forceinline__ void accumulate(Acc &acc, const SampleVals &v, bool g) {
-    if (g) { acc.wB += v.wj; acc.dB = fma(-v.wj, v.wj, acc.dB); } else { acc.wA += v.wj; acc.dA = fma(-v.wj, v.wj, acc.dA); }
+    // the sample's group is wave-uniform: multiply by an exact 1.0 / 0.0 (scalar operands) instead of selecting
+    // registers — x*1 + s and x*0 + s round exactly like s + x and s, at 6 instructions instead of 14
+    const double gB = g ? 1.0 : 0.0, gA = g ? 0.0 : 1.0;
+    const double tA = v.wj * gA, tB = v.wj * gB;
+    acc.wA += tA;
+    acc.wB += tB;
+    acc.dA = fma(-tA, v.wj, acc.dA);
+    acc.dB = fma(-tB, v.wj, acc.dB);
     acc.pe += v.pe;
     acc.pm *= v.pm;
     acc.ll += v.tll;

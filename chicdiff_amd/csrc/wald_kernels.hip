@@ -154,7 +154,12 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
                 const double t1 = 1.0 + ma;
                 const double rt = rcp(t1);
                 const double wj = mu * rt;
-                if (g) { wB += wj; uB = fma(y, rt, uB); } else { wA += wj; uA = fma(y, rt, uA); }
+                const double gB = g ? 1.0 : 0.0, gA = g ? 0.0 : 1.0;  // wave-uniform: exact 1/0 factors instead of register selects
+                const double yr = y * rt;
+                wA = fma(wj, gA, wA);
+                wB = fma(wj, gB, wB);
+                uA = fma(yr, gA, uA);
+                uB = fma(yr, gB, uB);
                 // -log dnbinom's mu-dependent part: (size+y) log1p(alpha mu) - y log(alpha mu)
                 Dl = fma(size + y, tlog1p_from(ma, t1, rt, s_logtab), Dl);
                 if (floored) {  // eta_j = log(minmu) - log(nf_j) instead of the group's eta
