@@ -298,7 +298,8 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     const size_t partials = align256(sizeof(double) * ((size_t)kRedBlocks * 72 + 128));
     const size_t hist = align256(sizeof(double) * (size_t)kMaxS * 2 * kSelBins);
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
-    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + hist + align256(sizeof(FitScalars)) + 256 + nfbytes;
+    const size_t selcnt = align256(sizeof(double) * (size_t)kSelMaxWorld * kMaxS * 2);
+    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + 2 * hist + selcnt + align256(sizeof(FitScalars)) + 256 + nfbytes;
     hipError_t e = hipMalloc(&c->ws, total);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "workspace of %zu bytes: %s", total, hipGetErrorString(e));
     c->ws_bytes = total;
@@ -312,6 +313,8 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter); takeI(w.optimConv);
     w.partials = (double *)p; p += partials;
     w.hist = (double *)p; p += hist;
+    w.hist_local = (double *)p; p += hist;
+    w.selcnt = (double *)p; p += selcnt;
     w.sc = (FitScalars *)p; p += align256(sizeof(FitScalars));
     w.queue = (unsigned long long *)p; p += 256;
     c->d_nf_tmp = (double *)p;
@@ -387,6 +390,18 @@ struct HipBackend {
         return true;
     }
     void sel_finish(const SelSpec &) { launch_sel_finish(sa, c->w, c->stream); }
+    // sharded shortcut
+    int world_size() const { return c->world; }
+    bool sel_can_gather() const { return c->world <= kSelMaxWorld && !getenv("CHICDIFF_SELECT_SIXROUNDS"); }
+    double *sel_counts() { return c->w.selcnt; }
+    void sel_keep_local_hist(const SelSpec &) { launch_sel_keep_local(sa, c->w, c->stream); }
+    void sel_gather_counts(const SelSpec &) { launch_sel_gather_counts(sa, c->w, c->world, c->rank, c->stream); }
+    void sel_gather_place(const SelSpec &) {
+        Scope t(c, "select_gather");
+        sa.shift = 40;
+        launch_sel_gather_place(sa, c->w, c->world, c->rank, c->stream);
+    }
+    void sel_gather_finish(const SelSpec &) { launch_sel_gather_finish(sa, c->w, c->world, c->rank, c->stream); }
 };
 
 // exact medians by radix select; results land in w.sc (see sel_finish_kernel)

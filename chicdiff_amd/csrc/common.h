@@ -24,6 +24,8 @@ struct FitWork {
     int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter, *optimConv;
     double *partials;             // kRedBlocks x 72 doubles
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
+    double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut
+    double *selcnt;               // kSelMaxWorld x kMaxS*2 doubles: per-rank candidate counts
     unsigned long long *queue;    // work-queue heads
     FitScalars *sc;
 };
@@ -69,6 +71,11 @@ void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st);     // digit histogr
 void launch_sel_step(SelArgs a, FitWork w, hipStream_t st);     // pick bins, extend prefixes
 void launch_sel_shortcut(SelArgs a, FitWork w, hipStream_t st); // single rank: gather the candidates left after two rounds, finish by sorting
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st);   // prefixes -> values; median into sc
+// sharded shortcut (fit_state.h): keep the local histogram, own count row, place candidates, sort + pick
+void launch_sel_keep_local(SelArgs a, FitWork w, hipStream_t st);
+void launch_sel_gather_counts(SelArgs a, FitWork w, int world, int rank, hipStream_t st);
+void launch_sel_gather_place(SelArgs a, FitWork w, int world, int rank, hipStream_t st);
+void launch_sel_gather_finish(SelArgs a, FitWork w, int world, int rank, hipStream_t st);
 
 void launch_gather_sf(FitWork w, int S, double *d_sf, hipStream_t st);  // select results -> sf[S]
 void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, hipStream_t st);  // keys of the size-factor medians

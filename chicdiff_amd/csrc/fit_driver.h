@@ -14,7 +14,12 @@
 //   void sel_hist(const SelSpec&, int shift);   // digit histograms for the live prefixes (first round: all keys)
 //   void sel_step(const SelSpec&, int shift);   // first round also derives the populations and ranks
 //   void sel_finish(const SelSpec&);
-//   bool sel_shortcut(const SelSpec&);          // optional: finish after the second round; true = rounds 3-6 not needed
+//   bool sel_shortcut(const SelSpec&);          // single rank, optional: finish after the second round; true = done
+//   bool sel_can_gather();  double *sel_counts(); int rank();   // sharded shortcut (fit_state.h): per-rank count rows,
+//   void sel_keep_local_hist(const SelSpec&);   //   this rank's round-2 histogram kept aside before the all-reduce,
+//   void sel_gather_counts(const SelSpec&);     //   own row of the count buffer,
+//   void sel_gather_place(const SelSpec&);      //   own candidates at their offset in the zeroed hist() buffer,
+//   void sel_gather_finish(const SelSpec&);     //   sort + pick; sets sel_fast_done when every list fitted
 #pragma once
 #include "fit_state.h"
 
@@ -52,10 +57,20 @@ template <class B>
 int drive_select(B &be, const SelSpec &a) {
     // round 0 doubles as the population count: the sum of its (all-reduced) histogram
     for (int r = 0; r < 6; r++) {
+        const bool gather = r == 1 && be.world() > 1 && be.sel_can_gather();
         be.sel_hist(a, kSelShifts[r]);
+        if (gather) be.sel_keep_local_hist(a);
         if (be.allreduce(be.hist(), (int64_t)a.ncol * 2 * kSelBins)) return -1;
         be.sel_step(a, kSelShifts[r]);
-        if (r == 1 && be.sel_shortcut(a)) break;  // single-rank HIP backend: finishes from the few candidates left
+        if (r == 1 && be.world() <= 1 && be.sel_shortcut(a)) break;  // single-rank HIP backend: finishes from the few candidates left
+        if (gather) {  // 2 collectives + 1 pass instead of 4 + 4; falls through to the remaining rounds if a list overflows
+            be.sel_gather_counts(a);
+            if (be.allreduce(be.sel_counts(), (int64_t)be.world_size() * 2 * a.ncol)) return -1;
+            be.sel_gather_place(a);
+            if (be.allreduce(be.hist(), (int64_t)a.ncol * 2 * kSelCap)) return -1;
+            be.sel_gather_finish(a);
+            if (be.sync_scalars()->sel_fast_done) break;
+        }
     }
     be.sel_finish(a);
     return 0;

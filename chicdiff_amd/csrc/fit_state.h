@@ -194,6 +194,34 @@ static const int kSelShifts[6] = {52, 40, 28, 16, 4, 0};  // 5 x 12 bits + 4 bit
 CD_HD bool sel_first_round(int shift) { return shift == 52; }
 CD_HD int sel_bits(int shift) { return shift == 0 ? 4 : kSelBits; }
 
+// ---- gathering the candidates after two rounds (sharded shortcut) ------------------------------------
+// After two 12-bit rounds only the keys sharing 24 bits with a median are left — a few hundred among millions.
+// Sharded, every rank knows how many of them it holds (its own round-2 histogram at the chosen digit), so
+// instead of four more histogram rounds: one all-reduce of the per-rank counts (each rank fills its own row),
+// every rank writes its candidates at its offset into a zeroed buffer, one all-reduce (a sum of disjoint
+// entries with zeros = a gather), and every rank sorts the same list.
+constexpr int kSelCap = 4096;      // candidates per (column, slot): what the histogram buffer holds
+constexpr int kSelMaxWorld = 64;   // rows of the count buffer
+// this rank's candidates of (col, slot): the entry of its own round-2 histogram at the digit the (global) step chose
+CD_HD double sel_local_count(const FitScalars *sc, const double *local_hist, int col, int slot) {
+    const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
+    if (slot == 1 && p0 == p1) return 0.0;  // the upper middle shares the lower one's candidates
+    const uint64_t p = slot ? p1 : p0;
+    const int hslot = (slot == 1 && (p0 >> 52) != (p1 >> 52)) ? 1 : 0;  // which round-2 histogram counted them
+    return local_hist[((size_t)col * 2 + hslot) * kSelBins + (size_t)((p >> 40) & (kSelBins - 1))];
+}
+// offset of `rank`'s candidates of entry q (= 2*col + slot) and the total over ranks, from the all-reduced counts
+CD_HD void sel_gather_layout(const double *cnt, int world, int rank, int nq, int q, double *base, double *total) {
+    double b = 0, t = 0;
+    for (int r = 0; r < world; r++) {
+        const double c = cnt[(size_t)r * nq + q];
+        if (r < rank) b += c;
+        t += c;
+    }
+    *base = b;
+    *total = t;
+}
+
 // ---- prior variance (estimateDispersionsPriorVar, closed-form branch) ---------------------------
 CD_HD double trigamma_pos(double x) {
     double r = 0.0;

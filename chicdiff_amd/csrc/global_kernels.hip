@@ -329,7 +329,6 @@ __global__ __launch_bounds__(256) void sel_step_kernel(SelArgs a, FitWork w, int
 // ---- single-rank shortcut: after two rounds (24 of 64 key bits fixed) only a handful of keys share
 // the live prefixes; gather them and finish in one block per column instead of four more passes over
 // all the data.  Exact and order-independent (a sort), so results equal the six-round path bit for bit.
-constexpr int kSelCap = 4096;  // candidates per (column, slot): the histogram buffer holds exactly that many
 __global__ __launch_bounds__(256) void sel_compact_kernel(SelArgs a, FitWork w) {
     const int col = blockIdx.y;
     FitScalars *sc = w.sc;
@@ -435,6 +434,87 @@ __global__ __launch_bounds__(1024) void sel_tail_kernel(SelArgs a, FitWork w) {
     if (threadIdx.x < 2) sc->sel_prefix[2 * col + threadIdx.x] = s_pre[threadIdx.x];
 }
 
+// ---- sharded shortcut (protocol and layout: fit_state.h) -------------------------------------------------------
+__global__ void sel_gcount_kernel(SelArgs a, FitWork w, int world, int rank) {
+    const int nq = 2 * a.ncol;
+    for (int k = threadIdx.x; k < world * nq; k += blockDim.x) {
+        const int r = k / nq, q = k - r * nq;
+        w.selcnt[k] = r == rank ? sel_local_count(w.sc, w.hist_local, q >> 1, q & 1) : 0.0;
+    }
+    if (threadIdx.x < (unsigned)nq) w.sc->sel_cnt[threadIdx.x] = 0;  // write positions of the place pass
+    if (threadIdx.x == 0) w.sc->sel_fast_done = 0;
+}
+__device__ __forceinline__ bool sel_gather_fits(const double *cnt, int world, int nq) {
+    for (int q = 0; q < nq; q++) {
+        double t = 0;
+        for (int r = 0; r < world; r++) t += cnt[(size_t)r * nq + q];
+        if (t > (double)kSelCap) return false;
+    }
+    return true;
+}
+// this rank's candidates, as values, at its offset of the (zeroed) hist buffer; the sum-all-reduce then gathers
+__global__ __launch_bounds__(256) void sel_gplace_kernel(SelArgs a, FitWork w, int world, int rank) {
+    const int col = blockIdx.y, nq = 2 * a.ncol;
+    FitScalars *sc = w.sc;
+    if (!sel_gather_fits(w.selcnt, world, nq)) return;  // same verdict on every rank: the histogram rounds go on
+    const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
+    const bool same = p0 == p1;
+    double base[2], tot;
+    sel_gather_layout(w.selcnt, world, rank, nq, 2 * col, &base[0], &tot);
+    sel_gather_layout(w.selcnt, world, rank, nq, 2 * col + 1, &base[1], &tot);
+    uint64_t key;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        if (!sel_key(a, sc, col, i, key)) continue;
+        int slot = -1;
+        if (sel_match(key, p0, 40)) slot = 0;
+        else if (!same && sel_match(key, p1, 40)) slot = 1;
+        if (slot < 0) continue;
+        const unsigned pos = atomicAdd(&sc->sel_cnt[2 * col + slot], 1u);
+        w.hist[((size_t)2 * col + slot) * kSelCap + (size_t)base[slot] + pos] = value_of(key);
+    }
+}
+__global__ __launch_bounds__(256) void sel_gfinish_kernel(SelArgs a, FitWork w, int world, int rank) {
+    __shared__ uint64_t s_k[kSelCap];
+    FitScalars *sc = w.sc;
+    const int nq = 2 * a.ncol;
+    if (!sel_gather_fits(w.selcnt, world, nq)) return;
+    const int col = blockIdx.x;
+    const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
+    uint64_t result[2] = {p0, p1};
+    for (int slot = 0; slot < 2; slot++) {
+        const int hslot = (slot == 1 && p0 != p1) ? 1 : 0;
+        double b, t;
+        sel_gather_layout(w.selcnt, world, rank, nq, 2 * col + hslot, &b, &t);
+        const int m = (int)t;
+        if (m == 0) continue;
+        int len = 64;
+        while (len < m) len <<= 1;
+        __syncthreads();
+        for (int e = threadIdx.x; e < len; e += 256) s_k[e] = e < m ? key_of(w.hist[((size_t)2 * col + hslot) * kSelCap + e]) : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= len; k <<= 1)  // bitonic sort, ascending
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int e = threadIdx.x; e < len; e += 256) {
+                    const int p = e ^ j;
+                    if (p > e) {
+                        const uint64_t x = s_k[e], y = s_k[p];
+                        const bool up = (e & k) == 0;
+                        if ((x > y) == up) { s_k[e] = y; s_k[p] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        const int r = (int)sc->sel_rank[2 * col + slot];
+        result[slot] = s_k[r < m ? r : m - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sc->sel_prefix[2 * col] = result[0];
+        sc->sel_prefix[2 * col + 1] = result[1];
+        if (col == 0) sc->sel_fast_done = 1;
+    }
+}
+
 __global__ void sel_finish_kernel(SelArgs a, FitWork w) {
     const int c = threadIdx.x;
     if (c >= a.ncol) return;
@@ -474,6 +554,19 @@ void launch_sel_shortcut(SelArgs a, FitWork w, hipStream_t st) {
     sel_tail_kernel<<<a.ncol, 1024, 0, st>>>(a, w);
 }
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st) { sel_finish_kernel<<<1, 64, 0, st>>>(a, w); }
+void launch_sel_keep_local(SelArgs a, FitWork w, hipStream_t st) {
+    (void)hipMemcpyAsync(w.hist_local, w.hist, sizeof(double) * (size_t)a.ncol * 2 * kSelBins, hipMemcpyDeviceToDevice, st);
+}
+void launch_sel_gather_counts(SelArgs a, FitWork w, int world, int rank, hipStream_t st) {
+    sel_gcount_kernel<<<1, 256, 0, st>>>(a, w, world, rank);
+}
+void launch_sel_gather_place(SelArgs a, FitWork w, int world, int rank, hipStream_t st) {
+    (void)hipMemsetAsync(w.hist, 0, sizeof(double) * (size_t)a.ncol * 2 * kSelCap, st);
+    sel_gplace_kernel<<<dim3(sel_blocks(a.n), a.ncol), 256, 0, st>>>(a, w, world, rank);
+}
+void launch_sel_gather_finish(SelArgs a, FitWork w, int world, int rank, hipStream_t st) {
+    sel_gfinish_kernel<<<a.ncol, 256, 0, st>>>(a, w, world, rank);
+}
 
 // ------------------------------------------------------------------------------------------
 __global__ void gather_sf_kernel(FitWork w, int S, double *sf) {

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../chicdiff_amd/csrc/fit_driver.h"
@@ -19,7 +20,7 @@ using namespace cd;
 typedef int (*allreduce_fn)(void *user, void *buf, int64_t count);
 
 struct CpuBackend {
-    int world_ = 1;
+    int world_ = 1, rank_ = 0;
     allreduce_fn cb = nullptr;
     void *user = nullptr;
     // trend inputs (row shard)
@@ -33,10 +34,12 @@ struct CpuBackend {
     std::vector<double> lgm;
     int S = 0;
     FitScalars sc;
-    std::vector<double> sums_, hist_;
-    CpuBackend() : sums_(128, 0.0), hist_((size_t)kMaxS * 2 * kSelBins, 0.0) { memset(&sc, 0, sizeof sc); }
+    std::vector<double> sums_, hist_, hist_local_, cnt_;
+    CpuBackend() : sums_(128, 0.0), hist_((size_t)kMaxS * 2 * kSelBins, 0.0), hist_local_((size_t)kMaxS * 2 * kSelBins, 0.0),
+                   cnt_((size_t)kSelMaxWorld * 2 * kMaxS, 0.0) { memset(&sc, 0, sizeof sc); }
 
     int world() const { return world_; }
+    int world_size() const { return world_; }
     int allreduce(double *buf, int64_t cnt) { return world_ > 1 ? cb(user, buf, cnt) : 0; }
     double *sums() { return sums_.data(); }
     int64_t sums_len() const { return cd::kTrendSums; }
@@ -103,7 +106,68 @@ struct CpuBackend {
             }
         }
     }
-    bool sel_shortcut(const SelSpec &) { return false; }  // the sharded path always runs all six rounds
+    bool sel_shortcut(const SelSpec &) { return false; }
+    // sharded shortcut (fit_state.h), plain-loop twin of the HIP kernels
+    bool sel_can_gather() const { return world_ <= kSelMaxWorld && !no_gather; }
+    bool no_gather = false;
+    double *sel_counts() { return cnt_.data(); }
+    void sel_keep_local_hist(const SelSpec &a) { std::copy(hist_.begin(), hist_.begin() + (size_t)a.ncol * 2 * kSelBins, hist_local_.begin()); }
+    void sel_gather_counts(const SelSpec &a) {
+        const int nq = 2 * a.ncol;
+        std::fill(cnt_.begin(), cnt_.begin() + (size_t)world_ * nq, 0.0);
+        for (int q = 0; q < nq; q++) cnt_[(size_t)rank_ * nq + q] = sel_local_count(&sc, hist_local_.data(), q / 2, q % 2);
+    }
+    bool gather_fits(const SelSpec &a) const {
+        for (int q = 0; q < 2 * a.ncol; q++) {
+            double b, t;
+            sel_gather_layout(cnt_.data(), world_, rank_, 2 * a.ncol, q, &b, &t);
+            if (t > kSelCap) return false;
+        }
+        return true;
+    }
+    void sel_gather_place(const SelSpec &a) {
+        std::fill(hist_.begin(), hist_.begin() + (size_t)a.ncol * 2 * kSelCap, 0.0);
+        if (!gather_fits(a)) return;
+        uint64_t k;
+        for (int c = 0; c < a.ncol; c++) {
+            const uint64_t p0 = sc.sel_prefix[2 * c], p1 = sc.sel_prefix[2 * c + 1];
+            double pos[2], tot;
+            sel_gather_layout(cnt_.data(), world_, rank_, 2 * a.ncol, 2 * c, &pos[0], &tot);
+            sel_gather_layout(cnt_.data(), world_, rank_, 2 * a.ncol, 2 * c + 1, &pos[1], &tot);
+            for (int64_t i = 0; i < n; i++) {
+                if (!key(a, c, i, k)) continue;
+                int slot = -1;
+                if (sel_match(k, p0, 40)) slot = 0;
+                else if (p0 != p1 && sel_match(k, p1, 40)) slot = 1;
+                if (slot < 0) continue;
+                hist_[((size_t)2 * c + slot) * kSelCap + (size_t)pos[slot]] = value_of(k);
+                pos[slot] += 1;
+            }
+        }
+    }
+    void sel_gather_finish(const SelSpec &a) {
+        sc.sel_fast_done = 0;
+        if (!gather_fits(a)) return;
+        for (int c = 0; c < a.ncol; c++) {
+            const uint64_t p0 = sc.sel_prefix[2 * c], p1 = sc.sel_prefix[2 * c + 1];
+            uint64_t res[2] = {p0, p1};
+            for (int slot = 0; slot < 2; slot++) {
+                const int hs = (slot == 1 && p0 != p1) ? 1 : 0;
+                double b, t;
+                sel_gather_layout(cnt_.data(), world_, rank_, 2 * a.ncol, 2 * c + hs, &b, &t);
+                const int m = (int)t;
+                if (m == 0) continue;
+                std::vector<uint64_t> ks((size_t)m);
+                for (int e = 0; e < m; e++) ks[(size_t)e] = key_of(hist_[((size_t)2 * c + hs) * kSelCap + (size_t)e]);
+                std::sort(ks.begin(), ks.end());
+                const int r = (int)sc.sel_rank[2 * c + slot];
+                res[slot] = ks[(size_t)(r < m ? r : m - 1)];
+            }
+            sc.sel_prefix[2 * c] = res[0];
+            sc.sel_prefix[2 * c + 1] = res[1];
+        }
+        sc.sel_fast_done = 1;
+    }
     void sel_finish(const SelSpec &a) {
         for (int c = 0; c < a.ncol; c++) {
             const double med = sel_median(&sc, c);
@@ -118,9 +182,12 @@ extern "C" {
 
 // trend + MAD + prior variance over a row shard.  out: c0, c1, varLogDispEsts, dispPriorVar, outer_it, failed, med, mad
 int harness_trend_mad(const double *baseMean, const double *dispGene, const int32_t *allZero, int64_t n, double minDisp,
-                      int32_t S, int32_t p, double prior_in, int32_t world, allreduce_fn cb, void *user, double *out) {
+                      int32_t S, int32_t p, double prior_in, int32_t world, int32_t rank, int32_t six_rounds, allreduce_fn cb,
+                      void *user, double *out) {
     CpuBackend be;
     be.world_ = world;
+    be.rank_ = rank;
+    be.no_gather = six_rounds != 0;
     be.cb = cb;
     be.user = user;
     be.bm = baseMean;
@@ -154,9 +221,12 @@ int harness_trend_mad(const double *baseMean, const double *dispGene, const int3
 }
 
 // median-of-ratios size factors over a row shard (counts column-major n x S)
-int harness_size_factors(const int32_t *counts, int64_t n, int32_t S, int32_t world, allreduce_fn cb, void *user, double *sf) {
+int harness_size_factors(const int32_t *counts, int64_t n, int32_t S, int32_t world, int32_t rank, int32_t six_rounds,
+                         allreduce_fn cb, void *user, double *sf) {
     CpuBackend be;
     be.world_ = world;
+    be.rank_ = rank;
+    be.no_gather = six_rounds != 0;
     be.cb = cb;
     be.user = user;
     be.n = n;

@@ -25,9 +25,9 @@ def build_harness():
     from chicdiff_amd.dist import ALLREDUCE_FN
     L = C.CDLL(HARNESS_SO)
     pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
-    L.harness_trend_mad.argtypes = [pd, pd, pi, C.c_int64, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_int32,
-                                    ALLREDUCE_FN, C.c_void_p, pd]
-    L.harness_size_factors.argtypes = [pi, C.c_int64, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p, pd]
+    L.harness_trend_mad.argtypes = [pd, pd, pi, C.c_int64, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                    C.c_int32, ALLREDUCE_FN, C.c_void_p, pd]
+    L.harness_size_factors.argtypes = [pi, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p, pd]
     return L
 
 
@@ -52,12 +52,22 @@ def _worker(rank, world, port, n, S, q):
         out = np.zeros(8)
         pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
         rc = L.harness_trend_mad(bm.ctypes.data_as(pd), dg.ctypes.data_as(pd), az.ctypes.data_as(pi), hi - lo, 1e-8, S, 2,
-                                 float("nan"), world, hook.fn, None, out.ctypes.data_as(pd))
+                                 float("nan"), world, rank, 0, hook.fn, None, out.ctypes.data_as(pd))
         assert rc == 0 and hook.error is None, (rc, hook.error)
         k = np.asfortranarray(d["counts"][lo:hi].astype(np.int32))
         sf = np.zeros(S)
-        rc = L.harness_size_factors(k.ctypes.data_as(pi), hi - lo, S, world, hook.fn, None, sf.ctypes.data_as(pd))
+        calls0 = hook.calls
+        rc = L.harness_size_factors(k.ctypes.data_as(pi), hi - lo, S, world, rank, 0, hook.fn, None, sf.ctypes.data_as(pd))
         assert rc == 0 and hook.error is None, (rc, hook.error)
+        assert hook.calls - calls0 == 4  # two histogram rounds, the count rows, the gathered candidates
+        # the same medians through all six histogram rounds (what an overflowing candidate list falls back to)
+        out6, sf6 = np.zeros(8), np.zeros(S)
+        assert L.harness_trend_mad(bm.ctypes.data_as(pd), dg.ctypes.data_as(pd), az.ctypes.data_as(pi), hi - lo, 1e-8, S, 2,
+                                   float("nan"), world, rank, 1, hook.fn, None, out6.ctypes.data_as(pd)) == 0
+        calls0 = hook.calls
+        assert L.harness_size_factors(k.ctypes.data_as(pi), hi - lo, S, world, rank, 1, hook.fn, None, sf6.ctypes.data_as(pd)) == 0
+        assert hook.calls - calls0 == 6 and hook.error is None
+        assert np.array_equal(out6, out) and np.array_equal(sf6, sf)
         q.put((rank, out.tolist(), sf.tolist(), hook.calls, ref["trendCoef"].tolist(), ref["varLogDispEsts"],
                ref["dispPriorVar"], ref["trendOuterIter"], oracle.size_factors(d["counts"]).tolist()))
     finally:
@@ -107,11 +117,11 @@ def test_single_rank_harness_matches_oracle():
     az = np.ascontiguousarray(ref["allZero"], dtype=np.int32)
     null_cb = C.cast(None, ALLREDUCE_FN)
     rc = L.harness_trend_mad(bm.ctypes.data_as(pd), dg.ctypes.data_as(pd), az.ctypes.data_as(pi), len(bm), 1e-8, 6, 2,
-                             float("nan"), 1, null_cb, None, out.ctypes.data_as(pd))
+                             float("nan"), 1, 0, 0, null_cb, None, out.ctypes.data_as(pd))
     assert rc == 0
     assert np.allclose(out[:2], ref["trendCoef"], rtol=1e-10)
     assert np.isclose(out[2], ref["varLogDispEsts"], rtol=1e-10) and np.isclose(out[3], ref["dispPriorVar"], rtol=1e-10)
     k = np.asfortranarray(d["counts"].astype(np.int32))
     sf = np.zeros(6)
-    assert L.harness_size_factors(k.ctypes.data_as(pi), len(k), 6, 1, null_cb, None, sf.ctypes.data_as(pd)) == 0
+    assert L.harness_size_factors(k.ctypes.data_as(pi), len(k), 6, 1, 0, 0, null_cb, None, sf.ctypes.data_as(pd)) == 0
     assert np.allclose(sf, oracle.size_factors(d["counts"]), rtol=1e-13)
