@@ -950,3 +950,46 @@ extern "C" int chicdiff_hip_memcpy_d2h(chicdiff_hip_ctx *c, void *h_dst, const v
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CHICDIFF_OK;
 }
+
+// ---- a9: results() on device -----------------------------------------------------------------------------------
+extern "C" int chicdiff_hip_cooks_filter_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S, const int32_t *group,
+                                             const double *d_maxCooks, const int32_t *d_cooksArgmax, double cutoff, double *d_pvalue,
+                                             int64_t *n_outliers_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_counts || !d_maxCooks || !d_cooksArgmax || !d_pvalue || !n_outliers_host) return fail(c, CHICDIFF_E_INVALID, "cooks_filter: NULL pointer");
+    FitDims d;
+    int rc = check_counts_group(c, n, S, group, d);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure_aux(c, 256))) return rc;
+    timing_reset(c);
+    {
+        Scope t(c, "cooks_filter");
+        launch_cooks_filter(d_counts, n, S, d.p, d_maxCooks, d_cooksArgmax, cutoff, d_pvalue, (unsigned long long *)c->aux, c->stream);
+    }
+    unsigned long long h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, c->aux, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    *n_outliers_host = (int64_t)h;
+    return CHICDIFF_OK;
+}
+
+extern "C" int chicdiff_hip_independent_filtering_dev(chicdiff_hip_ctx *c, const double *d_baseMean, const double *d_pvalue, int64_t n,
+                                                      double alpha, double *d_padj, chicdiff_results_info *info) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_baseMean || !d_pvalue || !d_padj || !info || n < 1 || n >= (1ll << 32) || !(alpha > 0 && alpha < 1))
+        return fail(c, CHICDIFF_E_INVALID, "independent_filtering: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_aux(c, if_workspace_bytes(n));
+    if (rc) return rc;
+    timing_reset(c);
+    {
+        Scope t(c, "independent_filtering");
+        if (run_independent_filtering(d_baseMean, d_pvalue, n, alpha, d_padj, c->aux, c->stream, info))
+            return fail(c, CHICDIFF_E_HIP, "independent_filtering: %s", hipGetErrorString(hipGetLastError()));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return CHICDIFF_OK;
+}

@@ -95,6 +95,11 @@ int launch_bh_adjust(const double *p, int64_t n, double *padj, char *ws, hipStre
 size_t ihw_workspace_bytes();
 void launch_ihw_apply(const double *avDist, const double *pvalue, int64_t n, const double *breaks, const double *weights,
                       int ng, int32_t *group, double *weight, double *wp, double *partials, hipStream_t st);
+void launch_cooks_filter(const int32_t *counts, int64_t n, int S, int p, const double *maxCooks, const int32_t *argmax,
+                         double cutoff, double *pvalue, unsigned long long *nout, hipStream_t st);
+size_t if_workspace_bytes(int64_t n);
+int run_independent_filtering(const double *d_bm, const double *d_p, int64_t n, double alpha, double *d_padj, char *ws, hipStream_t st,
+                              chicdiff_results_info *info);  // synchronises (three small read-backs)
 size_t ct_workspace_bytes(int64_t n);
 int launch_count_table(const int32_t *bait, const int32_t *oe, const int32_t *N, int64_t n, const uint8_t *keep, int32_t max_id,
                        int64_t *keys_out, int32_t *vals_out, char *ws, hipStream_t st);

@@ -6,7 +6,12 @@
 //          restriction map and to the bait's chromosome, as a CSR over regions.
 // HBM-bound integer/byte work plus one device sort; rocPRIM provides the sort and the scans (plain library
 // primitives), the rest is hand-written.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -55,7 +60,7 @@ size_t bh_workspace_bytes(int64_t n) {
     (void)rocprim::inclusive_scan(nullptr, scan_tmp, rocprim::make_reverse_iterator(d), rocprim::make_reverse_iterator(d),
                                   (size_t)n, rocprim::minimum<double>(), (hipStream_t)0);
     const size_t tmp = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
-    return 256 + ((size_t)n * (8 + 8 + 4 + 4 + 8 + 8) + 6 * 256) + tmp + 256;
+    return (256 + ((size_t)n * (8 + 8 + 4 + 4 + 8 + 8) + 6 * 256) + tmp + 511) / 256 * 256;  // a multiple of 256: callers append to it
 }
 
 // `ws` holds bh_workspace_bytes(n) bytes; everything is enqueued on `st`
@@ -179,7 +184,7 @@ size_t ct_workspace_bytes(int64_t n) {
     uint64_t *k = nullptr;
     int32_t *v = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, v, v, (size_t)n, 0, 64, (hipStream_t)0);
-    return 256 + ((size_t)n * 8 + 255) / 256 * 256 + tmp + 256;
+    return (256 + ((size_t)n * 8 + 255) / 256 * 256 + tmp + 511) / 256 * 256;
 }
 int launch_count_table(const int32_t *bait, const int32_t *oe, const int32_t *N, int64_t n, const uint8_t *keep, int32_t max_id,
                        int64_t *keys_out, int32_t *vals_out, char *ws, hipStream_t st) {
@@ -304,6 +309,344 @@ void launch_ru_fill(const int32_t *bait, const int32_t *oe, int64_t n, int s, co
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     ru_fill_kernel<<<blocks, 256, 0, st>>>(bait, oe, n, s, chr_of, maxfrag, region_ptr, ru_bait, ru_region, ru_oe);
+}
+
+}  // namespace cd
+
+// ================================================================================================================
+// a9 — DESeq2 results(): Cook's cutoff and independent filtering on device (chicdiff.R:1720-1741 call results()
+// with its defaults).  Host numpy needs ~5 s for 2 M rows (50 filtered BH passes); here the
+// 50 rejection counts come from ONE sort by p-value and a 50-wide prefix count.
+namespace cd {
+
+// p <- NA for Cook's outliers: maxCooks > cutoff, unless (two-group design) at least 3 counts of the row exceed the
+// count of the sample with the largest Cook's distance (then the outlier is a low count and the p-value stays)
+__global__ __launch_bounds__(256) void cooks_filter_kernel(const int32_t *__restrict__ counts, int64_t n, int S, int p,
+                                                           const double *__restrict__ maxCooks, const int32_t *__restrict__ argmax,
+                                                           double cutoff, double *pvalue, unsigned long long *nout) {
+    unsigned int mine = 0;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double mc = maxCooks[i];
+        if (!(mc > cutoff)) continue;  // NaN: not an outlier
+        bool outlier = true;
+        if (p == 2) {
+            const int a = argmax[i];
+            if (a >= 0 && a < S) {
+                const int32_t oc = counts[(int64_t)a * n + i];
+                int larger = 0;
+                for (int j = 0; j < S; j++) larger += counts[(int64_t)j * n + i] > oc ? 1 : 0;
+                if (larger >= 3) outlier = false;
+            }
+        }
+        if (outlier) {
+            pvalue[i] = NAN;
+            mine++;
+        }
+    }
+    if (mine) atomicAdd(nout, (unsigned long long)mine);
+}
+void launch_cooks_filter(const int32_t *counts, int64_t n, int S, int p, const double *maxCooks, const int32_t *argmax,
+                         double cutoff, double *pvalue, unsigned long long *nout, hipStream_t st) {
+    (void)hipMemsetAsync(nout, 0, 8, st);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    cooks_filter_kernel<<<blocks, 256, 0, st>>>(counts, n, S, p, maxCooks, argmax, cutoff, pvalue, nout);
+}
+
+constexpr int kIfN = 50;      // quantile cutoffs (DESeq2: theta <- seq(lower, upper, length = 50))
+constexpr int kIfBlock = 1024;
+
+__global__ __launch_bounds__(256) void if_keys_kernel(const double *__restrict__ bm, int64_t n, uint64_t *keys, unsigned long long *nzero) {
+    unsigned int mine = 0;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double x = bm[i];
+        keys[i] = x != x ? ~0ull : key_of(x);
+        mine += x == 0.0 ? 1u : 0u;
+    }
+    if (mine) atomicAdd(nzero, (unsigned long long)mine);
+}
+// order statistics lo/hi of the 50 quantiles (R quantile type 7 interpolates between them on the host)
+__global__ void if_gather_kernel(const uint64_t *__restrict__ sorted, const int64_t *__restrict__ idx, int m, double *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) out[k] = value_of(sorted[idx[k]]);
+}
+struct IfCuts { double c[kIfN]; };
+// T = number of cutoffs <= baseMean (cutoffs ascending): the row passes the filters 0 .. T-1
+__device__ __forceinline__ int if_T(double bm, const IfCuts &cu) {
+    int lo = 0, hi = kIfN;  // first cutoff > bm
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cu.c[mid] <= bm) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// pass 1 over the p-sorted rows: per block and filter, how many rows pass (and have a p-value)
+__global__ __launch_bounds__(kIfBlock) void if_count_kernel(const uint32_t *__restrict__ idx, const double *__restrict__ bm, int64_t n,
+                                                             const unsigned long long *nvalid, IfCuts cu, uint8_t *T, uint32_t *blockcnt,
+                                                             int nblocks) {
+    __shared__ unsigned int h[kIfN + 1];
+    if (threadIdx.x <= kIfN) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t k = (int64_t)blockIdx.x * kIfBlock + threadIdx.x;
+    int t = 0;
+    if (k < n && (unsigned long long)k < *nvalid) t = if_T(bm[idx[k]], cu);
+    if (k < n) T[k] = (uint8_t)t;
+    atomicAdd(&h[t], 1u);
+    __syncthreads();
+    if (threadIdx.x < kIfN) {  // rows with T > f pass filter f
+        unsigned int s = 0;
+        for (int b = threadIdx.x + 1; b <= kIfN; b++) s += h[b];
+        blockcnt[(size_t)threadIdx.x * nblocks + blockIdx.x] = s;
+    }
+}
+// exclusive scan over the blocks, one workgroup per filter; total[f] = rows passing filter f
+__global__ __launch_bounds__(1024) void if_scan_kernel(uint32_t *blockcnt, int nblocks, uint32_t *total) {
+    __shared__ unsigned int part[1024];
+    uint32_t *c = blockcnt + (size_t)blockIdx.x * nblocks;
+    const int per = (nblocks + 1023) / 1024, b0 = threadIdx.x * per;
+    unsigned int s = 0;
+    for (int b = b0; b < b0 + per && b < nblocks; b++) s += c[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned int run = part[threadIdx.x] - s;  // exclusive
+    for (int b = b0; b < b0 + per && b < nblocks; b++) {
+        const unsigned int v = c[b];
+        c[b] = run;
+        run += v;
+    }
+    if (threadIdx.x == 1023) total[blockIdx.x] = part[1023];
+}
+// pass 2: BH at level alpha rejects the hypotheses up to the largest filtered rank j with m/j * p_(j) < alpha
+// (DESeq2 counts padj < alpha): numRej[f] = that j
+__global__ __launch_bounds__(kIfBlock) void if_rej_kernel(const uint64_t *__restrict__ pkeys, const uint8_t *__restrict__ T, int64_t n,
+                                                           const uint32_t *__restrict__ blockoff, const uint32_t *__restrict__ total,
+                                                           int nblocks, double alpha, unsigned int *numRej) {
+    __shared__ unsigned int wsum[kIfBlock / 64];
+    __shared__ unsigned int best[kIfN];
+    const int64_t k = (int64_t)blockIdx.x * kIfBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = k < n ? T[k] : 0;
+    const double p = t > 0 ? value_of(pkeys[k]) : 0.0;
+    if (threadIdx.x < kIfN) best[threadIdx.x] = 0;
+    __syncthreads();
+    for (int f = 0; f < kIfN; f++) {
+        const bool pass = t > f;
+        const unsigned long long bal = __ballot(pass);
+        if (lane == 0) wsum[wave] = (unsigned int)__popcll(bal);
+        __syncthreads();
+        unsigned int before = 0;
+        for (int w2 = 0; w2 < wave; w2++) before += wsum[w2];
+        if (pass) {
+            const unsigned int rank = blockoff[(size_t)f * nblocks + blockIdx.x] + before + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull)) + 1u;
+            if ((double)total[f] / (double)rank * p < alpha) atomicMax(&best[f], rank);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < kIfN && best[threadIdx.x]) atomicMax(&numRej[threadIdx.x], best[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void if_mask_kernel(const double *__restrict__ bm, const double *__restrict__ p, int64_t n, double cutoff,
+                                                      double *out) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = bm[i] >= cutoff ? p[i] : NAN;
+}
+
+// Cleveland's LOWESS as in R stats::lowess / clowess.c (x ascending), host side: 50 points
+static void lowess_host(const double *x, const double *y, int n, double f, int nsteps, double delta, double *ys) {
+    std::vector<double> rw((size_t)n, 1.0), res((size_t)n, 0.0), w((size_t)n, 0.0);
+    if (n < 2) {
+        for (int i = 0; i < n; i++) ys[i] = y[i];
+        return;
+    }
+    int ns = (int)(f * n + 1e-7);
+    if (ns > n) ns = n;
+    if (ns < 2) ns = 2;
+    auto lowest = [&](double xs, int nleft, int nright, bool userw, double &out) -> bool {
+        const double range = x[n - 1] - x[0];
+        const double h = std::max(xs - x[nleft], x[nright] - xs), h9 = 0.999 * h, h1 = 0.001 * h;
+        double a = 0.0;
+        int j = nleft;
+        while (j < n) {
+            w[j] = 0.0;
+            const double r = fabs(x[j] - xs);
+            if (r <= h9) {
+                if (r <= h1) w[j] = 1.0;
+                else { const double q = r / h, c = 1.0 - q * q * q; w[j] = c * c * c; }
+                if (userw) w[j] *= rw[j];
+                a += w[j];
+            } else if (x[j] > xs) break;
+            j++;
+        }
+        const int nrt = j - 1;
+        if (a <= 0.0) return false;
+        for (j = nleft; j <= nrt; j++) w[j] /= a;
+        if (h > 0.0) {
+            a = 0.0;
+            for (j = nleft; j <= nrt; j++) a += w[j] * x[j];
+            double b = xs - a, c = 0.0;
+            for (j = nleft; j <= nrt; j++) c += w[j] * (x[j] - a) * (x[j] - a);
+            if (sqrt(c) > 0.001 * range) {
+                b /= c;
+                for (j = nleft; j <= nrt; j++) w[j] *= (b * (x[j] - a) + 1.0);
+            }
+        }
+        out = 0.0;
+        for (j = nleft; j <= nrt; j++) out += w[j] * y[j];
+        return true;
+    };
+    for (int it = 0; it <= nsteps; it++) {
+        int nleft = 0, nright = ns - 1, last = -1, i = 0;
+        for (;;) {
+            if (nright < n - 1) {
+                const double d1 = x[i] - x[nleft], d2 = x[nright + 1] - x[i];
+                if (d1 > d2) { nleft++; nright++; continue; }
+            }
+            double v;
+            ys[i] = lowest(x[i], nleft, nright, it > 0, v) ? v : y[i];
+            if (last < i - 1) {
+                const double denom = x[i] - x[last];
+                for (int j = last + 1; j < i; j++) {
+                    const double al = (x[j] - x[last]) / denom;
+                    ys[j] = al * ys[i] + (1.0 - al) * ys[last];
+                }
+            }
+            last = i;
+            const double cut = x[last] + delta;
+            for (i = last + 1; i < n; i++) {
+                if (x[i] > cut) break;
+                if (x[i] == x[last]) { ys[i] = ys[last]; last = i; }
+            }
+            i = std::max(last + 1, i - 1);
+            if (last >= n - 1) break;
+        }
+        for (int k = 0; k < n; k++) res[k] = y[k] - ys[k];
+        if (it >= nsteps) break;
+        double sc = 0.0;
+        for (int k = 0; k < n; k++) { rw[k] = fabs(res[k]); sc += rw[k]; }
+        sc /= n;
+        std::vector<double> srt(rw);
+        std::sort(srt.begin(), srt.end());
+        const int m1 = n / 2;
+        const double cmad = 3.0 * (srt[m1] + srt[n - m1 - 1]);
+        if (cmad < 1e-7 * sc) break;
+        const double c9 = 0.999 * cmad, c1 = 0.001 * cmad;
+        for (int k = 0; k < n; k++) {
+            const double r = fabs(res[k]);
+            if (r <= c1) rw[k] = 1.0;
+            else if (r <= c9) { const double q = r / cmad, c = 1.0 - q * q; rw[k] = c * c; }
+            else rw[k] = 0.0;
+        }
+    }
+}
+
+size_t if_workspace_bytes(int64_t n) {
+    const int nblocks = (int)((n + kIfBlock - 1) / kIfBlock);
+    size_t sort_tmp = 0;
+    uint64_t *k = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, sort_tmp, k, k, (size_t)n, 0, 64, (hipStream_t)0);
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    return bh_workspace_bytes(n) + 2 * al(8 * (size_t)n) + al((size_t)n) + al(4 * (size_t)kIfN * nblocks) + al(sort_tmp) + 16 * 256 + al(8 * (size_t)n) + 256;
+}
+
+// returns 0 ok.  info: filterThreshold, filterTheta, index (1-based), theta[50], numRej[50], lowess[50]
+int run_independent_filtering(const double *d_bm, const double *d_p, int64_t n, double alpha, double *d_padj, char *ws, hipStream_t st,
+                              chicdiff_results_info *info) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const int nblocks = (int)((n + kIfBlock - 1) / kIfBlock);
+    char *bh_ws = ws;
+    char *p = ws + bh_workspace_bytes(n);
+    uint64_t *k0 = (uint64_t *)p; p += al(8 * (size_t)n);
+    uint64_t *k1 = (uint64_t *)p; p += al(8 * (size_t)n);
+    uint8_t *T = (uint8_t *)p; p += al((size_t)n);
+    uint32_t *blockcnt = (uint32_t *)p; p += al(4 * (size_t)kIfN * nblocks);
+    unsigned long long *nzero = (unsigned long long *)p; p += 256;
+    int64_t *qidx = (int64_t *)p; p += 4 * 256;
+    double *qval = (double *)p; p += 4 * 256;
+    uint32_t *total = (uint32_t *)p; p += 256;
+    unsigned int *numRej = (unsigned int *)p; p += 256;
+    double *pmask = (double *)p; p += al(8 * (size_t)n);
+    void *sort_tmp = p;
+    size_t sort_bytes = 0;
+    (void)rocprim::radix_sort_keys(nullptr, sort_bytes, k0, k1, (size_t)n, 0, 64, st);
+    int g = (int)((n + 2047) / 2048);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    // 1. lower = mean(baseMean == 0); cutoffs = quantile(baseMean, theta) (type 7)
+    if (hipMemsetAsync(nzero, 0, 8, st) != hipSuccess) return 1;
+    if_keys_kernel<<<g, 256, 0, st>>>(d_bm, n, k0, nzero);
+    if (rocprim::radix_sort_keys(sort_tmp, sort_bytes, k0, k1, (size_t)n, 0, 64, st) != hipSuccess) return 1;
+    unsigned long long h_nzero = 0;
+    if (hipMemcpyAsync(&h_nzero, nzero, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+    const double lower = (double)h_nzero / (double)n, upper = lower < 0.95 ? 0.95 : 1.0;
+    int64_t h_qidx[2 * kIfN];
+    double frac[kIfN];
+    for (int k = 0; k < kIfN; k++) {
+        info->theta[k] = lower + (double)k * ((upper - lower) / (double)(kIfN - 1));  // seq(lower, upper, length = 50)
+        const double h = (double)(n - 1) * info->theta[k];
+        const int64_t lo = (int64_t)floor(h);
+        h_qidx[2 * k] = lo;
+        h_qidx[2 * k + 1] = lo + 1 < n ? lo + 1 : n - 1;
+        frac[k] = h - (double)lo;
+    }
+    info->theta[kIfN - 1] = upper;
+    double h_q[2 * kIfN];
+    if (hipMemcpyAsync(qidx, h_qidx, sizeof h_qidx, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    if_gather_kernel<<<1, 128, 0, st>>>(k1, qidx, 2 * kIfN, qval);
+    if (hipMemcpyAsync(h_q, qval, sizeof h_q, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+    IfCuts cu;
+    for (int k = 0; k < kIfN; k++) cu.c[k] = h_q[2 * k] + frac[k] * (h_q[2 * k + 1] - h_q[2 * k]);
+    // 2. one sort by p-value (NA last) via the BH machinery's buffers, then the 50 filtered rejection counts
+    //    (bh_ws layout: count | k0 | k1 | i0 | i1 | q | s — see launch_bh_adjust)
+    unsigned long long *count = (unsigned long long *)bh_ws;
+    uint64_t *pk0 = (uint64_t *)(bh_ws + 256), *pk1 = (uint64_t *)((char *)pk0 + al(8 * (size_t)n));
+    uint32_t *pi0 = (uint32_t *)((char *)pk1 + al(8 * (size_t)n)), *pi1 = (uint32_t *)((char *)pi0 + al(4 * (size_t)n));
+    size_t psort = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, psort, pk0, pk1, pi0, pi1, (size_t)n, 0, 64, st);
+    if (psort > bh_workspace_bytes(n)) return 1;
+    if (hipMemsetAsync(count, 0, 8, st) != hipSuccess) return 1;
+    bh_keys_kernel<<<g, 256, 0, st>>>(d_p, n, pk0, pi0, count);
+    void *ptmp = (char *)pi1 + al(4 * (size_t)n) + 2 * al(8 * (size_t)n);  // behind q and s
+    if (rocprim::radix_sort_pairs(ptmp, psort, pk0, pk1, pi0, pi1, (size_t)n, 0, 64, st) != hipSuccess) return 1;
+    if (hipMemsetAsync(numRej, 0, sizeof(unsigned int) * kIfN, st) != hipSuccess) return 1;
+    if_count_kernel<<<nblocks, kIfBlock, 0, st>>>(pi1, d_bm, n, count, cu, T, blockcnt, nblocks);
+    if_scan_kernel<<<kIfN, 1024, 0, st>>>(blockcnt, nblocks, total);
+    if_rej_kernel<<<nblocks, kIfBlock, 0, st>>>(pk1, T, n, blockcnt, total, nblocks, alpha, numRej);
+    unsigned int h_rej[kIfN];
+    if (hipMemcpyAsync(h_rej, numRej, sizeof h_rej, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+    // 3. lowess(numRej ~ theta, f = 1/5), threshold choice (DESeq2 pvalueAdjustment)
+    double maxRej = 0;
+    for (int k = 0; k < kIfN; k++) {
+        info->numRej[k] = (double)h_rej[k];
+        maxRej = std::max(maxRej, info->numRej[k]);
+    }
+    lowess_host(info->theta, info->numRej, kIfN, 1.0 / 5.0, 3, 0.01 * (info->theta[kIfN - 1] - info->theta[0]), info->lowess);
+    int j = 0;
+    if (maxRej > 10) {
+        double ss = 0, fitmax = info->lowess[0];
+        int cnt = 0;
+        for (int k = 0; k < kIfN; k++) {
+            fitmax = std::max(fitmax, info->lowess[k]);
+            if (info->numRej[k] > 0) {
+                const double r = info->numRej[k] - info->lowess[k];
+                ss += r * r;
+                cnt++;
+            }
+        }
+        const double thresh = fitmax - sqrt(cnt ? ss / cnt : 0.0);
+        for (int k = 0; k < kIfN; k++)
+            if (info->numRej[k] > thresh) { j = k; break; }
+    }
+    info->index = j + 1;
+    info->filterThreshold = cu.c[j];
+    info->filterTheta = info->theta[j];
+    info->alpha = alpha;
+    // 4. padj = BH over the rows that pass the chosen filter
+    if_mask_kernel<<<g, 256, 0, st>>>(d_bm, d_p, n, cu.c[j], pmask);
+    return launch_bh_adjust(pmask, n, d_padj, bh_ws, st);
 }
 
 }  // namespace cd

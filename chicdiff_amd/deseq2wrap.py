@@ -168,12 +168,14 @@ def DESeq2Wrap(chicdiff_settings, RU, FullRegionData, suffix="", theta=None, ctx
         if not np.array_equal(anno["regionID"].to_numpy(), np.arange(1, n + 1)):
             raise AssertionError("identical(1:nrow(annoData), annoData$regionID) is not TRUE")
 
-        # results(): Cook's cutoff, independent filtering, BH (a9)
+        # results(): Cook's cutoff, independent filtering, BH (a9) — on the device
+        sizes = [int((group == 0).sum()), int((group == 1).sum())]
+        if S > 2 and max(sizes) >= 3:  # DESeq2 applies the Cook's cutoff only when some group has >= 3 replicates
+            from scipy import stats
+            ctx.cooks_filter(d_N, group, out["maxCooks"], out["cooksArgmax"], out["pvalue"], stats.f.ppf(0.99, 2, S - 2))
+        d_padj, _info = ctx.independent_filtering(out["baseMean"], out["pvalue"])
         host = {k: v.cpu().numpy() for k, v in out.items()}
-        pvalue, _ = _results.cooks_filter(
-            host["pvalue"], host["maxCooks"], host["cooksArgmax"],
-            lambda idx: d_N[:, torch.as_tensor(idx, device=ctx.device)].T.cpu().numpy(), group)
-        padj, _info = _results.independent_filtering(host["baseMean"], pvalue)
+        pvalue, padj = host["pvalue"], d_padj.cpu().numpy()
         message(f"{label}: # unweighted interactions with padj<0.05: ", int(np.sum(padj < 0.05)))
         if save_rds:
             message("Saving the DESeq object")

@@ -28,7 +28,8 @@ EXPORTS = [
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
     "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
     "chicdiff_hip_malloc", "chicdiff_hip_free", "chicdiff_hip_memcpy_h2d", "chicdiff_hip_memcpy_d2h",
-    "chicdiff_hip_rccl_unique_id", "chicdiff_hip_rccl_init",
+    "chicdiff_hip_rccl_unique_id", "chicdiff_hip_rccl_init", "chicdiff_hip_cooks_filter_dev",
+    "chicdiff_hip_independent_filtering_dev",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
     "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
@@ -54,6 +55,11 @@ class Scalars(C.Structure):
     _fields_ = [("trendCoef", C.c_double * 2), ("varLogDispEsts", C.c_double), ("dispPriorVar", C.c_double),
                 ("sumDeviance", C.c_double), ("nAllZero", C.c_int64), ("trendOuterIter", C.c_int32),
                 ("status", C.c_int32)]
+
+
+class ResultsInfo(C.Structure):
+    _fields_ = [("filterThreshold", C.c_double), ("filterTheta", C.c_double), ("alpha", C.c_double), ("index", C.c_int32),
+                ("_pad", C.c_int32), ("theta", C.c_double * 50), ("numRej", C.c_double * 50), ("lowess", C.c_double * 50)]
 
 
 class KernelTime(C.Structure):
@@ -93,6 +99,8 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_count_join_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp]
     L.chicdiff_hip_fragment_background_dev.argtypes = [vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32,
                                                        C.POINTER(dbl), vp, vp, vp]
+    L.chicdiff_hip_cooks_filter_dev.argtypes = [vp, vp, i64, i32, C.POINTER(i32), vp, vp, dbl, vp, C.POINTER(i64)]
+    L.chicdiff_hip_independent_filtering_dev.argtypes = [vp, vp, vp, i64, dbl, vp, C.POINTER(ResultsInfo)]
     L.chicdiff_hip_rccl_unique_id.argtypes = [vp, C.c_char_p, vp]
     L.chicdiff_hip_rccl_init.argtypes = [vp, C.c_char_p, vp, i32, i32]
     L.chicdiff_hip_malloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
@@ -304,6 +312,27 @@ class HipContext:
             d_bait_in_RU.data_ptr() if d_bait_in_RU is not None else None,
             d_bait_in_RU.numel() - 1 if d_bait_in_RU is not None else 0, keys.data_ptr(), vals.data_ptr(), C.byref(nk)))
         return keys[: nk.value], vals[: nk.value]
+
+    # -- a9: results() ---------------------------------------------------------------------------
+    def cooks_filter(self, d_counts, group, d_maxCooks, d_cooksArgmax, d_pvalue, cutoff):
+        """p <- NA for Cook's outliers, in place on ``d_pvalue``; returns the number of rows set to NA."""
+        S, n = d_counts.shape
+        g = (C.c_int32 * S)(*[int(x) for x in group])
+        nout = C.c_int64(0)
+        self._check(self.lib.chicdiff_hip_cooks_filter_dev(self.h, d_counts.data_ptr(), n, S, g, d_maxCooks.data_ptr(),
+                                                           d_cooksArgmax.data_ptr(), float(cutoff), d_pvalue.data_ptr(), C.byref(nout)))
+        return nout.value
+
+    def independent_filtering(self, d_baseMean, d_pvalue, alpha=0.1):
+        """DESeq2 pvalueAdjustment(independentFiltering = TRUE): returns (padj device tensor, info dict)."""
+        torch = self.torch
+        n = d_pvalue.numel()
+        padj = torch.empty(n, dtype=torch.float64, device=self.device)
+        info = ResultsInfo()
+        self._check(self.lib.chicdiff_hip_independent_filtering_dev(self.h, d_baseMean.data_ptr(), d_pvalue.data_ptr(), n, float(alpha),
+                                                                    padj.data_ptr(), C.byref(info)))
+        return padj, dict(filterThreshold=info.filterThreshold, filterTheta=info.filterTheta, index=info.index,
+                          theta=np.array(info.theta[:]), numRej=np.array(info.numRej[:]), lowess=np.array(info.lowess[:]))
 
     # -- f1 / f3: BH and the IHW application side ----------------------------------------------
     def bh_adjust(self, d_p):

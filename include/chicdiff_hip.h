@@ -176,6 +176,29 @@ int chicdiff_hip_count_table_dev(chicdiff_hip_ctx *ctx, const int32_t *d_bait, c
  * on the weighted p-values).  NaN = NA: not counted, stays NaN.  n < 2^32. */
 int chicdiff_hip_bh_adjust_dev(chicdiff_hip_ctx *ctx, const double *d_p, int64_t n, double *d_padj);
 
+/* a9 — DESeq2 results() on device (chicdiff.R:1720-1741 call it with its defaults).
+ *
+ * Cook's cutoff: p <- NA where maxCooks > cutoff (host passes qf(.99, p, m - p)); for the two-group design the
+ * p-value is kept when at least 3 counts of the row exceed the count of the sample with the largest Cook's
+ * distance.  Only meaningful when some group has >= 3 samples (otherwise DESeq2 skips the step: do not call).
+ * d_pvalue is modified in place; *n_outliers_host = rows set to NA. */
+int chicdiff_hip_cooks_filter_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts, int64_t n, int32_t S, const int32_t *group,
+                                  const double *d_maxCooks, const int32_t *d_cooksArgmax, double cutoff, double *d_pvalue,
+                                  int64_t *n_outliers_host);
+
+/* Independent filtering + BH (pvalueAdjustment, independentFiltering = TRUE): theta = seq(mean(baseMean == 0), 0.95,
+ * length = 50), cutoffs = quantile(baseMean, theta), numRej[k] = #{BH-adjusted p < alpha among rows with baseMean >=
+ * cutoff k}, lowess(numRej ~ theta, f = 1/5), first theta whose numRej exceeds max(fit) - RMSE; padj = BH over the rows
+ * passing that cutoff, NaN elsewhere. */
+typedef struct {
+    double filterThreshold, filterTheta, alpha;
+    int32_t index; /* 1-based position of the chosen theta */
+    int32_t _pad;
+    double theta[50], numRej[50], lowess[50];
+} chicdiff_results_info;
+int chicdiff_hip_independent_filtering_dev(chicdiff_hip_ctx *ctx, const double *d_baseMean, const double *d_pvalue, int64_t n,
+                                           double alpha, double *d_padj, chicdiff_results_info *info);
+
 /* f3 — application side of IHWcorrection (chicdiff.R:2038-2049), after ihw() has been trained in R:
  *   group <- as.integer(cut(log(abs(avDist)), breaks)); avWeights <- distLookup$avWeights[group];
  *   weight <- avWeights / mean(avWeights); weighted_pvalue <- pvalue / weight;

@@ -866,3 +866,44 @@ def test_all_rows_zero_and_bad_inputs(ctx):
         ctx.nbglm_fit(z[:2].contiguous(), nf[:2].contiguous(), [0, 1])   # no residual degrees of freedom
     with pytest.raises(hip.ChicdiffHipError):
         ctx.nbglm_fit(z, nf, [1, 1, 1, 1])          # no sample in the reference level
+
+
+def test_results_on_device(ctx, golden, oracle):
+    """a9: independent filtering + BH on device reproduces the reference's padj column (24 863 rows: the 2 411 NA,
+    quantile index 6, the BH values) and, on a synthetic 300 k table with ties and NA, the host restatement that the
+    golden table pins; Cook's filter against the host restatement."""
+    import torch
+    from chicdiff_amd import results
+    dev = lambda a, t=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(ctx.device)
+    padj, info = ctx.independent_filtering(dev(golden["baseMean"]), dev(golden["pvalue"]))
+    got, ref = padj.cpu().numpy(), golden["padj"]
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(ref).sum() == 2411
+    assert info["index"] == 6 and 4.7967 < info["filterThreshold"] <= 4.7975
+    ok = ~np.isnan(ref)
+    assert np.allclose(got[ok], ref[ok], rtol=1e-13, atol=0)
+    rng = np.random.default_rng(9)
+    n = 300000
+    bm = rng.lognormal(np.log(19), 1.4, n)
+    bm[rng.uniform(size=n) < 0.02] = 0.0
+    p = rng.uniform(size=n)
+    p[rng.uniform(size=n) < 0.15] **= 6
+    p[bm == 0] = np.nan
+    p[rng.integers(0, n, 500)] = p[11]
+    hp, hinfo = results.independent_filtering(bm, p)
+    dp, dinfo = ctx.independent_filtering(dev(bm), dev(p))
+    assert np.array_equal(dinfo["numRej"], hinfo["numRej"]) and dinfo["index"] == hinfo["index"]
+    assert np.allclose(dinfo["theta"], hinfo["theta"], rtol=1e-15) and np.isclose(dinfo["filterThreshold"], hinfo["filterThreshold"], rtol=1e-15)
+    assert np.allclose(dinfo["lowess"], hinfo["lowess"], rtol=1e-9)
+    assert np.allclose(dp.cpu().numpy(), hp, rtol=1e-13, equal_nan=True)
+    # Cook's filter
+    S, m = 8, 20000
+    d = synth.make(m, S)
+    group = d["group"]
+    mc = rng.gamma(1.0, 1.0, m)
+    mc[rng.uniform(size=m) < 0.1] = np.nan
+    am = rng.integers(0, S, m).astype(np.int32)
+    pv = rng.uniform(size=m)
+    ref_p, ref_n = results.cooks_filter(pv, mc, am, lambda idx: d["counts"][idx], group, cutoff=2.5)
+    dpv = dev(pv)
+    nout = ctx.cooks_filter(ctx.to_device(d["counts"], np.int32), group, dev(mc), dev(am, np.int32), dpv, 2.5)
+    assert nout == ref_n > 0 and np.array_equal(dpv.cpu().numpy(), ref_p, equal_nan=True)
