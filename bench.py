@@ -108,6 +108,8 @@ def hbm_kernels(ctx, torch, n, S, F=11):
     run_wall("region_universe", lambda: ctx.region_universe(pb, po, 5, chr_of), 2 * (8 * n) + 16 * n + 12 * nrow)
     pv = torch.rand(n, dtype=torch.float64, device=dev, generator=g)
     run("bh_adjust", lambda: ctx.bh_adjust(pv), 16 * n)
+    bmv = torch.exp(torch.randn(n, dtype=torch.float64, device=dev, generator=g) * 1.4 + 2.9)
+    run("independent_filtering", lambda: ctx.independent_filtering(bmv, pv), 24 * n)  # a9: baseMean + p in, padj out
     ctx.enable_timing(False)
     return out
 
