@@ -125,3 +125,54 @@ def test_single_rank_harness_matches_oracle():
     sf = np.zeros(6)
     assert L.harness_size_factors(k.ctypes.data_as(pi), len(k), 6, 1, 0, 0, null_cb, None, sf.ctypes.data_as(pd)) == 0
     assert np.allclose(sf, oracle.size_factors(d["counts"]), rtol=1e-13)
+
+
+def _ties_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from chicdiff_amd.dist import AllReduceHook, shard_bounds
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = build_harness()
+        rng = np.random.default_rng(5)
+        n, S = 24000, 4
+        counts = rng.poisson(30, size=(n, S)).astype(np.int32)
+        counts[: 2 * n // 3] = [10, 20, 30, 41]  # 16 000 identical ratios per column: more than a gathered list holds
+        counts = counts[rng.permutation(n)]
+        lo, hi = shard_bounds(n, world, rank)
+        hook = AllReduceHook(memory="host")
+        pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        k = np.asfortranarray(counts[lo:hi])
+        sf = np.zeros(S)
+        rc = L.harness_size_factors(k.ctypes.data_as(pi), hi - lo, S, world, rank, 0, hook.fn, None, sf.ctypes.data_as(pd))
+        assert rc == 0 and hook.error is None
+        q.put((rank, sf.tolist(), hook.calls, oracle.size_factors(counts).tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_median_falls_back_when_the_gathered_list_would_overflow():
+    """Massive ties: after two rounds more than 4096 candidates share the median's 24 leading key bits, every rank
+    sees that from the all-reduced count rows, nobody places candidates, and the remaining histogram rounds run."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_ties_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, sf, calls, ref in res:
+        assert calls == 8  # 2 histogram rounds + count rows + (empty) candidate buffer + 4 more histogram rounds
+        assert np.allclose(sf, ref, rtol=1e-13)
+    assert res[0][1] == res[1][1]
