@@ -47,6 +47,7 @@ struct chicdiff_hip_ctx {
     size_t aux_bytes = 0;
     FitWork w{};
     double *d_sf = nullptr;   // kMaxS doubles
+    double *d_logfact = nullptr;  // kLogFactN doubles: log(k!) (wald_prep)
     double *d_nf_tmp = nullptr;
     FitScalars *h_sc = nullptr;  // pinned
     double *h_sf = nullptr;      // pinned, kMaxS
@@ -104,10 +105,20 @@ int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_sc, sizeof(FitScalars))) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_sf, sizeof(double) * kMaxS)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_sf, sizeof(double) * kMaxS)) != hipSuccess) {
+        (e = hipMalloc((void **)&c->d_sf, sizeof(double) * kMaxS)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_logfact, sizeof(double) * kLogFactN)) != hipSuccess) {
         fail(nullptr, CHICDIFF_E_HIP, "context setup: %s", hipGetErrorString(e));
         delete c;
         return CHICDIFF_E_HIP;
+    }
+    {  // log(k!) for k < kLogFactN: lgamma(y + 1) of the NB log-likelihood's constant part is a table look-up for ordinary counts
+        std::vector<double> lf(kLogFactN);
+        for (int k = 0; k < kLogFactN; k++) lf[k] = lgamma((double)k + 1.0);
+        if ((e = hipMemcpy(c->d_logfact, lf.data(), sizeof(double) * kLogFactN, hipMemcpyHostToDevice)) != hipSuccess) {
+            fail(nullptr, CHICDIFF_E_HIP, "context setup: %s", hipGetErrorString(e));
+            chicdiff_hip_destroy(c);
+            return CHICDIFF_E_HIP;
+        }
     }
     c->stream = c->own_stream;
     *out = c;
@@ -122,6 +133,7 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->aux) (void)hipFree(c->aux);
     if (c->d_sf) (void)hipFree(c->d_sf);
+    if (c->d_logfact) (void)hipFree(c->d_logfact);
     if (c->h_sc) (void)hipHostFree(c->h_sc);
     if (c->h_sf) (void)hipHostFree(c->h_sf);
     if (c->rccl_comm && c->rccl_comm_destroy) (void)c->rccl_comm_destroy(c->rccl_comm);
@@ -316,6 +328,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     w.hist_local = (double *)p; p += hist;
     w.selcnt = (double *)p; p += selcnt;
     w.sc = (FitScalars *)p; p += align256(sizeof(FitScalars));
+    w.logfact = c->d_logfact;
     w.queue = (unsigned long long *)p; p += 256;
     c->d_nf_tmp = (double *)p;
     c->cap_n = n;

@@ -28,7 +28,9 @@ struct FitWork {
     double *selcnt;               // kSelMaxWorld x kMaxS*2 doubles: per-rank candidate counts
     unsigned long long *queue;    // work-queue heads
     FitScalars *sc;
+    const double *logfact;        // log(k!) for k < kLogFactN
 };
+constexpr int kLogFactN = 1024;
 
 struct Opts {
     double minDisp, dispTol, kappa0, betaTol, minmu, outlierSD, dispPriorVarIn, maxDisp, trendIn[2];
