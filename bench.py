@@ -114,6 +114,20 @@ def hbm_kernels(ctx, torch, n, S, F=11):
     return out
 
 
+def theta_grid_time(ctx, torch, dk, dfm, S):
+    """a8: the reference's default mode first scans theta over a 5-point grid, one design-~1 fit per theta
+    (chicdiff.R:1619-1662); wall clock of that scan on the benchmark matrix."""
+    sf = ctx.size_factors(dk)
+    grid = [0.0, 0.25, 0.5, 0.75, 1.0]
+    ctx.theta_grid(dk, dfm, sf, grid)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev = ctx.theta_grid(dk, dfm, sf, grid)
+    torch.cuda.synchronize()
+    del dev  # (all-zero rows of the synthetic matrix make every total deviance NA, as in the reference: sum() without na.rm)
+    return {"ms": round((time.perf_counter() - t0) * 1e3, 3), "thetas": len(grid)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +243,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_hbm_kernels:
         result["hbm_kernels"] = hbm_kernels(ctx, torch, n, S)
+        result["theta_grid"] = theta_grid_time(ctx, torch, dk, dfm, S)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = 1  # DESeq2 as Chicdiff calls it is single-threaded
         v1, dt1 = cpu_baseline(S, args.theta, args.cpu_sample_rows, cores)

@@ -28,6 +28,7 @@ struct KTimer {
 
 struct chicdiff_hip_ctx {
     int device = 0;
+    int cu_count = 0;  // compute units of the device (the persistent trend kernel needs one resident workgroup per CU it launches)
     hipStream_t own_stream = nullptr, stream = nullptr;
     chicdiff_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
@@ -110,6 +111,10 @@ int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
         fail(nullptr, CHICDIFF_E_HIP, "context setup: %s", hipGetErrorString(e));
         delete c;
         return CHICDIFF_E_HIP;
+    }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
     }
     {  // log(k!) for k < kLogFactN: lgamma(y + 1) of the NB log-likelihood's constant part is a table look-up for ordinary counts
         std::vector<double> lf(kLogFactN);
@@ -478,7 +483,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_trend_init(d, w, o, st);
         HIPCHK(c, hipMemcpyAsync(w.sc->coefs, o.trendIn, sizeof(double) * 2, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));  // o.trendIn lives on this frame
-    } else if (!c->allreduce && !getenv("CHICDIFF_TREND_MULTILAUNCH")) {
+    } else if (!c->allreduce && c->cu_count >= trend_persistent_blocks() && !getenv("CHICDIFF_TREND_MULTILAUNCH")) {
         Scope t(c, "trend_fit");  // single rank: one persistent launch (LDS-resident rows, grid barrier per IRLS pass)
         launch_trend_persistent(d, w, o, st);  // no host round trip: `failed` comes back with the final scalars
     } else {

@@ -44,6 +44,7 @@ void launch_xim(FitDims d, FitWork w, hipStream_t st);                  // colsu
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_disp_map(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st);  // single rank: whole trend fit, one launch
+int trend_persistent_blocks();  // workgroups that must be co-resident (grid barrier): needs that many CUs
 void launch_trend_init(FitDims d, FitWork w, Opts o, hipStream_t st);
 int trend_blocks();                                                       // grid of the trend pass = rows of 8 partial sums
 void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st, bool fused_step);  // pass (+ reduce + step when single rank)

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
         sc->finished = 1;
     }
 }
+int trend_persistent_blocks() { return kTpBlocks; }
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
     (void)hipMemsetAsync(w.queue + 8, 0, 8, st);
     trend_persistent_kernel<<<kTpBlocks, kTpThreads, 0, st>>>(d, w, o.minDisp);
