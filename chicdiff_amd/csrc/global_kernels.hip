@@ -193,7 +193,12 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
 int trend_persistent_blocks() { return kTpBlocks; }
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
     (void)hipMemsetAsync(w.queue + 8, 0, 8, st);
-    trend_persistent_kernel<<<kTpBlocks, kTpThreads, 0, st>>>(d, w, o.minDisp);
+    // as few workgroups as keep every row LDS-resident: the pass time is the grid barrier plus the all-partials sum,
+    // both of which grow with the number of workgroups (small fits are latency-bound by these ~20 passes)
+    int64_t blocks = (d.n + kTpCap - 1) / kTpCap;
+    if (blocks < 1) blocks = 1;
+    if (blocks > kTpBlocks) blocks = kTpBlocks;
+    trend_persistent_kernel<<<(unsigned)blocks, kTpThreads, 0, st>>>(d, w, o.minDisp);
 }
 
 void launch_trend_init(FitDims, FitWork w, Opts, hipStream_t st) { trend_init_kernel<<<1, 1, 0, st>>>(w); }
