@@ -1,8 +1,9 @@
 // api.hip — host side of include/chicdiff_hip.h: context, workspace, and the launch sequence of
-// one fit.  Everything is enqueued on one HIP stream; the host blocks only (a) to learn that the
-// trend state machine has finished (once per batch of IRLS passes) and (b) to read the fit's
-// scalars back at the end.  With world_size > 1 every global sum goes through the caller's
-// sum-all-reduce callback (RCCL via torch.distributed in this repo), on the same stream.
+// one fit.  Everything is enqueued on one HIP stream.  On a single rank the host blocks once, to read
+// the fit's scalars back at the end; sharded, it also looks at the trend's `finished` flag once per
+// batch of IRLS passes and at the verdict of each median's candidate gather.  With world_size > 1
+// every global sum goes through a sum-all-reduce on the same stream: the library's own RCCL
+// communicator (chicdiff_hip_rccl_init) or the caller's callback (chicdiff_hip_set_allreduce).
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -13,7 +14,6 @@
 #include <vector>
 
 #include <dlfcn.h>
-#include <string.h>
 
 #include "common.h"
 

@@ -13,8 +13,10 @@
 //     Armijo step, the start point, or a grid point of the fitDispGrid fallback — so lanes in
 //     different phases still execute the same instruction stream;
 //   * iteration counts are heavy-tailed (median ~7, 1.7 % of rows run 100 + 40 grid points),
-//     so a finished lane immediately pulls the next row from a global queue (one atomic per
-//     wave per refill) instead of idling until its 63 neighbours finish.
+//     so a finished lane immediately pulls the next row from a global queue (wave-private chunks
+//     of 64 rows, one atomic per chunk) instead of idling until its 63 neighbours finish;
+//   * at the end of the launch, waves left with a few stragglers evaluate them with the samples
+//     spread across lanes (eval_point_spread), bit-identical to the row-per-lane evaluation.
 #include <stdio.h>
 #include <stdlib.h>
 

@@ -2,11 +2,14 @@
 //
 //  * dispersion trend  alpha(mu) = a0 + a1/mu  — DESeq2 parametricDispersionFit + R glm.fit for
 //    Gamma(link="identity"): one fused pass per IRLS step (deviance of
-//    the current iterate + weighted-LS sums for the next), two-stage deterministic reduction,
-//    and a one-thread state machine so the host never has to read the iterate back;
+//    the current iterate + weighted-LS sums for the next), fixed-order reductions, and a state
+//    machine that runs on the device (fit_state.h).  Single rank: ONE persistent launch with the
+//    rows resident in LDS and a grid barrier per pass; sharded: one launch + one all-reduce of the
+//    block partials + one reduce-and-step launch per pass;
 //  * exact medians (size factors, chicdiff.R:1561-1562 / A1; MAD of log residuals, A3) by a
-//    12-bit radix select over order-preserving 64-bit keys — every step is a SUM, so row
-//    sharding only needs sum-all-reduces of the histograms;
+//    12-bit radix select over order-preserving 64-bit keys: two histogram rounds, then the few
+//    hundred candidates left are gathered and sorted (single rank: compaction; sharded: count rows
+//    + a sum-all-reduce of disjoint entries) — every step is a SUM, so it shards;
 //  * offsets (chicdiff.R:1583-1589, 1635-1638), window sums (:1540-1547), count join (:843-858).
 #include "common.h"
 #include "devmath.h"

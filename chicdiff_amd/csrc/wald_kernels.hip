@@ -5,11 +5,13 @@
 // builds (~condition with two levels; ~1) the (S+2)x2 QR solve of fitBeta's ridge-augmented
 // system collapses to a closed-form 2x2 solve (det(X'WX) = sum_A w * sum_B w), so there is no
 // dense contraction and no MFMA: three kernels,
-//   wald_prep   (row per thread) : beta start = LS of log(q+0.1); the mu-independent part of the
-//                                   NB log-likelihood, so the IRLS ticks need one log1p/sample;
+//   wald_prep   (row per thread) : beta start = LS of log(q+0.1); the mu-independent parts of the
+//                                   NB log-likelihood (log y! from a table), so that an IRLS tick
+//                                   needs one log1p and one reciprocal per sample, no log(mu), no 1/mu;
 //   wald_irls   (row per lane + queue refill, as disp_fit_kernel) : IRLS ticks;
-//   wald_final  (row per thread) : sandwich SE, stat, p (Cody), deviance via the saddle-point
-//                                   dnbinom R uses, hat diagonals -> max Cook's distance.
+//   wald_optim  (row per thread) : the few rows the IRLS left unconverged (DESeq2: optim fallback);
+//   wald_final  (row per thread) : sandwich SE, stat, p (Cody), deviance, hat diagonals -> max
+//                                   Cook's distance (trimmed cell variances by rank counting in LDS).
 #include "common.h"
 #include "devmath.h"
 
