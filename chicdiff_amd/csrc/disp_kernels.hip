@@ -249,16 +249,16 @@ __device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double n
     const double rt = rcp(t);
     const double L = tlog1p_from(ma, t, rt, lt);
     v.wj = mu * rt;  // 1 / (1/mu + alpha)
+    double dlg = 0.0, ddg = H;
     v.pe = __builtin_amdgcn_frexp_exp(P);
     v.pm = __builtin_amdgcn_frexp_mant(P);
-    // no branch: in a wave of 64 rows some lane needs the Stirling difference at nearly every sample anyway
-    // (unrolling the sample loop four-fold on top of this, 240 VGPRs, bought nothing: issue-bound, not latency-bound)
-    const bool far = yi > c.nr;
-    const double z = far ? y + c.r : c.r + (double)c.nr;  // (the reference point itself when not needed: difference 0)
-    double lgz, dgz;
-    stirling(z, tlog(z, lt), rcp(z), lgz, dgz);
-    const double dlg = far ? lgz - c.lgS0 : 0.0;
-    const double ddg = far ? H + (dgz - c.dgS0) : H;
+    if (yi > c.nr) {
+        const double z = y + c.r;
+        double lgz, dgz;
+        stirling(z, tlog(z, lt), rcp(z), lgz, dgz);
+        dlg = lgz - c.lgS0;
+        ddg += dgz - c.dgS0;
+    }
     v.tll = fma(-c.r, L, fma(-y, L - c.a, dlg));          // dlg - y (L - a) - r L
     v.tsd = fma(y * c.alpha, rt, fma(-ma, rt, L - ddg));  // L - ddg - ma/t + y alpha/t
     return v;

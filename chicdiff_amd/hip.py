@@ -78,11 +78,12 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("CHICDIFF_HIP_LIB", LIB_PATH)  # (override: A/B runs of two builds)
+    if not os.path.exists(path):
         raise ChicdiffHipError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     L.chicdiff_hip_create.argtypes = [C.POINTER(vp), i32]
     L.chicdiff_hip_destroy.argtypes = [vp]
