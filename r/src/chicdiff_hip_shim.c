@@ -170,7 +170,40 @@ SEXP chicdiff_hip_region_universe(SEXP baitID, SEXP oeID, SEXP RUexpand, SEXP ch
     return out;
 }
 
+/* .Call("chicdiff_hip_padj", baseMean, pvalue, alpha) -> list(padj, filterThreshold, filterTheta, numRej):
+ * DESeq2 pvalueAdjustment(independentFiltering = TRUE) as results() runs it at chicdiff.R:1721/1730/1739.
+ * NA_real_ is a NaN, which is what the library treats as NA. */
+SEXP chicdiff_hip_padj(SEXP baseMean, SEXP pvalue, SEXP alpha) {
+    if (!Rf_isReal(baseMean) || !Rf_isReal(pvalue) || XLENGTH(baseMean) != XLENGTH(pvalue)) Rf_error("chicdiff_hip_padj: bad arguments");
+    const R_xlen_t n = XLENGTH(pvalue);
+    chicdiff_hip_ctx *c = ctx_or_error();
+    static const char *names[] = {"padj", "filterThreshold", "filterTheta", "numRej"};
+    SEXP out = PROTECT(named_list(4, names));
+    SET_VECTOR_ELT(out, 0, Rf_allocVector(REALSXP, n));
+    SET_VECTOR_ELT(out, 3, Rf_allocVector(REALSXP, 50));
+    void *d_bm = to_device(c, REAL(baseMean), 8 * (size_t)n), *d_p = to_device(c, REAL(pvalue), 8 * (size_t)n), *d_q = NULL;
+    chicdiff_results_info info;
+    int rc = chicdiff_hip_malloc(c, 8 * (size_t)n, &d_q);
+    if (!rc) rc = chicdiff_hip_independent_filtering_dev(c, d_bm, d_p, (int64_t)n, Rf_asReal(alpha), d_q, &info);
+    if (!rc) rc = chicdiff_hip_memcpy_d2h(c, REAL(VECTOR_ELT(out, 0)), d_q, 8 * (size_t)n);
+    char msg[512] = "";
+    if (rc) strncpy(msg, chicdiff_hip_last_error(c), sizeof msg - 1);
+    chicdiff_hip_free(c, d_bm);
+    chicdiff_hip_free(c, d_p);
+    chicdiff_hip_free(c, d_q);
+    if (rc) {
+        UNPROTECT(1);
+        Rf_error("chicdiff_hip_padj: %s", msg);
+    }
+    SET_VECTOR_ELT(out, 1, Rf_ScalarReal(info.filterThreshold));
+    SET_VECTOR_ELT(out, 2, Rf_ScalarReal(info.filterTheta));
+    memcpy(REAL(VECTOR_ELT(out, 3)), info.numRej, sizeof info.numRej);
+    UNPROTECT(1);
+    return out;
+}
+
 static const R_CallMethodDef call_methods[] = {{"chicdiff_hip_fit", (DL_FUNC)&chicdiff_hip_fit, 4},
+                                               {"chicdiff_hip_padj", (DL_FUNC)&chicdiff_hip_padj, 3},
                                                {"chicdiff_hip_ihw_apply", (DL_FUNC)&chicdiff_hip_ihw_apply, 4},
                                                {"chicdiff_hip_region_universe", (DL_FUNC)&chicdiff_hip_region_universe, 4},
                                                {NULL, NULL, 0}};
