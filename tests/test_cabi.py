@@ -33,6 +33,26 @@ def test_struct_layouts_match_header(lib):
         (1e-8, 1e-6, 1.0, 100, 100, 1e-8, 0.5, 2.0)
     assert o.dispPriorVar != o.dispPriorVar and o.trendCoef[0] != o.trendCoef[0]  # NaN = estimate
     assert C.sizeof(hip.Opts) == 80 and C.sizeof(hip.Out) == 21 * 8 and C.sizeof(hip.Scalars) == 56
+    # the compiler's view of the header (gcc, plain C): sizes and a few offsets against the ctypes mirrors
+    import subprocess
+    import tempfile
+    src = r"""
+#include <stddef.h>
+#include <stdio.h>
+#include "chicdiff_hip.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(chicdiff_nbglm_opts), sizeof(chicdiff_nbglm_out), sizeof(chicdiff_nbglm_scalars),
+           sizeof(chicdiff_results_info), offsetof(chicdiff_results_info, index), offsetof(chicdiff_results_info, theta),
+           offsetof(chicdiff_nbglm_opts, trendCoef));
+    return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(td, "t.c"), "-o", os.path.join(td, "t")], check=True)
+        got = [int(x) for x in subprocess.run([os.path.join(td, "t")], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == [C.sizeof(hip.Opts), C.sizeof(hip.Out), C.sizeof(hip.Scalars), C.sizeof(hip.ResultsInfo), hip.ResultsInfo.index.offset,
+                   hip.ResultsInfo.theta.offset, hip.Opts.trendCoef.offset]
 
 
 def test_product_path_fails_loudly_without_gpu(lib):
