@@ -299,8 +299,9 @@ __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c,
     dlp = (c.r * c.r * acc.sd + dcr) * c.alpha + dpr;
 }
 
-// Row-per-lane evaluation: the lane's own row, all S samples.
-__device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int S, uint64_t gmask,
+// Row-per-lane evaluation: all S samples of the row in LDS column `slot` (the lane's own row, or — grid burst —
+// another lane's), the prefix table in the lane's own column.
+__device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int slot, int S, uint64_t gmask,
                                            bool p2, double gm0, double gm1, double minmu, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
                                            double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
@@ -321,10 +322,10 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
     }
     Acc acc;
     for (int j = 0; j < S; j++) {
-        const int yi = s_y[j * 64 + lane];
+        const int yi = s_y[j * 64 + slot];
         const int n = yi < c.nr ? yi : c.nr;
         const bool g = (gmask >> j) & 1;
-        accumulate(acc, sample_values(c, s_nf[j * 64 + lane], yi, g, gm0, gm1, minmu, s_tab[n * 64 + lane], s_tab[(11 + n) * 64 + lane], lt), g);
+        accumulate(acc, sample_values(c, s_nf[j * 64 + slot], yi, g, gm0, gm1, minmu, s_tab[n * 64 + lane], s_tab[(11 + n) * 64 + lane], lt), g);
     }
     finish_point(acc, c, p2, use_prior, prior_mean, prior_isig, lp, dlp, lt);
 }
@@ -514,16 +515,62 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             a_eval = (gt == 19) ? ghat + gstep : (ghat - gstep) + gt * (2.0 * gstep / 19.0);
         }
 
+        // ---- grid burst -------------------------------------------------------------------------
+        // The 20 points of a fitDispGrid stage are independent evaluations.  Once the queue is empty and at least 19
+        // lanes of the wave have nothing left to do, they evaluate points 1..19 of the lowest lane that is about to
+        // start a stage (its row sits in that lane's LDS column) while it evaluates point 0 itself: 40 serial ticks
+        // of a straggler become 2.  Same eval_point(), same first-maximum rule: identical bits.
+        int burst_owner = -1, slot = lane, hk = 0;
+        bool helper = false;
+        double gm0_e = gm0, gm1_e = gm1, pm_e = prior_mean;
+        if (queue_empty && A.spread) {
+            const unsigned long long starting = __ballot((phase == PH_GRID1 || phase == PH_GRID2) && gt == 0);
+            const unsigned long long idle = __ballot(phase == PH_DONE);
+            if (starting && __popcll(idle) >= 19) {
+                burst_owner = __ffsll((long long)starting) - 1;
+                const int ph_o = __shfl(phase, burst_owner);
+                const double ghat_o = __shfl(ghat, burst_owner);
+                const double g0 = __shfl(gm0, burst_owner), g1 = __shfl(gm1, burst_owner), pmo = __shfl(prior_mean, burst_owner);
+                const int r = __popcll(idle & ((1ull << lane) - 1ull));
+                if (phase == PH_DONE && r < 19) {
+                    helper = true;
+                    hk = r + 1;
+                    slot = burst_owner;
+                    gm0_e = g0;
+                    gm1_e = g1;
+                    pm_e = pmo;
+                    a_eval = ph_o == PH_GRID1 ? ((hk == 19) ? ghi : glo + hk * gstep)
+                                              : ((hk == 19) ? ghat_o + gstep : (ghat_o - gstep) + hk * (2.0 * gstep / 19.0));
+                }
+            }
+        }
+
         // ---- evaluate -------------------------------------------------------------------------
         double l_new = 0, dl_new = 0, alpha_new = 0;
         const bool active = phase != PH_DONE && phase != PH_NEED;
         const unsigned long long actmask = __ballot(active);
-        if (queue_empty && spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) {
+        if (burst_owner < 0 && queue_empty && spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) {
             eval_point_spread(s_nf, s_y, lane, S, spread_lg, gmask, p2, o.minmu, actmask, active, a_eval, gm0, gm1, MAP,
                               prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab);
-        } else if (active) {
-            eval_point(s_nf, s_y, s_tab, lane, S, gmask, p2, gm0, gm1, o.minmu, a_eval, MAP, prior_mean, prior_isig, l_new,
+        } else if (active || helper) {
+            eval_point(s_nf, s_y, s_tab, lane, slot, S, gmask, p2, gm0_e, gm1_e, o.minmu, a_eval, MAP, pm_e, prior_isig, l_new,
                        dl_new, alpha_new, s_logtab);
+        }
+        bool burst_done = false;  // this lane owns the burst: l_new / hk now describe the best of the 20 points
+        if (burst_owner >= 0) {
+            const bool part = helper || lane == burst_owner;
+            double bl = (part && l_new == l_new) ? l_new : -INFINITY;  // NaN never beats anything (l_new > gbest is false)
+            int bk = part ? hk : 99;                                     // the owner evaluated point 0
+            for (int off = 1; off < 64; off <<= 1) {
+                const double ol = __shfl_xor(bl, off);
+                const int ok = __shfl_xor(bk, off);
+                if (ol > bl || (ol == bl && ok < bk)) { bl = ol; bk = ok; }  // first maximum
+            }
+            if (lane == burst_owner) {
+                burst_done = true;
+                l_new = bl;
+                hk = bk < 20 ? bk : 0;
+            }
         }
 
         // ---- advance the per-lane state machine ---------------------------------------------
@@ -584,11 +631,19 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                 }
             }
         } else if (phase == PH_GRID1 || phase == PH_GRID2) {
-            if (l_new > gbest) {
-                gbest = l_new;
-                gbi = gt;
+            if (burst_done) {  // all 20 points at once (gbest was -inf, gbi 0)
+                if (l_new > gbest) {
+                    gbest = l_new;
+                    gbi = hk;
+                }
+                gt = 20;
+            } else {
+                if (l_new > gbest) {
+                    gbest = l_new;
+                    gbi = gt;
+                }
+                gt++;
             }
-            gt++;
             if (gt == 20) {
                 if (phase == PH_GRID1) {
                     ghat = (gbi == 19) ? ghi : glo + gbi * gstep;
