@@ -516,25 +516,27 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         }
 
         // ---- grid burst -------------------------------------------------------------------------
-        // The 20 points of a fitDispGrid stage are independent evaluations.  Once the queue is empty and at least 19
-        // lanes of the wave have nothing left to do, they evaluate points 1..19 of the lowest lane that is about to
-        // start a stage (its row sits in that lane's LDS column) while it evaluates point 0 itself: 40 serial ticks
-        // of a straggler become 2.  Same eval_point(), same first-maximum rule: identical bits.
-        int burst_owner = -1, slot = lane, hk = 0;
+        // The 20 points of a fitDispGrid stage are independent evaluations.  Once the queue is empty, lanes of the wave
+        // that have nothing left to do evaluate the next points of the lowest lane that is inside a stage (its row sits
+        // in that lane's LDS column) while it evaluates its current point itself: with 19 idle lanes the 40 serial
+        // ticks of a straggler become 2.  Same eval_point(), same first-maximum rule: identical bits.
+        int burst_owner = -1, slot = lane, hk = 0, nhelp = 0;
         bool helper = false;
         double gm0_e = gm0, gm1_e = gm1, pm_e = prior_mean;
         if (queue_empty && A.spread) {
-            const unsigned long long starting = __ballot((phase == PH_GRID1 || phase == PH_GRID2) && gt == 0);
+            const unsigned long long ingrid = __ballot(phase == PH_GRID1 || phase == PH_GRID2);
             const unsigned long long idle = __ballot(phase == PH_DONE);
-            if (starting && __popcll(idle) >= 19) {
-                burst_owner = __ffsll((long long)starting) - 1;
-                const int ph_o = __shfl(phase, burst_owner);
+            if (ingrid && idle) {
+                burst_owner = __ffsll((long long)ingrid) - 1;
+                const int ph_o = __shfl(phase, burst_owner), gt_o = __shfl(gt, burst_owner);
                 const double ghat_o = __shfl(ghat, burst_owner);
                 const double g0 = __shfl(gm0, burst_owner), g1 = __shfl(gm1, burst_owner), pmo = __shfl(prior_mean, burst_owner);
+                const int nidle = __popcll(idle);
+                nhelp = 19 - gt_o < nidle ? 19 - gt_o : nidle;  // points gt_o+1 .. gt_o+nhelp go to idle lanes
                 const int r = __popcll(idle & ((1ull << lane) - 1ull));
-                if (phase == PH_DONE && r < 19) {
+                if (phase == PH_DONE && r < nhelp) {
                     helper = true;
-                    hk = r + 1;
+                    hk = gt_o + r + 1;
                     slot = burst_owner;
                     gm0_e = g0;
                     gm1_e = g1;
@@ -542,6 +544,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     a_eval = ph_o == PH_GRID1 ? ((hk == 19) ? ghi : glo + hk * gstep)
                                               : ((hk == 19) ? ghat_o + gstep : (ghat_o - gstep) + hk * (2.0 * gstep / 19.0));
                 }
+                if (nhelp == 0) burst_owner = -1;  // the owner is on its last point
             }
         }
 
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         if (burst_owner >= 0) {
             const bool part = helper || lane == burst_owner;
             double bl = (part && l_new == l_new) ? l_new : -INFINITY;  // NaN never beats anything (l_new > gbest is false)
-            int bk = part ? hk : 99;                                     // the owner evaluated point 0
+            int bk = part ? (helper ? hk : gt) : 99;                     // the owner evaluated its point gt
             for (int off = 1; off < 64; off <<= 1) {
                 const double ol = __shfl_xor(bl, off);
                 const int ok = __shfl_xor(bk, off);
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             if (lane == burst_owner) {
                 burst_done = true;
                 l_new = bl;
-                hk = bk < 20 ? bk : 0;
+                hk = bk < 20 ? bk : gt;
             }
         }
 
@@ -631,12 +634,12 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                 }
             }
         } else if (phase == PH_GRID1 || phase == PH_GRID2) {
-            if (burst_done) {  // all 20 points at once (gbest was -inf, gbi 0)
+            if (burst_done) {  // points gt .. gt+nhelp at once; an earlier point keeps a tie (strict >, as one by one)
                 if (l_new > gbest) {
                     gbest = l_new;
                     gbi = hk;
                 }
-                gt = 20;
+                gt += nhelp + 1;
             } else {
                 if (l_new > gbest) {
                     gbest = l_new;
