@@ -316,7 +316,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     const size_t hist = align256(sizeof(double) * (size_t)kMaxS * 2 * kSelBins);
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
     const size_t selcnt = align256(sizeof(double) * (size_t)kSelMaxWorld * kMaxS * 2);
-    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + 2 * hist + selcnt + align256(sizeof(FitScalars)) + 256 + nfbytes;
+    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + 2 * hist + selcnt + align256(sizeof(FitScalars)) + 256 + 1024 + nfbytes;
     hipError_t e = hipMalloc(&c->ws, total);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "workspace of %zu bytes: %s", total, hipGetErrorString(e));
     c->ws_bytes = total;
@@ -335,6 +335,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     w.sc = (FitScalars *)p; p += align256(sizeof(FitScalars));
     w.logfact = c->d_logfact;
     w.queue = (unsigned long long *)p; p += 256;
+    w.barrier = (unsigned int *)p; p += 1024;
     c->d_nf_tmp = (double *)p;
     c->cap_n = n;
     c->cap_S = S;

@@ -27,6 +27,7 @@ struct FitWork {
     double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut
     double *selcnt;               // kSelMaxWorld x kMaxS*2 doubles: per-rank candidate counts
     unsigned long long *queue;    // work-queue heads
+    unsigned int *barrier;        // 9 x 64 B: grid-barrier counters of the persistent trend kernel
     FitScalars *sc;
     const double *logfact;        // log(k!) for k < kLogFactN
 };

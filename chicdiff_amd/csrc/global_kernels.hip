@@ -97,17 +97,28 @@ __global__ void trend_step_kernel(FitWork w) { trend_step(w.sc, w.partials + (si
 // of the state machine (fit_state.h) — identical in all workgroups, no broadcast needed.
 constexpr int kTpBlocks = 256, kTpThreads = 1024, kTpCap = 8000;  // rows cached per workgroup (2 x 64 000 B of LDS)
 
-__device__ __forceinline__ bool grid_sync(unsigned int *ctr, unsigned int target) {
+// Two-level grid barrier: workgroups arrive at one of 8 group counters (blockIdx % 8, i.e. one per XCD under
+// round-robin dispatch — different cache lines, so the arrivals of different groups do not serialise behind one
+// another), the last arrival of a group bumps the top counter, everybody polls the top counter.  256 atomics on
+// one word cost ~10 us per barrier; this way the longest chain is 32 + 8.  `pass` counts barriers from 0.
+__device__ __forceinline__ bool grid_sync(unsigned int *top, unsigned int *groups, unsigned int pass) {
     __shared__ int ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
+        const unsigned int nblk = gridDim.x, g = blockIdx.x & 7u;
+        const unsigned int ngroups = nblk < 8u ? nblk : 8u, gsize = (nblk - g + 7u) >> 3;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int old = __hip_atomic_fetch_add(groups + g * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // 64-byte stride
+        if (old + 1u == (pass + 1u) * gsize) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned int target = (pass + 1u) * ngroups;
         int spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < (1 << 24)) {
-            __builtin_amdgcn_s_sleep(4);
+        while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < (1 << 24)) {
+            __builtin_amdgcn_s_sleep(2);
             spins++;
         }
         ok = spins < (1 << 24);  // a bounded spin: a lost workgroup must not hang the device
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
     }
     if (tid == 0) trend_init(&st);
     __syncthreads();
-    unsigned int *ctr = reinterpret_cast<unsigned int *>(w.queue + 8);
+    unsigned int *ctr = reinterpret_cast<unsigned int *>(w.barrier), *grp = ctr + 16;  // top counter, then 8 group counters 64 B apart
     double *slots = w.partials;  // [2][gridDim.x][kTrendSums], double-buffered by pass parity
     bool alive = true;
     for (unsigned int pass = 0; pass < 11 * 27 + 16; pass++) {
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
             for (int q = 0; q < kTpThreads / 64; q++) acc += red[tid][q];
             mine[tid] = acc;
         }
-        alive = grid_sync(ctr, (pass + 1) * gridDim.x);
+        alive = grid_sync(ctr, grp, pass);
         if (!alive) break;
         // every workgroup: fixed-order sum of all partials (wave k sums quantity k: 64 lanes x strided
         // partials, then a shuffle tree — the same order in every workgroup), then the same state-machine step
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
 }
 int trend_persistent_blocks() { return kTpBlocks; }
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
-    (void)hipMemsetAsync(w.queue + 8, 0, 8, st);
+    (void)hipMemsetAsync(w.barrier, 0, 64 * 9, st);
     // as few workgroups as keep every row LDS-resident: the pass time is the grid barrier plus the all-partials sum,
     // both of which grow with the number of workgroups (small fits are latency-bound by these ~20 passes)
     int64_t blocks = (d.n + kTpCap - 1) / kTpCap;
