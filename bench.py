@@ -215,6 +215,7 @@ def main():
     alg_bytes = algorithmic_bytes(S) * n
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = None
+    valu = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
@@ -222,10 +223,15 @@ def main():
             ent = pj.get(f"{dom_name}:{n}x{S}")
             if ent:
                 traffic = ent["hbm_bytes_per_launch"]
+                if "valu" in ent:  # what actually bounds the kernel: wave-level VALU instructions against the issue slots of the launch
+                    slots = avg_ms * 1e-3 * 1024 * 2.4e9 / 4  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+                    valu = {"insts_per_launch": ent["valu"]["SQ_INSTS_VALU"], "issue_slot_fraction": round(ent["valu"]["SQ_INSTS_VALU"] / slots, 3),
+                            "active_lanes_per_inst": ent["valu"]["active_lanes_per_inst"], "source": ent["valu"]["source"]}
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac_of_measured_stream_6290": round(achieved / 6290.0, 5), "valu": valu,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "fit kernels are fp64-VALU/transcendental bound (~4e4 flop per interaction), not HBM bound; "
                         "see kernels_ms for the whole step"}

@@ -25,5 +25,15 @@ df["k"] = df["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("cd
 g = df.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
 g.to_csv("$OUT/${TAG}_pmc_sq_bench_2Mx8.csv")
 print(g.to_string())
+import json
+tj = json.load(open("$OUT/pmc_traffic.json"))
+names = {"disp_gene": "disp_fit_kernel<false, 2>", "disp_map": "disp_fit_kernel<true, 2>", "wald_irls": "wald_irls_kernel"}
+for k, kn in names.items():
+    key = k + ":2000000x8"
+    if key in tj and kn in g.index:
+        r = g.loc[kn]
+        tj[key]["valu"] = {"SQ_INSTS_VALU": float(r["SQ_INSTS_VALU"]), "active_lanes_per_inst": round(float(r["SQ_THREAD_CYCLES_VALU"] / r["SQ_INSTS_VALU"]), 1),
+                           "source": "profiles/${TAG}_pmc_sq_bench_2Mx8.csv"}
+json.dump(tj, open("$OUT/pmc_traffic.json", "w"), indent=1)
 PY
 tail -1 $OUT/bench.json
