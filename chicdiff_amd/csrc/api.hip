@@ -466,8 +466,8 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     int rc;
     hipStream_t st = c->stream;
     FitWork &w = c->w;
-    HIPCHK(c, hipMemsetAsync(w.queue, 0, 256, st));
-    HIPCHK(c, hipMemsetAsync(w.sc, 0, sizeof(FitScalars), st));
+    // the scalars, the queue heads and the barrier counters sit next to each other in the workspace: one fill
+    HIPCHK(c, hipMemsetAsync(w.sc, 0, align256(sizeof(FitScalars)) + 256 + 1024, st));
     {
         Scope t(c, "prep");
         launch_prep(d_counts, d_nf, d, w, o, st);

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
 }
 int trend_persistent_blocks() { return kTpBlocks; }
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
-    (void)hipMemsetAsync(w.barrier, 0, 64 * 9, st);
+    // (the barrier counters were zeroed with the fit's scalars; the trend runs once per fit)
     // as few workgroups as keep every row LDS-resident: the pass time is the grid barrier plus the all-partials sum,
     // both of which grow with the number of workgroups (small fits are latency-bound by these ~20 passes)
     int64_t blocks = (d.n + kTpCap - 1) / kTpCap;
