@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ctx():
+    import __graft_entry__ as g
+    g.build()  # no-op when the in-tree library and the oracle are up to date (they travel with the snapshot)
     from chicdiff_amd import hip
     c = hip.HipContext(0)
     yield c
