@@ -406,9 +406,13 @@ struct HipBackend {
         Scope t(c, "select_shortcut");
         sa.shift = 40;
         launch_sel_shortcut(sa, c->w, c->stream);
+        finished_by_shortcut = true;  // its last kernel also did what sel_finish does
         return true;
     }
-    void sel_finish(const SelSpec &) { launch_sel_finish(sa, c->w, c->stream); }
+    bool finished_by_shortcut = false;
+    void sel_finish(const SelSpec &) {
+        if (!finished_by_shortcut) launch_sel_finish(sa, c->w, c->stream);
+    }
     // sharded shortcut
     int world_size() const { return c->world; }
     bool sel_can_gather() const { return c->world <= kSelMaxWorld && !getenv("CHICDIFF_SELECT_SIXROUNDS"); }
@@ -644,10 +648,8 @@ static int size_factors_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, int64
     sa.n = n;
     sa.ratio = c->d_nf_tmp;
     sa.S = S;
-    int rc = run_select(c, sa);
-    if (rc) return rc;
-    launch_gather_sf(c->w, S, c->d_sf, c->stream);
-    return CHICDIFF_OK;
+    sa.sf_out = c->d_sf;  // the finishing step of the select writes the size factors there
+    return run_select(c, sa);
 }
 
 int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S, double *sf_host) {

@@ -70,6 +70,7 @@ struct SelArgs {
     const double *ratio;    // SEL_SIZEFACTOR: log(count) - row log geometric mean, S x n (NaN = excluded)
     int S;
     int shift;              // bit position of the current digit
+    double *sf_out;         // SEL_SIZEFACTOR: where the size factors go as well (device, may be NULL)
 };
 void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st);     // digit histograms for the live prefixes
 void launch_sel_step(SelArgs a, FitWork w, hipStream_t st);     // pick bins, extend prefixes
@@ -81,7 +82,6 @@ void launch_sel_gather_counts(SelArgs a, FitWork w, int world, int rank, hipStre
 void launch_sel_gather_place(SelArgs a, FitWork w, int world, int rank, hipStream_t st);
 void launch_sel_gather_finish(SelArgs a, FitWork w, int world, int rank, hipStream_t st);
 
-void launch_gather_sf(FitWork w, int S, double *d_sf, hipStream_t st);  // select results -> sf[S]
 void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, hipStream_t st);  // keys of the size-factor medians
 void launch_offsets(const double *fullMean, const double *sf_dev, int64_t n, int S, double theta, int mix,
                     double *out, hipStream_t st);

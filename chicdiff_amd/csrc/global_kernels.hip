@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void sel_step_kernel(SelArgs a, FitWork w, int
     const bool first = sel_first_round(a.shift);
     if (!first && sc->sel_fast_done) return;
     if (first && col == 0 && threadIdx.x == 0) sc->sel_fast_done = 0;  // (read again only after later launches)
+    if (a.shift == 40 && threadIdx.x < 2) sc->sel_cnt[2 * col + threadIdx.x] = 0;  // write positions of the compaction that follows
     const uint64_t p0 = first ? 0 : sc->sel_prefix[2 * col], p1 = first ? 0 : sc->sel_prefix[2 * col + 1];
     double rank0 = sc->sel_rank[2 * col], rank1 = sc->sel_rank[2 * col + 1];
     const int nb = 1 << bits, per = (nb + 255) / 256;
@@ -366,13 +367,19 @@ __global__ __launch_bounds__(256) void sel_compact_kernel(SelArgs a, FitWork w) 
         if (pos < (unsigned)kSelCap) cand[(size_t)slot * kSelCap + pos] = key;
     }
 }
+__device__ __forceinline__ void sel_tail_rounds(const SelArgs &a, FitScalars *sc, int col, unsigned int *h);
+__device__ __forceinline__ void sel_finish_col(const SelArgs &a, FitScalars *sc, int c);
 __global__ __launch_bounds__(256) void sel_small_kernel(SelArgs a, FitWork w) {
     __shared__ uint64_t s_k[kSelCap];
     FitScalars *sc = w.sc;
     bool fits = true;
     for (int q = 0; q < 2 * a.ncol; q++) fits &= sc->sel_cnt[q] <= (unsigned)kSelCap;  // same verdict in every block
-    if (!fits) return;  // the remaining radix rounds take over
     const int col = blockIdx.x;
+    if (!fits) {  // massive ties: this column's remaining radix rounds, here and now
+        sel_tail_rounds(a, sc, col, reinterpret_cast<unsigned int *>(s_k));
+        if (threadIdx.x == 0) sel_finish_col(a, sc, col);
+        return;
+    }
     const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
     const uint64_t *cand = reinterpret_cast<const uint64_t *>(w.hist) + (size_t)col * 2 * kSelCap;
     uint64_t result[2] = {p0, p1};
@@ -405,46 +412,45 @@ __global__ __launch_bounds__(256) void sel_small_kernel(SelArgs a, FitWork w) {
         sc->sel_prefix[2 * col] = result[0];
         sc->sel_prefix[2 * col + 1] = result[1];
         if (col == 0) sc->sel_fast_done = 1;
+        sel_finish_col(a, sc, col);  // (a column's order statistics and what follows from them are its own)
     }
 }
 
 // The shortcut's own fallback: more than kSelCap candidates share 24 key bits with a median (massive ties).
-// One block per column runs the four remaining radix rounds by itself — slow (one block scans all n), but
-// it keeps the host from launching those rounds every time just in case.
-__global__ __launch_bounds__(1024) void sel_tail_kernel(SelArgs a, FitWork w) {
-    __shared__ unsigned int h[2][kSelBins];
+// The column's workgroup runs the four remaining radix rounds by itself — slow (one workgroup scans all n), but it
+// keeps the host from launching those rounds every time just in case.  `h` : 2 x kSelBins counters in LDS.
+__device__ __forceinline__ void sel_tail_rounds(const SelArgs &a, FitScalars *sc, int col, unsigned int *h) {
     __shared__ uint64_t s_pre[2];
     __shared__ double s_rank[2];
-    FitScalars *sc = w.sc;
-    if (sc->sel_fast_done) return;
-    const int col = blockIdx.x;
+    const int nthr = blockDim.x;
     if (threadIdx.x < 2) {
         s_pre[threadIdx.x] = sc->sel_prefix[2 * col + threadIdx.x];
         s_rank[threadIdx.x] = sc->sel_rank[2 * col + threadIdx.x];
     }
     for (int r = 2; r < 6; r++) {
         const int shift = kSelShifts[r], bits = sel_bits(shift), hi = shift + bits;
-        for (int k = threadIdx.x; k < 2 * kSelBins; k += 1024) (&h[0][0])[k] = 0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < 2 * kSelBins; k += nthr) h[k] = 0;
         __syncthreads();
         const uint64_t p0 = s_pre[0], p1 = s_pre[1], mask = (1ull << bits) - 1ull;
         const bool same = p0 == p1;
         uint64_t key;
-        for (int64_t i = threadIdx.x; i < a.n; i += 1024) {
+        for (int64_t i = threadIdx.x; i < a.n; i += nthr) {
             if (!sel_key(a, sc, col, i, key)) continue;
             const unsigned dig = (unsigned)((key >> shift) & mask);
-            if (sel_match(key, p0, hi)) atomicAdd(&h[0][dig], 1u);
-            else if (!same && sel_match(key, p1, hi)) atomicAdd(&h[1][dig], 1u);
+            if (sel_match(key, p0, hi)) atomicAdd(&h[dig], 1u);
+            else if (!same && sel_match(key, p1, hi)) atomicAdd(&h[kSelBins + dig], 1u);
         }
         __syncthreads();
-        if (threadIdx.x < 2) {  // fit_state.h sel_pick, on the block's own histogram
+        if (threadIdx.x < 2) {  // fit_state.h sel_pick, on the workgroup's own histogram
             const int slot = threadIdx.x, hslot = (slot == 1 && !same) ? 1 : 0;
             const double rank = s_rank[slot];
             const int nb = 1 << bits;
             double cum = 0;
             int b = 0;
             for (; b < nb - 1; b++) {
-                if (cum + (double)h[hslot][b] > rank) break;
-                cum += (double)h[hslot][b];
+                if (cum + (double)h[hslot * kSelBins + b] > rank) break;
+                cum += (double)h[hslot * kSelBins + b];
             }
             s_pre[slot] = (slot ? p1 : p0) | ((uint64_t)b << shift);
             s_rank[slot] = rank - cum;
@@ -452,6 +458,22 @@ __global__ __launch_bounds__(1024) void sel_tail_kernel(SelArgs a, FitWork w) {
         __syncthreads();
     }
     if (threadIdx.x < 2) sc->sel_prefix[2 * col + threadIdx.x] = s_pre[threadIdx.x];
+    __syncthreads();
+}
+// prefixes -> order statistics -> what the select was for (one thread per column)
+__device__ __forceinline__ void sel_finish_col(const SelArgs &a, FitScalars *sc, int c) {
+    const double med = sel_median(sc, c);
+    sc->sel_value[2 * c] = value_of(sc->sel_prefix[2 * c]);
+    sc->sel_value[2 * c + 1] = value_of(sc->sel_prefix[2 * c + 1]);
+    if (a.mode == SEL_RESID) {
+        sc->med = med;
+        sc->nres = sc->sel_count[c];
+    } else if (a.mode == SEL_ABSDEV) {
+        sc->mad = 1.4826 * med;  // R mad(): constant 1.4826
+    } else {
+        sc->sel_value[2 * c] = exp(med);  // size factor of column c
+        if (a.sf_out) a.sf_out[c] = sc->sel_value[2 * c];
+    }
 }
 
 // ---- sharded shortcut (protocol and layout: fit_state.h) -------------------------------------------------------
@@ -536,20 +558,7 @@ __global__ __launch_bounds__(256) void sel_gfinish_kernel(SelArgs a, FitWork w, 
 }
 
 __global__ void sel_finish_kernel(SelArgs a, FitWork w) {
-    const int c = threadIdx.x;
-    if (c >= a.ncol) return;
-    FitScalars *sc = w.sc;
-    const double med = sel_median(sc, c);
-    sc->sel_value[2 * c] = value_of(sc->sel_prefix[2 * c]);
-    sc->sel_value[2 * c + 1] = value_of(sc->sel_prefix[2 * c + 1]);
-    if (a.mode == SEL_RESID) {
-        sc->med = med;
-        sc->nres = sc->sel_count[c];
-    } else if (a.mode == SEL_ABSDEV) {
-        sc->mad = 1.4826 * med;  // R mad(): constant 1.4826
-    } else {
-        sc->sel_value[2 * c] = exp(med);  // size factor of column c
-    }
+    if ((int)threadIdx.x < a.ncol) sel_finish_col(a, w.sc, threadIdx.x);
 }
 
 static int sel_blocks(int64_t n) {
@@ -568,10 +577,8 @@ void launch_sel_step(SelArgs a, FitWork w, hipStream_t st) {
     sel_step_kernel<<<a.ncol, 256, 0, st>>>(a, w, bits);
 }
 void launch_sel_shortcut(SelArgs a, FitWork w, hipStream_t st) {
-    (void)hipMemsetAsync(w.sc->sel_cnt, 0, sizeof(uint32_t) * 2 * a.ncol, st);
-    sel_compact_kernel<<<dim3(sel_blocks(a.n), a.ncol), 256, 0, st>>>(a, w);
-    sel_small_kernel<<<a.ncol, 256, 0, st>>>(a, w);
-    sel_tail_kernel<<<a.ncol, 1024, 0, st>>>(a, w);
+    sel_compact_kernel<<<dim3(sel_blocks(a.n), a.ncol), 256, 0, st>>>(a, w);  // (sel_cnt was zeroed by the round-2 step)
+    sel_small_kernel<<<a.ncol, 256, 0, st>>>(a, w);  // sort + pick, or the fallback rounds; then the column's finish
 }
 void launch_sel_finish(SelArgs a, FitWork w, hipStream_t st) { sel_finish_kernel<<<1, 64, 0, st>>>(a, w); }
 void launch_sel_keep_local(SelArgs a, FitWork w, hipStream_t st) {
@@ -589,10 +596,6 @@ void launch_sel_gather_finish(SelArgs a, FitWork w, int world, int rank, hipStre
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void gather_sf_kernel(FitWork w, int S, double *sf) {
-    if ((int)threadIdx.x < S) sf[threadIdx.x] = w.sc->sel_value[2 * threadIdx.x];
-}
-void launch_gather_sf(FitWork w, int S, double *d_sf, hipStream_t st) { gather_sf_kernel<<<1, 64, 0, st>>>(w, S, d_sf); }
 
 // a5 helper: the keys of the size-factor medians, computed once: ratio[j][i] = log(counts[j][i]) -
 // rowMeans(log(counts))[i] for rows without a zero count (estimateSizeFactorsForMatrix uses only rows with

@@ -78,6 +78,11 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own ROCm runtime (libamdhip64 & co.), and whichever copy is loaded first serves the
+    # whole process.  Loading this library before torch would bind everybody to /opt/rocm's copy, which torch's
+    # build does not match ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+
     path = os.environ.get("CHICDIFF_HIP_LIB", LIB_PATH)  # (override: A/B runs of two builds)
     if not os.path.exists(path):
         raise ChicdiffHipError(
