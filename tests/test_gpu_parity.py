@@ -909,3 +909,40 @@ def test_results_on_device(ctx, golden, oracle):
     dpv = dev(pv)
     nout = ctx.cooks_filter(ctx.to_device(d["counts"], np.int32), group, dev(mc), dev(am, np.int32), dpv, 2.5)
     assert nout == ref_n > 0 and np.array_equal(dpv.cpu().numpy(), ref_p, equal_nan=True)
+
+
+def test_fit_fuzz_shapes_and_designs(ctx, oracle):
+    """Random sample counts, group splits and row counts (both designs) against the oracle: every configuration must
+    agree on the NA pattern and on >= 99 % of the rows to 1e-6 (small n makes single noise-decided rows visible)."""
+    rng = np.random.default_rng(2024)
+    worst = 1.0
+    for trial in range(14):
+        S = int(rng.integers(3, 21))
+        n = int(rng.integers(800, 4000))
+        d = synth.make(n, S, start=int(rng.integers(0, 10 ** 6)))
+        if trial % 4 == 3:
+            group = np.zeros(S, dtype=np.int32)  # design ~1
+        else:
+            nB = int(rng.integers(1, S - 1))
+            group = np.zeros(S, dtype=np.int32)
+            group[rng.choice(S, nB, replace=False)] = 1
+            if S - nB < 1 or S <= 2:
+                continue
+        ref = oracle.nbglm_fit(d["counts"], d["nf"], group)
+        got, sc = run_fit(ctx, d, group)
+        assert bool(sc["status"] & 1) == bool(ref["status"] & 1), (trial, S, n)
+        if ref["status"] & 1:
+            continue
+        nz = ref["allZero"] == 0
+        assert np.array_equal(got["allZero"], ref["allZero"])
+        assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6), (trial, sc["trendCoef"], ref["trendCoef"])
+        r = rel(got["dispersion"][nz], ref["dispersion"][nz])
+        worst = min(worst, float(np.mean(r < 1e-6)))
+        assert np.mean(r < 1e-6) > 0.99, (trial, S, n, group.tolist())
+        if group.any():
+            conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
+            rp = rel(got["pvalue"][conv], ref["pvalue"][conv])
+            assert np.mean(rp < 1e-6) > 0.99 and np.array_equal(np.isnan(got["pvalue"]), np.isnan(ref["pvalue"])), (trial, S, n)
+        else:
+            assert np.isclose(sc["sumDeviance"], ref["sumDeviance"], rtol=1e-6, equal_nan=True)
+    print("fuzz: worst fraction of rows within 1e-6:", worst)
