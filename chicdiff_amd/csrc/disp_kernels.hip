@@ -146,7 +146,7 @@ __global__ void xim_kernel(FitDims d, FitWork w) {
 
 constexpr int kColsumBlocks = 512;  // per column; (S+1) x 512 partials fit the 1024 x 72 partials buffer for S <= 64
 void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts, hipStream_t st) {
-    if (d.S <= 16) prep16_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
+    if (d.S <= 16) prep16_kernel<<<768, 256, 0, st>>>(counts, nf, d, w);  // one resident round: 149 VGPRs = 3 workgroups per CU
     else prep_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
     colsum_kernel<<<dim3(kColsumBlocks, d.S + 1), 256, 0, st>>>(nf, d, w);
 }
