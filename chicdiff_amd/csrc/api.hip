@@ -28,6 +28,7 @@ struct KTimer {
 
 struct chicdiff_hip_ctx {
     int device = 0;
+    bool no_persistent_trend = false;  // set after a grid-barrier timeout (see fit_dev_impl)
     int cu_count = 0;  // compute units of the device (the persistent trend kernel needs one resident workgroup per CU it launches)
     hipStream_t own_stream = nullptr, stream = nullptr;
     chicdiff_allreduce_fn allreduce = nullptr;
@@ -488,7 +489,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_trend_init(d, w, o, st);
         HIPCHK(c, hipMemcpyAsync(w.sc->coefs, o.trendIn, sizeof(double) * 2, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));  // o.trendIn lives on this frame
-    } else if (!c->allreduce && c->cu_count >= trend_persistent_blocks() && !getenv("CHICDIFF_TREND_MULTILAUNCH")) {
+    } else if (!c->allreduce && !c->no_persistent_trend && c->cu_count >= trend_persistent_blocks() && !getenv("CHICDIFF_TREND_MULTILAUNCH")) {
         Scope t(c, "trend_fit");  // single rank: one persistent launch (LDS-resident rows, grid barrier per IRLS pass)
         launch_trend_persistent(d, w, o, st);  // no host round trip: `failed` comes back with the final scalars
     } else {
@@ -555,7 +556,13 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     HIPCHK(c, hipMemcpyAsync(hs, sums_of(w), sizeof hs, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
-    if (c->h_sc->failed == 3) return fail(c, CHICDIFF_E_HIP, "trend fit: grid barrier timed out");
+    if (c->h_sc->failed == 3) {
+        // the persistent trend kernel's workgroups were not all resident within the barrier's patience (a GPU shared
+        // with other work): fit again with one launch per IRLS pass, and stay with that for this context
+        if (c->no_persistent_trend) return fail(c, CHICDIFF_E_HIP, "trend fit: grid barrier timed out");
+        c->no_persistent_trend = true;
+        return fit_dev_impl(c, d_counts, d_nf, d, o, d_out, scalars);
+    }
     if (c->h_sc->failed) status |= CHICDIFF_ST_TREND_FAILED;
     if (scalars) {
         const FitScalars *s = c->h_sc;
