@@ -10,12 +10,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include <dlfcn.h>
 
 #include "common.h"
+#include "prior_mc.h"
 
 using namespace cd;
 
@@ -501,6 +503,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         if (trc == -2) return fail(c, CHICDIFF_E_NUMERIC, "trend state machine did not finish");
     }
     int status = 0;
+    const bool prior_by_simulation = !(o.dispPriorVarIn == o.dispPriorVarIn) && d.S - d.p <= 3 && d.S > d.p;
     // MAD of the log residuals
     launch_dispfit_resid(d, w, o, st);
     SelArgs sa{};
@@ -513,6 +516,28 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         if ((rc = run_select(c, sa))) return rc;
         sa.mode = SEL_ABSDEV;
         if ((rc = run_select(c, sa))) return rc;
+        if (prior_by_simulation) {
+            // residual d.f. <= 3: DESeq2 matches the prior variance by simulation (prior_mc.h).  One small histogram
+            // leaves the device, the 200 x 40 simulated densities are constants built once per process and d.f.
+            double *d_hist = sums_of(w) + 32, h_hist[kPmcBins];
+            launch_resid_hist(d, w, d_hist, st);
+            if ((rc = do_allreduce(c, d_hist, kPmcBins))) return rc;
+            HIPCHK(c, hipMemcpyAsync(h_hist, d_hist, sizeof h_hist, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            static PmcTable tables[4];
+            static bool ready[4] = {false, false, false, false};
+            static std::mutex mu;
+            const int df = d.S - d.p;
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                if (!ready[df]) {
+                    pmc_build(df, tables[df]);
+                    ready[df] = true;
+                }
+            }
+            const double pv = pmc_prior_var(h_hist, tables[df]);
+            if (pv == pv) o.dispPriorVarIn = pv;  // (no residuals at all: the closed form's 0.25 floor)
+        }
         launch_prior_var(d, w, o, st);
     }
     {
@@ -575,7 +600,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         scalars->trendOuterIter = s->outer_it;
         if (hs[2] > 0) status |= CHICDIFF_ST_ALLZERO_ROWS;
         if (hs[1] > 0) status |= CHICDIFF_ST_BETA_NONCONV;
-        if (!(o.dispPriorVarIn == o.dispPriorVarIn) && d.S - d.p <= 3) status |= CHICDIFF_ST_PRIORVAR_MC;
+        if (prior_by_simulation) status |= CHICDIFF_ST_PRIORVAR_MC;
         scalars->status = status;
     }
     return CHICDIFF_OK;

@@ -240,6 +240,28 @@ void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st) {
     resid_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp);
 }
 
+// 40-bin histogram of the log dispersion residuals inside (-10, 10) (hist(breaks = -20:20/2), right-closed): input of
+// the simulation-matched prior variance for residual d.f. <= 3 (prior_mc.h).  Counts as doubles: a sum-all-reducible
+// statistic like the others.
+__global__ __launch_bounds__(256) void resid_hist_kernel(FitDims d, FitWork w, double *out) {
+    __shared__ unsigned int h[40];
+    if (threadIdx.x < 40) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+        const double x = w.resid[i];
+        if (!(x > -10.0 && x < 10.0)) continue;  // NaN = not part of the fit
+        int b = (int)ceil((x + 10.0) * 2.0) - 1;
+        b = b < 0 ? 0 : (b > 39 ? 39 : b);
+        atomicAdd(&h[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 40 && h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (double)h[threadIdx.x]);
+}
+void launch_resid_hist(FitDims d, FitWork w, double *out40, hipStream_t st) {
+    (void)hipMemsetAsync(out40, 0, sizeof(double) * 40, st);
+    resid_hist_kernel<<<256, 256, 0, st>>>(d, w, out40);
+}
+
 // estimateDispersionsPriorVar, closed-form branch (A4): fit_state.h
 __global__ void prior_var_kernel(FitDims d, FitWork w, double prior_in) { prior_var(w.sc, d.S, d.p, prior_in); }
 void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st) {

@@ -38,7 +38,7 @@ extern "C" {
 
 /* status bits reported in chicdiff_nbglm_scalars.status (fit completed, with caveats) */
 #define CHICDIFF_ST_TREND_FAILED 1 /* parametric trend failed; DESeq2 would switch to locfit   */
-#define CHICDIFF_ST_PRIORVAR_MC 2  /* m-p<=3 and no dispPriorVar given: closed form used        */
+#define CHICDIFF_ST_PRIORVAR_MC 2  /* m-p<=3 and no dispPriorVar given: matched by simulation as in DESeq2, from a fixed-seed stream (R's own draws are unseeded) */
 #define CHICDIFF_ST_BETA_NONCONV 4 /* some rows hit betaMaxit (DESeq2 would call optim)        */
 #define CHICDIFF_ST_ALLZERO_ROWS 8 /* some rows are all zero: their outputs are NaN (R: NA)    */
 

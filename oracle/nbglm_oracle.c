@@ -551,6 +551,12 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
         if (!allZero[i] && dispGene[i] >= 100 * o.minDisp) fm[nres++] = log(dispGene[i]) - log(dispFit[i]);
     }
     memcpy(fd, fm, sizeof(double) * (size_t)nres);
+    double obs_hist[40];
+    memset(obs_hist, 0, sizeof obs_hist);
+    for (int64_t k = 0; k < nres; k++) {
+        const int b = oracle_prior_mc_bin(fm[k]);
+        if (b >= 0) obs_hist[b] += 1;
+    }
     double med = oracle_median(fd, nres);
     for (int64_t k = 0; k < nres; k++) fd[k] = fabs(fm[k] - med);
     double madv = 1.4826 * oracle_median(fd, nres);
@@ -562,8 +568,11 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
     /* A4 estimateDispersionsPriorVar */
     double dispPriorVar = o.dispPriorVar;
     if (isnan(dispPriorVar)) {
-        if (m - p <= 3) status |= ORACLE_ST_PRIORVAR_MC; /* DESeq2: R-RNG Monte Carlo + loess; closed form used */
-        dispPriorVar = fmax(varLogDispEsts - oracle_trigamma((m - p) / 2.0), 0.25);
+        if (m - p <= 3 && m > p) { /* DESeq2 matches the prior variance by simulation here (prior_mc_oracle.c) */
+            status |= ORACLE_ST_PRIORVAR_MC;
+            dispPriorVar = oracle_prior_var_mc(obs_hist, m - p);
+        }
+        if (isnan(dispPriorVar)) dispPriorVar = fmax(varLogDispEsts - oracle_trigamma((m - p) / 2.0), 0.25);
     }
     out->dispPriorVar = dispPriorVar;
 

@@ -115,6 +115,10 @@ int oracle_fragment_background(const int32_t *bait, const int32_t *oe, int64_t n
 /* a9 helpers: BH adjustment (p.adjust(method="BH") on the non-NaN entries; NaN stays NaN) */
 int oracle_bh_adjust(const double *p, int64_t n, double *padj);
 
+/* A4, residual d.f. <= 3: simulation-matched prior variance (prior_mc_oracle.c) */
+int oracle_prior_mc_bin(double x);
+double oracle_prior_var_mc(const double *obs_counts /*[40]*/, int df);
+
 /* f3: IHW application side, chicdiff.R:2038-2049 (see chicdiff_oracle.c) */
 int oracle_ihw_apply(const double *avDist, const double *pvalue, int64_t n, const double *breaks, const double *avWeights,
                      int32_t ngroups, int32_t *group, double *weight, double *wp, double *wpadj);

@@ -83,6 +83,9 @@ def lib():
         P64 = C.POINTER(C.c_int64)
         L.oracle_fragment_background.argtypes = [_PI, _PI, C.c_int64, C.c_int32, C.c_int32, P64, C.c_int32, _PD, _PD, _PI, _PI,
                                                  _PD, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD]
+        L.oracle_prior_var_mc.restype = C.c_double
+        L.oracle_prior_var_mc.argtypes = [_PD, C.c_int32]
+        L.oracle_prior_mc_bin.argtypes = [C.c_double]
         L.oracle_ihw_apply.argtypes = [_PD, _PD, C.c_int64, _PD, _PD, C.c_int32, _PI, _PD, _PD, _PD]
         L.oracle_region_universe.restype = C.c_int64
         L.oracle_region_universe.argtypes = [_PI, _PI, C.c_int64, C.c_int32, _PI, C.c_int32, P64, _PI, _PI, _PI]
@@ -284,3 +287,12 @@ def count_table(bait, oe, N, bait_in_RU=None):
     keys = (b << 32) | o
     order = np.argsort(keys, kind="stable")
     return keys[order], v[order]
+
+
+def prior_var_mc(residuals, df):
+    """Simulation-matched dispPriorVar for residual d.f. <= 3 from the log dispersion residuals."""
+    r = np.asarray(residuals, dtype=np.float64)
+    r = r[(r > -10) & (r < 10)]
+    counts = np.zeros(40)
+    np.add.at(counts, np.clip(np.ceil((r + 10.0) * 2.0).astype(int) - 1, 0, 39), 1.0)
+    return lib().oracle_prior_var_mc(_pd(counts), int(df))

@@ -946,3 +946,22 @@ def test_fit_fuzz_shapes_and_designs(ctx, oracle):
         else:
             assert np.isclose(sc["sumDeviance"], ref["sumDeviance"], rtol=1e-6, equal_nan=True)
     print("fuzz: worst fraction of rows within 1e-6:", worst)
+
+
+@pytest.mark.parametrize("S,group", [(4, [0, 0, 1, 1]), (4, [0, 0, 0, 0]), (5, [0, 0, 1, 1, 1]), (3, [0, 0, 0])])
+def test_prior_variance_by_simulation_matches_oracle(ctx, oracle, S, group):
+    """Residual d.f. 1..3 (2v2, the reference's own test design, among them): the device histogram + the library's
+    host-side simulation give the oracle's dispPriorVar, and with it the same dispersions and p-values."""
+    from test_oracle import heterogeneous_counts
+    counts, nf = heterogeneous_counts(6000, S, 1.3)
+    group = np.asarray(group, dtype=np.int32)
+    got, sc = run_fit(ctx, dict(counts=counts, nf=nf), group)
+    ref = oracle.nbglm_fit(counts, nf, group)
+    assert sc["status"] & 2 and ref["status"] & 2
+    assert np.isclose(sc["varLogDispEsts"], ref["varLogDispEsts"], rtol=1e-7)
+    assert sc["dispPriorVar"] == ref["dispPriorVar"] and sc["dispPriorVar"] > 0.3, (sc["dispPriorVar"], ref["dispPriorVar"])
+    nz = ref["allZero"] == 0
+    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6, 0.995)
+    if group.any():
+        conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
+        check_close("pvalue", got["pvalue"], ref["pvalue"], conv, 1e-6, 0.995)

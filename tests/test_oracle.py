@@ -345,3 +345,41 @@ def test_region_universe_matches_literal_restatement(s):
     assert np.array_equal(np.diff(ptr), np.bincount(rr, minlength=len(bait) + 1)[1:])
     with pytest.raises(ValueError):
         oracle.region_universe(np.array([5], np.int32), np.array([5], np.int32), s, chr_of)
+
+
+@pytest.mark.parametrize("df", [1, 2, 3])
+def test_prior_variance_by_simulation_recovers_a_known_variance(df):
+    """A4 with residual d.f. <= 3: residuals drawn from the model DESeq2 simulates, log(chisq_df / df) + N(0, v),
+    by an independent generator (numpy): the matched prior variance must come back as v (grid step 0.008, Monte
+    Carlo noise of 1e4 draws per grid point), and never below DESeq2's floor of 0.25."""
+    rng = np.random.default_rng(100 + df)
+    for v in (0.6, 1.0, 2.0, 4.0):
+        res = np.log(rng.chisquare(df, 300000) / df) + rng.normal(0, np.sqrt(v), 300000)
+        got = oracle.prior_var_mc(res, df)
+        assert abs(got - v) < 0.12 + 0.03 * v, (df, v, got)
+    assert oracle.prior_var_mc(np.log(rng.chisquare(df, 100000) / df), df) == 0.25
+
+
+def heterogeneous_counts(n, S, sdlog, seed=7):
+    """NB counts whose true dispersions scatter widely around their trend (log sd `sdlog`): the synthetic benchmark
+    generator's own scatter (0.5) sits at DESeq2's 0.25 floor of the prior variance."""
+    rng = np.random.default_rng(seed)
+    mu = rng.lognormal(np.log(60), 1.0, n)
+    alpha = (0.05 + 2.0 / mu) * rng.lognormal(0, sdlog, n)
+    nf = rng.lognormal(0, 0.2, (n, S))
+    nf /= np.exp(np.log(nf).mean(axis=1, keepdims=True))
+    lam = rng.gamma(1.0 / alpha[:, None], alpha[:, None] * mu[:, None] * nf)
+    return rng.poisson(lam).astype(np.int32), nf
+
+
+def test_fit_with_three_residual_df_uses_the_simulated_prior():
+    counts, nf = heterogeneous_counts(6000, 4, 1.3)
+    out = oracle.nbglm_fit(counts, nf, [0, 0, 1, 1])  # 2v2: m - p = 2
+    assert out["status"] & 2
+    closed = max(out["varLogDispEsts"] - special.polygamma(1, 1.0), 0.25)
+    # the simulation-matched value: well above the floor for this scatter (true log-variance 1.69), and not the closed form
+    assert 0.4 < out["dispPriorVar"] < 3.0 and not np.isclose(out["dispPriorVar"], closed, rtol=1e-3), (out["dispPriorVar"], closed)
+    out1 = oracle.nbglm_fit(counts, nf, [0, 0, 0, 0])  # ~1 with 4 samples: d.f. 3
+    assert out1["status"] & 2 and 0.4 < out1["dispPriorVar"] < 3.0
+    d = synth.make(4000, 4)
+    assert oracle.nbglm_fit(d["counts"], d["nf"], d["group"])["dispPriorVar"] == 0.25  # the benchmark generator sits at the floor
