@@ -19,9 +19,11 @@
   r
 }
 
-## residual d.f. <= 3 (e.g. 2 vs 2): DESeq2's prior variance is a Monte-Carlo match that needs R's RNG
-## and loess, so it is computed HERE with DESeq2's own code from the GPU's gene-wise estimates and
-## handed back to the library (chicdiff_nbglm_opts.dispPriorVar), exactly the argument DESeq2 exposes.
+## residual d.f. <= 3 (e.g. 2 vs 2): DESeq2's prior variance is a Monte-Carlo match drawn from R's session
+## RNG.  The library runs the same matching from a fixed-seed stream of its own (status bit 2), which is the
+## default; set options(chicdiff.hip.priorvar = "DESeq2") to have it computed HERE with DESeq2's own code
+## (and R's RNG) from the GPU's gene-wise estimates and handed back through chicdiff_nbglm_opts.dispPriorVar,
+## exactly the argument DESeq2 exposes.
 .hipPriorVar <- function(fit, modelMatrix, minDisp = 1e-8) {
   m <- nrow(modelMatrix); p <- ncol(modelMatrix)
   if (!((m - p) <= 3 && m > p)) return(NA_real_)
@@ -35,7 +37,7 @@
 DESeq2Hip <- function(regionDataMatrix, normFactors, condition) {
   fit <- .hipFit(regionDataMatrix, normFactors, condition)
   X <- stats::model.matrix(~ condition, data.frame(condition = factor(condition)))
-  pv <- .hipPriorVar(fit, X)
+  pv <- if (identical(getOption("chicdiff.hip.priorvar"), "DESeq2")) .hipPriorVar(fit, X) else NA_real_
   if (!is.na(pv)) fit <- .hipFit(regionDataMatrix, normFactors, condition, dispPriorVar = pv)
   if (bitwAnd(fit$status, 1L)) stop("parametric dispersion trend failed (DESeq2 would use a local fit)")
   fit
