@@ -52,6 +52,7 @@ struct chicdiff_hip_ctx {
     FitWork w{};
     double *d_sf = nullptr;   // kMaxS doubles
     double *d_logfact = nullptr;  // kLogFactN doubles: log(k!) (wald_prep)
+    double *d_pmc[4] = {nullptr, nullptr, nullptr, nullptr};  // simulated residual densities per d.f. (prior_mc.h)
     double *d_nf_tmp = nullptr;
     FitScalars *h_sc = nullptr;  // pinned
     double *h_sf = nullptr;      // pinned, kMaxS
@@ -142,6 +143,8 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     if (c->aux) (void)hipFree(c->aux);
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->d_logfact) (void)hipFree(c->d_logfact);
+    for (int k = 0; k < 4; k++)
+        if (c->d_pmc[k]) (void)hipFree(c->d_pmc[k]);
     if (c->h_sc) (void)hipHostFree(c->h_sc);
     if (c->h_sf) (void)hipHostFree(c->h_sf);
     if (c->rccl_comm && c->rccl_comm_destroy) (void)c->rccl_comm_destroy(c->rccl_comm);
@@ -517,28 +520,28 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         sa.mode = SEL_ABSDEV;
         if ((rc = run_select(c, sa))) return rc;
         if (prior_by_simulation) {
-            // residual d.f. <= 3: DESeq2 matches the prior variance by simulation (prior_mc.h).  One small histogram
-            // leaves the device, the 200 x 40 simulated densities are constants built once per process and d.f.
-            double *d_hist = sums_of(w) + 32, h_hist[kPmcBins];
+            // residual d.f. <= 3: DESeq2 matches the prior variance by simulation (prior_mc.h).  The 200 x 40 simulated
+            // densities are constants (built once per process and d.f.); the matching itself runs on the device
+            double *d_hist = sums_of(w) + 32;
             launch_resid_hist(d, w, d_hist, st);
             if ((rc = do_allreduce(c, d_hist, kPmcBins))) return rc;
-            HIPCHK(c, hipMemcpyAsync(h_hist, d_hist, sizeof h_hist, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            static PmcTable tables[4];
-            static bool ready[4] = {false, false, false, false};
-            static std::mutex mu;
             const int df = d.S - d.p;
-            {
+            if (!c->d_pmc[df]) {  // simulated densities of this d.f.: built once per process, uploaded once per context
+                static PmcTable tables[4];
+                static bool ready[4] = {false, false, false, false};
+                static std::mutex mu;
                 std::lock_guard<std::mutex> lock(mu);
                 if (!ready[df]) {
                     pmc_build(df, tables[df]);
                     ready[df] = true;
                 }
+                HIPCHK(c, hipMalloc((void **)&c->d_pmc[df], sizeof(PmcTable)));
+                HIPCHK(c, hipMemcpy(c->d_pmc[df], &tables[df], sizeof(PmcTable), hipMemcpyHostToDevice));
             }
-            const double pv = pmc_prior_var(h_hist, tables[df]);
-            if (pv == pv) o.dispPriorVarIn = pv;  // (no residuals at all: the closed form's 0.25 floor)
+            launch_prior_mc(d, w, d_hist, c->d_pmc[df], st);
+        } else {
+            launch_prior_var(d, w, o, st);
         }
-        launch_prior_var(d, w, o, st);
     }
     {
         Scope t(c, "disp_map");

@@ -13,6 +13,7 @@
 //  * offsets (chicdiff.R:1583-1589, 1635-1638), window sums (:1540-1547), count join (:843-858).
 #include "common.h"
 #include "devmath.h"
+#include "prior_mc.h"
 
 namespace cd {
 
@@ -260,6 +261,55 @@ __global__ __launch_bounds__(256) void resid_hist_kernel(FitDims d, FitWork w, d
 void launch_resid_hist(FitDims d, FitWork w, double *out40, hipStream_t st) {
     (void)hipMemsetAsync(out40, 0, sizeof(double) * 40, st);
     resid_hist_kernel<<<256, 256, 0, st>>>(d, w, out40);
+}
+
+// estimateDispersionsPriorVar for residual d.f. <= 3 (prior_mc.h): KL of the observed residual density against the 200
+// simulated ones, direct loess on the fine grid, first minimum — the pieces of pmc_prior_var(), one workgroup, no
+// host round trip.  dens: [kPmcGrid][kPmcBins] for this d.f. (built once per process on the host).
+__global__ __launch_bounds__(256) void prior_mc_kernel(FitDims d, FitWork w, const double *hist, const double *dens) {
+    __shared__ double obs[kPmcBins], kl[kPmcGrid], s_nobs, bestv[256];
+    __shared__ int besti[256];
+    if (threadIdx.x == 0) {
+        double nobs = 0;
+        for (int b = 0; b < kPmcBins; b++) nobs += hist[b];
+        s_nobs = nobs;
+    }
+    __syncthreads();
+    if (!(s_nobs > 0)) {  // no residuals at all: the closed form (its 0.25 floor)
+        if (threadIdx.x == 0) prior_var(w.sc, d.S, d.p, NAN);
+        return;
+    }
+    if (threadIdx.x < kPmcBins) obs[threadIdx.x] = hist[threadIdx.x] / (s_nobs * 0.5);
+    __syncthreads();
+    for (int g = threadIdx.x; g < kPmcGrid; g += 256) kl[g] = pmc_kl(obs, dens + (size_t)g * kPmcBins);
+    __syncthreads();
+    double best = INFINITY;
+    int bi = kPmcFine;
+    for (int f = threadIdx.x; f < kPmcFine; f += 256) {
+        const double fit = pmc_loess_at(f, kl);
+        if (fit < best) { best = fit; bi = f; }
+    }
+    bestv[threadIdx.x] = best;
+    besti[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {  // which.min: the first minimum
+        if ((int)threadIdx.x < off) {
+            const double ov = bestv[threadIdx.x + off];
+            const int oi = besti[threadIdx.x + off];
+            if (ov < bestv[threadIdx.x] || (ov == bestv[threadIdx.x] && oi < besti[threadIdx.x])) {
+                bestv[threadIdx.x] = ov;
+                besti[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double arg = besti[0] < kPmcFine ? pmc_fine_x(besti[0]) : 0.0;
+        prior_var(w.sc, d.S, d.p, arg > 0.25 ? arg : 0.25);
+    }
+}
+void launch_prior_mc(FitDims d, FitWork w, const double *hist40, const double *dens, hipStream_t st) {
+    prior_mc_kernel<<<1, 256, 0, st>>>(d, w, hist40, dens);
 }
 
 // estimateDispersionsPriorVar, closed-form branch (A4): fit_state.h

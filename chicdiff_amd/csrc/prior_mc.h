@@ -17,6 +17,12 @@
 #include <math.h>
 #include <stdint.h>
 
+#if defined(__HIPCC__)
+#define PMC_HD __host__ __device__ inline
+#else
+#define PMC_HD inline
+#endif
+
 namespace cd {
 
 constexpr int kPmcBins = 40, kPmcGrid = 200, kPmcFine = 1000, kPmcDraws = 10000;
@@ -77,50 +83,58 @@ inline void pmc_build(int df, PmcTable &t) {
     }
 }
 
+// KL divergence of the observed density from the simulated one of grid point g (DESeq2's `small` included)
+PMC_HD double pmc_kl(const double *obs, const double *dens_g) {
+    double small = INFINITY;
+    for (int b = 0; b < kPmcBins; b++) {
+        if (obs[b] > 0 && obs[b] < small) small = obs[b];
+        if (dens_g[b] > 0 && dens_g[b] < small) small = dens_g[b];
+    }
+    double s = 0;
+    for (int b = 0; b < kPmcBins; b++) s += obs[b] * (log(obs[b] + small) - log(dens_g[b] + small));
+    return s;
+}
+PMC_HD double pmc_grid_x(int g) { return 8.0 * g / (kPmcGrid - 1); }
+PMC_HD double pmc_fine_x(int f) { return 8.0 * f / (kPmcFine - 1); }
+// loess(kl ~ x, span = .2, degree = 2) at fine-grid point f, evaluated directly: local quadratic, tricube weights,
+// the q = 40 nearest of the 200 grid points
+PMC_HD double pmc_loess_at(int f, const double *kl) {
+    const int q = (int)floor(kPmcGrid * 0.2 + 1e-5);
+    const double x0 = pmc_fine_x(f);
+    // the q nearest grid points form a window [lo, lo + q): slide it to the one with the smallest reach
+    int lo = (int)floor(x0 / (8.0 / (kPmcGrid - 1))) - q / 2;
+    if (lo < 0) lo = 0;
+    if (lo > kPmcGrid - q) lo = kPmcGrid - q;
+    while (lo > 0 && fabs(pmc_grid_x(lo - 1) - x0) < fabs(pmc_grid_x(lo + q - 1) - x0)) lo--;
+    while (lo < kPmcGrid - q && fabs(pmc_grid_x(lo + q) - x0) < fabs(pmc_grid_x(lo) - x0)) lo++;
+    const double h = fmax(fabs(pmc_grid_x(lo) - x0), fabs(pmc_grid_x(lo + q - 1) - x0));
+    double S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0, T0 = 0, T1 = 0, T2 = 0;
+    for (int k = lo; k < lo + q; k++) {
+        const double d = pmc_grid_x(k) - x0, u = fabs(d) / h;
+        if (u >= 1.0) continue;
+        const double c = 1.0 - u * u * u, w = c * c * c;
+        S0 += w; S1 += w * d; S2 += w * d * d; S3 += w * d * d * d; S4 += w * d * d * d * d;
+        T0 += w * kl[k]; T1 += w * d * kl[k]; T2 += w * d * d * kl[k];
+    }
+    // intercept of the weighted quadratic fit in d = x - x0 (Cramer's rule on the 3x3 normal equations)
+    const double det = S0 * (S2 * S4 - S3 * S3) - S1 * (S1 * S4 - S3 * S2) + S2 * (S1 * S3 - S2 * S2);
+    const double num = T0 * (S2 * S4 - S3 * S3) - S1 * (T1 * S4 - S3 * T2) + S2 * (T1 * S3 - S2 * T2);
+    return num / det;
+}
+
 // obs_counts[kPmcBins]: histogram of the observed residuals inside (-10, 10).  Returns max(argminKL, 0.25)
-// (NaN when there are no residuals).
+// (NaN when there are no residuals).  Host form; the library runs the same pieces in a kernel (prior_mc_kernel).
 inline double pmc_prior_var(const double *obs_counts, const PmcTable &t) {
     double nobs = 0;
     for (int b = 0; b < kPmcBins; b++) nobs += obs_counts[b];
     if (!(nobs > 0)) return NAN;
-    double obs[kPmcBins], kl[kPmcGrid], xs[kPmcGrid];
+    double obs[kPmcBins], kl[kPmcGrid];
     for (int b = 0; b < kPmcBins; b++) obs[b] = obs_counts[b] / (nobs * 0.5);
-    for (int g = 0; g < kPmcGrid; g++) {
-        xs[g] = 8.0 * g / (kPmcGrid - 1);
-        double small = INFINITY;
-        for (int b = 0; b < kPmcBins; b++) {
-            if (obs[b] > 0 && obs[b] < small) small = obs[b];
-            if (t.dens[g][b] > 0 && t.dens[g][b] < small) small = t.dens[g][b];
-        }
-        double s = 0;
-        for (int b = 0; b < kPmcBins; b++) s += obs[b] * (log(obs[b] + small) - log(t.dens[g][b] + small));
-        kl[g] = s;
-    }
-    // loess(span = .2, degree = 2), evaluated directly on the fine grid
-    const int q = (int)floor(kPmcGrid * 0.2 + 1e-5);
+    for (int g = 0; g < kPmcGrid; g++) kl[g] = pmc_kl(obs, t.dens[g]);
     double best = INFINITY, arg = 0;
     for (int f = 0; f < kPmcFine; f++) {
-        const double x0 = 8.0 * f / (kPmcFine - 1);
-        // the q nearest grid points form a window [lo, lo + q): slide it to the one with the smallest reach
-        int lo = (int)floor(x0 / (8.0 / (kPmcGrid - 1))) - q / 2;
-        if (lo < 0) lo = 0;
-        if (lo > kPmcGrid - q) lo = kPmcGrid - q;
-        while (lo > 0 && fabs(xs[lo - 1] - x0) < fabs(xs[lo + q - 1] - x0)) lo--;
-        while (lo < kPmcGrid - q && fabs(xs[lo + q] - x0) < fabs(xs[lo] - x0)) lo++;
-        const double h = fmax(fabs(xs[lo] - x0), fabs(xs[lo + q - 1] - x0));
-        double S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0, T0 = 0, T1 = 0, T2 = 0;
-        for (int k = lo; k < lo + q; k++) {
-            const double d = xs[k] - x0, u = fabs(d) / h;
-            if (u >= 1.0) continue;
-            const double c = 1.0 - u * u * u, w = c * c * c;
-            S0 += w; S1 += w * d; S2 += w * d * d; S3 += w * d * d * d; S4 += w * d * d * d * d;
-            T0 += w * kl[k]; T1 += w * d * kl[k]; T2 += w * d * d * kl[k];
-        }
-        // intercept of the weighted quadratic fit in d = x - x0 (Cramer's rule on the 3x3 normal equations)
-        const double det = S0 * (S2 * S4 - S3 * S3) - S1 * (S1 * S4 - S3 * S2) + S2 * (S1 * S3 - S2 * S2);
-        const double num = T0 * (S2 * S4 - S3 * S3) - S1 * (T1 * S4 - S3 * T2) + S2 * (T1 * S3 - S2 * T2);
-        const double fit = num / det;
-        if (fit < best) { best = fit; arg = x0; }  // which.min: the first minimum
+        const double fit = pmc_loess_at(f, kl);
+        if (fit < best) { best = fit; arg = pmc_fine_x(f); }  // which.min: the first minimum
     }
     return arg > 0.25 ? arg : 0.25;
 }
