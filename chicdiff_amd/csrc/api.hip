@@ -52,7 +52,7 @@ struct chicdiff_hip_ctx {
     FitWork w{};
     double *d_sf = nullptr;   // kMaxS doubles
     double *d_logfact = nullptr;  // kLogFactN doubles: log(k!) (wald_prep)
-    double *d_pmc[4] = {nullptr, nullptr, nullptr, nullptr};  // simulated residual densities per d.f. (prior_mc.h)
+    PmcTable *d_pmc[4] = {nullptr, nullptr, nullptr, nullptr};  // simulated residual densities + loess operator per d.f. (prior_mc.h)
     double *d_nf_tmp = nullptr;
     FitScalars *h_sc = nullptr;  // pinned
     double *h_sf = nullptr;      // pinned, kMaxS
@@ -65,6 +65,19 @@ struct chicdiff_hip_ctx {
 };
 
 static char g_create_err[512];
+
+// simulated residual densities + loess operator of one d.f. (prior_mc.h): constants, built once per process
+static const PmcTable &pmc_table(int df) {
+    static PmcTable tables[4];
+    static bool ready[4] = {false, false, false, false};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ready[df]) {
+        pmc_build(df, tables[df]);
+        ready[df] = true;
+    }
+    return tables[df];
+}
 
 static int fail(chicdiff_hip_ctx *c, int code, const char *fmt, ...) {
     va_list ap;
@@ -526,17 +539,9 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
             launch_resid_hist(d, w, d_hist, st);
             if ((rc = do_allreduce(c, d_hist, kPmcBins))) return rc;
             const int df = d.S - d.p;
-            if (!c->d_pmc[df]) {  // simulated densities of this d.f.: built once per process, uploaded once per context
-                static PmcTable tables[4];
-                static bool ready[4] = {false, false, false, false};
-                static std::mutex mu;
-                std::lock_guard<std::mutex> lock(mu);
-                if (!ready[df]) {
-                    pmc_build(df, tables[df]);
-                    ready[df] = true;
-                }
+            if (!c->d_pmc[df]) {  // built once per process, uploaded once per context
                 HIPCHK(c, hipMalloc((void **)&c->d_pmc[df], sizeof(PmcTable)));
-                HIPCHK(c, hipMemcpy(c->d_pmc[df], &tables[df], sizeof(PmcTable), hipMemcpyHostToDevice));
+                HIPCHK(c, hipMemcpy(c->d_pmc[df], &pmc_table(df), sizeof(PmcTable), hipMemcpyHostToDevice));
             }
             launch_prior_mc(d, w, d_hist, c->d_pmc[df], st);
         } else {
@@ -832,6 +837,25 @@ extern "C" int chicdiff_hip_selftest_math_dev(chicdiff_hip_ctx *c, int32_t op, c
     HIPCHK(c, hipSetDevice(c->device));
     if (n > 0) launch_math_selftest(op, d_x, n, d_out, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CHICDIFF_OK;
+}
+
+// host-side self tests of the simulation-matched prior variance (no device involved)
+extern "C" int chicdiff_hip_selftest_r_random(int32_t kind, uint32_t seed, double a, double b, int64_t n, double *out) {
+    if (!out || n < 0 || kind < 0 || kind > 3) return CHICDIFF_E_INVALID;
+    if (kind == 3 && !(a > 0 && b > 0)) return CHICDIFF_E_INVALID;
+    RStream r(seed);
+    for (int64_t i = 0; i < n; i++) out[i] = kind == 0 ? r.unif() : kind == 1 ? r.norm() : kind == 2 ? r.expo() : r.gamma(a, b);
+    return CHICDIFF_OK;
+}
+extern "C" int chicdiff_hip_selftest_prior_mc(int32_t df, const double *hist40, double *dens_out, double *prior_var_out) {
+    if (df < 1 || df > 3) return CHICDIFF_E_INVALID;
+    const PmcTable &t = pmc_table(df);
+    if (dens_out) memcpy(dens_out, t.dens, sizeof t.dens);
+    if (prior_var_out) {
+        if (!hist40) return CHICDIFF_E_INVALID;
+        *prior_var_out = pmc_prior_var(hist40, t);
+    }
     return CHICDIFF_OK;
 }
 

@@ -53,7 +53,7 @@ void launch_trend_step(FitDims d, FitWork w, Opts o, hipStream_t st);   // fixed
 void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_resid_hist(FitDims d, FitWork w, double *out40, hipStream_t st);  // residual histogram for the d.f. <= 3 prior
-void launch_prior_mc(FitDims d, FitWork w, const double *hist40, const double *dens, hipStream_t st);  // simulation-matched prior variance
+void launch_prior_mc(FitDims d, FitWork w, const double *hist40, const void *table, hipStream_t st);  // simulation-matched prior variance
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_wald_optim(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);

@@ -241,22 +241,19 @@ void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st) {
     resid_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp);
 }
 
-// 40-bin histogram of the log dispersion residuals inside (-10, 10) (hist(breaks = -20:20/2), right-closed): input of
-// the simulation-matched prior variance for residual d.f. <= 3 (prior_mc.h).  Counts as doubles: a sum-all-reducible
-// statistic like the others.
+// 40-bin histogram of the log dispersion residuals inside (-10, 10) (hist(breaks = -20:20/2) as hist.default counts
+// it, pmc_bin): input of the simulation-matched prior variance for residual d.f. <= 3 (prior_mc.h).  Counts as
+// doubles: a sum-all-reducible statistic like the others.
 __global__ __launch_bounds__(256) void resid_hist_kernel(FitDims d, FitWork w, double *out) {
-    __shared__ unsigned int h[40];
-    if (threadIdx.x < 40) h[threadIdx.x] = 0;
+    __shared__ unsigned int h[kPmcBins];
+    if (threadIdx.x < kPmcBins) h[threadIdx.x] = 0;
     __syncthreads();
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
-        const double x = w.resid[i];
-        if (!(x > -10.0 && x < 10.0)) continue;  // NaN = not part of the fit
-        int b = (int)ceil((x + 10.0) * 2.0) - 1;
-        b = b < 0 ? 0 : (b > 39 ? 39 : b);
-        atomicAdd(&h[b], 1u);
+        const int b = pmc_bin(w.resid[i]);  // NaN = not part of the fit
+        if (b >= 0) atomicAdd(&h[b], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 40 && h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (double)h[threadIdx.x]);
+    if (threadIdx.x < kPmcBins && h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (double)h[threadIdx.x]);
 }
 void launch_resid_hist(FitDims d, FitWork w, double *out40, hipStream_t st) {
     (void)hipMemsetAsync(out40, 0, sizeof(double) * 40, st);
@@ -264,10 +261,11 @@ void launch_resid_hist(FitDims d, FitWork w, double *out40, hipStream_t st) {
 }
 
 // estimateDispersionsPriorVar for residual d.f. <= 3 (prior_mc.h): KL of the observed residual density against the 200
-// simulated ones, direct loess on the fine grid, first minimum — the pieces of pmc_prior_var(), one workgroup, no
-// host round trip.  dens: [kPmcGrid][kPmcBins] for this d.f. (built once per process on the host).
-__global__ __launch_bounds__(256) void prior_mc_kernel(FitDims d, FitWork w, const double *hist, const double *dens) {
-    __shared__ double obs[kPmcBins], kl[kPmcGrid], s_nobs, bestv[256];
+// simulated ones, loess as R evaluates it (local fits at the k-d tree vertices, cubic Hermite in between) on the fine
+// grid, first minimum — the pieces of pmc_prior_var(), one workgroup, no host round trip.  t: the table of this
+// d.f. (built once per process on the host).
+__global__ __launch_bounds__(256) void prior_mc_kernel(FitDims d, FitWork w, const double *hist, const PmcTable *t) {
+    __shared__ double obs[kPmcBins], kl[kPmcGrid], s_nobs, bestv[256], vert[kPmcMaxVert], val[kPmcMaxVert], slope[kPmcMaxVert];
     __shared__ int besti[256];
     if (threadIdx.x == 0) {
         double nobs = 0;
@@ -281,12 +279,18 @@ __global__ __launch_bounds__(256) void prior_mc_kernel(FitDims d, FitWork w, con
     }
     if (threadIdx.x < kPmcBins) obs[threadIdx.x] = hist[threadIdx.x] / (s_nobs * 0.5);
     __syncthreads();
-    for (int g = threadIdx.x; g < kPmcGrid; g += 256) kl[g] = pmc_kl(obs, dens + (size_t)g * kPmcBins);
+    for (int g = threadIdx.x; g < kPmcGrid; g += 256) kl[g] = pmc_kl(obs, t->dens[g]);
+    __syncthreads();
+    const int nvert = t->nvert;
+    if ((int)threadIdx.x < nvert) {
+        vert[threadIdx.x] = t->vert[threadIdx.x];
+        pmc_vertex(*t, threadIdx.x, kl, val[threadIdx.x], slope[threadIdx.x]);
+    }
     __syncthreads();
     double best = INFINITY;
     int bi = kPmcFine;
     for (int f = threadIdx.x; f < kPmcFine; f += 256) {
-        const double fit = pmc_loess_at(f, kl);
+        const double fit = pmc_loess_eval(vert, nvert, val, slope, pmc_fine_x(f));
         if (fit < best) { best = fit; bi = f; }
     }
     bestv[threadIdx.x] = best;
@@ -308,8 +312,8 @@ __global__ __launch_bounds__(256) void prior_mc_kernel(FitDims d, FitWork w, con
         prior_var(w.sc, d.S, d.p, arg > 0.25 ? arg : 0.25);
     }
 }
-void launch_prior_mc(FitDims d, FitWork w, const double *hist40, const double *dens, hipStream_t st) {
-    prior_mc_kernel<<<1, 256, 0, st>>>(d, w, hist40, dens);
+void launch_prior_mc(FitDims d, FitWork w, const double *hist40, const void *table, hipStream_t st) {
+    prior_mc_kernel<<<1, 256, 0, st>>>(d, w, hist40, (const PmcTable *)table);
 }
 
 // estimateDispersionsPriorVar, closed-form branch (A4): fit_state.h

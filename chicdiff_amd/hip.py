@@ -31,7 +31,8 @@ EXPORTS = [
     "chicdiff_hip_rccl_unique_id", "chicdiff_hip_rccl_init", "chicdiff_hip_cooks_filter_dev",
     "chicdiff_hip_independent_filtering_dev",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
-    "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
+    "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_selftest_r_random",
+    "chicdiff_hip_selftest_prior_mc", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
 
 

@@ -38,7 +38,7 @@ extern "C" {
 
 /* status bits reported in chicdiff_nbglm_scalars.status (fit completed, with caveats) */
 #define CHICDIFF_ST_TREND_FAILED 1 /* parametric trend failed; DESeq2 would switch to locfit   */
-#define CHICDIFF_ST_PRIORVAR_MC 2  /* m-p<=3 and no dispPriorVar given: matched by simulation as in DESeq2, from a fixed-seed stream (R's own draws are unseeded) */
+#define CHICDIFF_ST_PRIORVAR_MC 2  /* m-p<=3 and no dispPriorVar given: matched by simulation as DESeq2 does it (its set.seed(2) stream, hist(), loess()) */
 #define CHICDIFF_ST_BETA_NONCONV 4 /* some rows hit betaMaxit (DESeq2 would call optim)        */
 #define CHICDIFF_ST_ALLZERO_ROWS 8 /* some rows are all zero: their outputs are NaN (R: NA)    */
 
@@ -258,6 +258,15 @@ int chicdiff_hip_wald_pvalues_dev(chicdiff_hip_ctx *ctx, const double *d_stat, i
 /* Device-math self test: out[i] = f(x[i]) with op 0 log (polynomial), 1 log (table), 2 reciprocal,
  * 3 lgamma, 4 digamma, 5 2*pnorm(-|x|) — the special functions the fit kernels are built on. */
 int chicdiff_hip_selftest_math_dev(chicdiff_hip_ctx *ctx, int32_t op, const double *d_x, int64_t n, double *d_out);
+
+/* Host-side self tests of the pieces behind CHICDIFF_ST_PRIORVAR_MC (no device, no context).
+ * _r_random: set.seed(seed) followed by n draws of kind 0 runif(n), 1 rnorm(n), 2 rexp(n), 3 rgamma(n, shape = a,
+ * scale = b) from R's default generators (Mersenne-Twister, inversion).
+ * _prior_mc: DESeq2 estimateDispersionsPriorVar for residual d.f. df in 1..3: dens_out (200 x 40, row-major, may be
+ * NULL) = the densities of its 200 simulated residual distributions; *prior_var_out (may be NULL) = the prior
+ * variance matched to hist40, the counts of hist(residuals, breaks = -20:20/2). */
+int chicdiff_hip_selftest_r_random(int32_t kind, uint32_t seed, double a, double b, int64_t n, double *out);
+int chicdiff_hip_selftest_prior_mc(int32_t df, const double *hist40, double *dens_out, double *prior_var_out);
 
 /* Timing of the last *_dev call's kernels, measured with HIP events on the context's stream:
  * fills up to `cap` (name, milliseconds, launches) records; returns the number available. */

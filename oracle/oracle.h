@@ -13,6 +13,7 @@
 #ifndef ORACLE_H
 #define ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -37,7 +38,7 @@ void oracle_nbglm_default_opts(oracle_nbglm_opts *o);
 
 /* status bits returned in out->status */
 #define ORACLE_ST_TREND_FAILED 1     /* parametric trend fit failed (DESeq2 would switch to locfit) */
-#define ORACLE_ST_PRIORVAR_MC 2      /* m-p <= 3: DESeq2 uses an R-RNG Monte Carlo; not reproduced   */
+#define ORACLE_ST_PRIORVAR_MC 2      /* m-p <= 3: dispPriorVar matched by simulation as DESeq2 does (set.seed(2)) */
 #define ORACLE_ST_BETA_NONCONV 4     /* some rows hit betaMaxit (DESeq2 would call optim)           */
 #define ORACLE_ST_ALLZERO_ROWS 8     /* some rows are all-zero (NA outputs)                         */
 
@@ -118,6 +119,26 @@ int oracle_bh_adjust(const double *p, int64_t n, double *padj);
 /* A4, residual d.f. <= 3: simulation-matched prior variance (prior_mc_oracle.c) */
 int oracle_prior_mc_bin(double x);
 double oracle_prior_var_mc(const double *obs_counts /*[40]*/, int df);
+int oracle_prior_mc_table(int df, double *out /*[200*40]*/);
+/* loess(y ~ x, span, degree = 2, family = "gaussian", surface = "interpolate", cell) on sorted distinct x[n],
+ * predicted at z[nz] (inside the range of x); returns the number of k-d tree vertices or < 0 */
+int oracle_loess_interp(const double *x, const double *y, int n, double span, double cell, const double *z, int nz,
+                        double *out);
+
+/* R's default RNG chain (r_rng.c): set.seed + Mersenne-Twister + inversion normals + exp_rand + rgamma */
+struct oracle_r_rng;
+size_t oracle_r_rng_size(void);
+void oracle_r_set_seed(struct oracle_r_rng *r, uint32_t seed);
+double oracle_r_unif_rand(struct oracle_r_rng *r);
+double oracle_r_norm_rand(struct oracle_r_rng *r);
+double oracle_r_exp_rand(struct oracle_r_rng *r);
+double oracle_r_rgamma(struct oracle_r_rng *r, double a, double scale);
+double oracle_r_rchisq(struct oracle_r_rng *r, double df);
+double oracle_r_qnorm(double p);
+void oracle_r_runif(uint32_t seed, int64_t n, double *out);
+void oracle_r_rnorm(uint32_t seed, int64_t n, double *out);
+void oracle_r_rexp(uint32_t seed, int64_t n, double *out);
+void oracle_r_rgamma_vec(uint32_t seed, double shape, double scale, int64_t n, double *out);
 
 /* f3: IHW application side, chicdiff.R:2038-2049 (see chicdiff_oracle.c) */
 int oracle_ihw_apply(const double *avDist, const double *pvalue, int64_t n, const double *breaks, const double *avWeights,

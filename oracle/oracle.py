@@ -86,6 +86,15 @@ def lib():
         L.oracle_prior_var_mc.restype = C.c_double
         L.oracle_prior_var_mc.argtypes = [_PD, C.c_int32]
         L.oracle_prior_mc_bin.argtypes = [C.c_double]
+        L.oracle_prior_mc_table.argtypes = [C.c_int32, _PD]
+        L.oracle_loess_interp.argtypes = [_PD, _PD, C.c_int32, C.c_double, C.c_double, _PD, C.c_int32, _PD]
+        for name in ("oracle_r_runif", "oracle_r_rnorm", "oracle_r_rexp"):
+            getattr(L, name).argtypes = [C.c_uint32, C.c_int64, _PD]
+            getattr(L, name).restype = None
+        L.oracle_r_rgamma_vec.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_int64, _PD]
+        L.oracle_r_rgamma_vec.restype = None
+        L.oracle_r_qnorm.restype = C.c_double
+        L.oracle_r_qnorm.argtypes = [C.c_double]
         L.oracle_ihw_apply.argtypes = [_PD, _PD, C.c_int64, _PD, _PD, C.c_int32, _PI, _PD, _PD, _PD]
         L.oracle_region_universe.restype = C.c_int64
         L.oracle_region_universe.argtypes = [_PI, _PI, C.c_int64, C.c_int32, _PI, C.c_int32, P64, _PI, _PI, _PI]
@@ -292,7 +301,40 @@ def count_table(bait, oe, N, bait_in_RU=None):
 def prior_var_mc(residuals, df):
     """Simulation-matched dispPriorVar for residual d.f. <= 3 from the log dispersion residuals."""
     r = np.asarray(residuals, dtype=np.float64)
+    return lib().oracle_prior_var_mc(_pd(prior_mc_hist(r)), int(df))
+
+
+def prior_mc_hist(residuals) -> np.ndarray:
+    """hist(x[x > -10 & x < 10], breaks = -20:20/2)$counts with hist.default's 1e-7 fuzz on the breaks."""
+    r = np.asarray(residuals, dtype=np.float64)
     r = r[(r > -10) & (r < 10)]
-    counts = np.zeros(40)
-    np.add.at(counts, np.clip(np.ceil((r + 10.0) * 2.0).astype(int) - 1, 0, 39), 1.0)
-    return lib().oracle_prior_var_mc(_pd(counts), int(df))
+    fb = np.arange(-20, 21) / 2.0 + 5e-8
+    fb[0] = -10.0 - 5e-8
+    b = np.searchsorted(fb, r, side="left") - 1  # fb[b] < r <= fb[b+1]
+    return np.bincount(np.clip(b, 0, 39), minlength=40).astype(np.float64)
+
+
+def prior_mc_table(df) -> np.ndarray:
+    """The 200 x 40 simulated densities DESeq2's set.seed(2) stream gives for residual d.f. `df`."""
+    out = np.empty((200, 40))
+    if lib().oracle_prior_mc_table(int(df), _pd(out)):
+        raise ValueError("df must be 1..3")
+    return out
+
+
+def loess_interp(x, y, z, span=0.2, cell=0.2) -> np.ndarray:
+    x, y, z = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, z))
+    out = np.empty(len(z))
+    if lib().oracle_loess_interp(_pd(x), _pd(y), len(x), span, cell, _pd(z), len(z), _pd(out)) < 0:
+        raise ValueError("loess_interp: unsupported size")
+    return out
+
+
+def r_random(kind, seed, n, *args) -> np.ndarray:
+    """set.seed(seed); runif(n) / rnorm(n) / rexp(n) / rgamma(n, shape, scale = s) from the restated R generators."""
+    out = np.empty(n)
+    if kind == "rgamma":
+        lib().oracle_r_rgamma_vec(seed, float(args[0]), float(args[1]), n, _pd(out))
+    else:
+        getattr(lib(), {"runif": "oracle_r_runif", "rnorm": "oracle_r_rnorm", "rexp": "oracle_r_rexp"}[kind])(seed, n, _pd(out))
+    return out

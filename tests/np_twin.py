@@ -103,3 +103,38 @@ def bh(p):
     res[o] = np.minimum(1.0, v)
     out[ok] = res
     return out
+
+
+def loess_interpolate(x, y, z, span=0.2, cell=0.2):
+    """R's loess(y ~ x, span, degree = 2, family = "gaussian", surface = "interpolate") predicted at z, for sorted
+    distinct 1-d x: k-d tree vertices (cells cut between their two middle points until <= floor(n*span*cell) points,
+    box widened by 0.5 %), local quadratic tricube fits over the q = floor(n*span + 1e-5) nearest at the vertices
+    (numpy lstsq), cubic Hermite blending in between (scipy CubicHermiteSpline)."""
+    from scipy.interpolate import CubicHermiteSpline
+    x, y = np.asarray(x, float), np.asarray(y, float)
+    n = len(x)
+    q, fc = int(np.floor(n * span + 1e-5)), int(np.floor(n * (span * cell)))
+    margin = 0.005 * max(x[-1] - x[0], 1e-10 * max(abs(x[0]), abs(x[-1])) + 1e-30)
+    verts = [x[0] - margin, x[-1] + margin]
+
+    def split(lo, hi):  # 1-based inclusive
+        if hi - lo + 1 <= fc:
+            return
+        m = (lo + hi) // 2
+        verts.append((x[m - 1] + x[m]) / 2)
+        split(lo, m)
+        split(m + 1, hi)
+
+    split(1, n)
+    v = np.sort(verts)
+    val, slope = [], []
+    for s in v:
+        d = x - s
+        idx = np.argsort(np.abs(d), kind="stable")[:q]
+        h = np.abs(d[idx]).max()
+        sw = np.sqrt((1 - (np.abs(d[idx]) / h) ** 3) ** 3)
+        X = np.stack([np.ones(q), d[idx], d[idx] ** 2], 1)
+        b = np.linalg.lstsq(X * sw[:, None], y[idx] * sw, rcond=None)[0]
+        val.append(b[0])
+        slope.append(b[1])
+    return CubicHermiteSpline(v, val, slope)(np.asarray(z, float)), v
