@@ -785,10 +785,19 @@ __global__ __launch_bounds__(256) void offsets_kernel(const double *__restrict__
         }
     }
 }
+// norm = "standard" (chicdiff.R:1572-1575): the size factors themselves, one column per sample
+__global__ __launch_bounds__(256) void offsets_sf_kernel(const double *__restrict__ sf, int64_t n, int S, double *__restrict__ out) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        for (int j = 0; j < S; j++) out[(int64_t)j * n + i] = sf[j];
+}
 void launch_offsets(const double *fm, const double *sf_dev, int64_t n, int S, double theta, int mix, double *out,
                     hipStream_t st) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    if (!fm) {
+        offsets_sf_kernel<<<(unsigned)blocks, 256, 0, st>>>(sf_dev, n, S, out);
+        return;
+    }
     if (S <= 16)
         offsets16_kernel<<<(unsigned)blocks, 256, 0, st>>>(fm, sf_dev, n, S, theta, mix, out);
     else

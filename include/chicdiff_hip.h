@@ -128,7 +128,8 @@ int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts
                                   double *sf_host);
 
 /* a4 — offsets (chicdiff.R:1583-1589 M3; :1614-1615 nsf; :1635-1638 / :1666-1669 theta mix).
- * theta = NaN returns normFactorsM3 (norm="fullmean"); otherwise sc(theta). */
+ * theta = NaN returns normFactorsM3 (norm="fullmean"); otherwise sc(theta).  d_fullMean = NULL returns the size
+ * factors, one column per sample (norm="standard", chicdiff.R:1572-1575). */
 int chicdiff_hip_offsets_dev(chicdiff_hip_ctx *ctx, const double *d_fullMean, const double *sf_host,
                              int64_t n, int32_t S, double theta, double *d_nf_out);
 
@@ -241,7 +242,8 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *ctx, const int32_t *counts, const d
 
 /* a5 + a4 + a6 + a7 in one call — size factors -> sc(theta) -> dispersions -> Wald test
  * (chicdiff.R:1561-1562, 1666-1674), with size factors and offsets kept in HBM.  theta = NaN uses
- * normFactorsM3 (norm = "fullmean").  sf_host (S doubles) may be NULL. */
+ * normFactorsM3 (norm = "fullmean"); d_fullMean = NULL uses the size factors alone (norm = "standard",
+ * chicdiff.R:1572-1575).  sf_host (S doubles) may be NULL. */
 int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts, const double *d_fullMean, int64_t n,
                                int32_t S, const int32_t *group, double theta, const chicdiff_nbglm_opts *opts,
                                const chicdiff_nbglm_out *d_out, chicdiff_nbglm_scalars *scalars, double *sf_host);

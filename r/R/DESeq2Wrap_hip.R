@@ -1,44 +1,188 @@
-## DESeq2Wrap_hip.R -- drop-in body for the DESeq2 hand-off inside Chicdiff's DESeq2Wrap().
+## DESeq2Wrap_hip.R -- Chicdiff's DESeq2Wrap() with the MI355X backend behind it.
 ##
-## NOT run in this repository (no R in the authoring image or on the GPU box).  It shows the
-## reference-side binding: the caller-visible function keeps the reference signature
-##     DESeq2Wrap(chicdiff.settings, RU, FullRegionData, suffix = "", theta = NULL)   (chicdiff.R:1494)
-## and only the block chicdiff.R:1557-1691 (+ results(), :1720-1750) is swapped for .Call()s into
-## r/src/chicdiff_hip_shim.c when chicdiff.settings[["backend"]] == "hip"; otherwise the reference
-## DESeq2 path runs unchanged.  The Python mirror chicdiff_amd/deseq2wrap.py is the tested twin.
+## Drop-in for the exported function of the reference (chicdiff.R:1494):
+##     DESeq2Wrap(chicdiff.settings, RU, FullRegionData, suffix = "", theta = NULL)
+## Same arguments, messages, warnings, errors and returned data.table (columns and order of chicdiff.R:1752-1757,
+## attr "theta" as :1759-1760).  With chicdiff.settings[["backend"]] == "hip" the DESeq2 hand-off of
+## chicdiff.R:1540-1691 (+ results(), :1720-1750) runs in libchicdiff_hip.so through the .Call routines of
+## r/src/chicdiff_hip_shim.c; with any other value the reference's own body runs (the maintainer keeps it under the
+## name .DESeq2WrapReference, see INTEGRATION.md).  New optional settings: backend ("hip"), device (GPU index, 0).
+##
+## NOT run in this repository: there is no R in the authoring image or on the GPU box (SURVEY.md §0).  The tested
+## twin with the same control flow is chicdiff_amd/deseq2wrap.py (pandas standing in for data.table).
 
-.hipFit <- function(counts, nf, condition, dispPriorVar = NA_real_) {
-  storage.mode(counts) <- "integer"            # n x S, column-major = sample-major
-  storage.mode(nf) <- "double"
-  lev <- sort(unique(as.character(condition)))  # character -> factor: alphabetical, first = reference
-  stopifnot(length(lev) == 2L)
-  group <- as.integer(as.character(condition) == lev[2L])
-  r <- .Call("chicdiff_hip_fit", counts, nf, group, as.double(dispPriorVar), PACKAGE = "chicdiffhip")
-  for (k in c("baseMean", "log2FoldChange", "lfcSE", "stat", "pvalue", "deviance"))
-    r[[k]][is.nan(r[[k]])] <- NA_real_          # all-zero rows: DESeq2 reports NA
-  r
+.hipEnv <- new.env(parent = emptyenv())
+
+## one context per R process and device (one R process per GPU when sharding, INTEGRATION.md §4)
+.hipContext <- function(device = 0L) {
+  key <- paste0("ctx", device)
+  if (is.null(.hipEnv[[key]]))
+    .hipEnv[[key]] <- .Call("chicdiff_hip_open", as.integer(device), PACKAGE = "chicdiffhip")
+  .hipEnv[[key]]
 }
 
-## residual d.f. <= 3 (e.g. 2 vs 2): DESeq2's prior variance is a Monte-Carlo match drawn from R's session
-## RNG.  The library runs the same matching from a fixed-seed stream of its own (status bit 2), which is the
-## default; set options(chicdiff.hip.priorvar = "DESeq2") to have it computed HERE with DESeq2's own code
-## (and R's RNG) from the GPU's gene-wise estimates and handed back through chicdiff_nbglm_opts.dispPriorVar,
-## exactly the argument DESeq2 exposes.
-.hipPriorVar <- function(fit, modelMatrix, minDisp = 1e-8) {
-  m <- nrow(modelMatrix); p <- ncol(modelMatrix)
-  if (!((m - p) <= 3 && m > p)) return(NA_real_)
-  dds <- DESeq2::makeExampleDESeqDataSet(n = length(fit$dispGeneEst), m = m)
-  S4Vectors::mcols(dds)$dispGeneEst <- fit$dispGeneEst
-  S4Vectors::mcols(dds)$dispFit <- fit$dispFit
-  S4Vectors::mcols(dds)$allZero <- is.na(fit$dispGeneEst)
-  DESeq2::estimateDispersionsPriorVar(dds, modelMatrix = modelMatrix)
+## character condition -> factor: alphabetical levels, the first is the reference level (DESeqDataSetFromMatrix)
+.hipGroup <- function(condition) {
+  lev <- sort(unique(as.character(condition)))
+  if (length(lev) != 2L) stop("design ~ condition needs exactly two conditions, got: ", paste(lev, collapse = ", "))
+  as.integer(as.character(condition) == lev[2L])
 }
 
-DESeq2Hip <- function(regionDataMatrix, normFactors, condition) {
-  fit <- .hipFit(regionDataMatrix, normFactors, condition)
-  X <- stats::model.matrix(~ condition, data.frame(condition = factor(condition)))
-  pv <- if (identical(getOption("chicdiff.hip.priorvar"), "DESeq2")) .hipPriorVar(fit, X) else NA_real_
-  if (!is.na(pv)) fit <- .hipFit(regionDataMatrix, normFactors, condition, dispPriorVar = pv)
-  if (bitwAnd(fit$status, 1L)) stop("parametric dispersion trend failed (DESeq2 would use a local fit)")
+## qf(.99, p, m - p), or NA when DESeq2 would skip the Cook's cutoff (no group with >= 3 replicates)
+.hipCooksCutoff <- function(group) {
+  m <- length(group); p <- 2L
+  if (m > p && max(table(group)) >= 3L) stats::qf(.99, p, m - p) else NA_real_
+}
+
+.hipNA <- function(fit) {
+  for (k in c("baseMean", "log2FoldChange", "lfcSE", "stat", "pvalue", "padj", "dispGeneEst", "dispFit", "dispersion",
+              "deviance", "maxCooks"))
+    fit[[k]][is.nan(fit[[k]])] <- NA_real_   # all-zero rows / filtered rows: DESeq2 reports NA
   fit
+}
+
+.hipCheckFit <- function(fit) {
+  if (bitwAnd(fit$status, 1L))
+    stop("the parametric dispersion trend did not converge; DESeq2 would switch to a local fit here (fitType = \"local\")")
+  fit
+}
+
+## estimateDispersions + nbinomWaldTest + results() for given normalisation factors: what a caller outside
+## DESeq2Wrap() uses (and tools/make_golden.R compares with DESeq2 itself)
+DESeq2Hip <- function(regionDataMatrix, normFactors, condition, device = 0L, alpha = 0.1, dispPriorVar = NA_real_) {
+  storage.mode(regionDataMatrix) <- "integer"   # n x S, column-major = sample-major
+  storage.mode(normFactors) <- "double"
+  group <- .hipGroup(condition)
+  fit <- .Call("chicdiff_hip_fit", .hipContext(device), regionDataMatrix, normFactors, group, as.double(dispPriorVar),
+               .hipCooksCutoff(group), as.double(alpha), as.double(nrow(regionDataMatrix)), ncol(regionDataMatrix),
+               PACKAGE = "chicdiffhip")
+  .hipNA(.hipCheckFit(fit))
+}
+
+## long "recast" table -> dense per-sample fragment columns in (regionID, otherEndID) order + region offsets.
+## setkey(fragData, otherEndID) and by = c("baitID", "regionID", "sample") of chicdiff.R:1526, :1540-1547: inside a
+## region the fragments are added in ascending otherEndID order.
+.hipDenseFragments <- function(FullRegionData) {
+  fragData <- data.table::copy(FullRegionData)  # as the reference: the caller's table must not change
+  data.table::setkey(fragData, otherEndID)
+  samples <- unique(fragData$sample)
+  S <- length(samples)
+  condition <- fragData$condition[seq_len(S)]   # colData, chicdiff.R:1556
+  if (!identical(as.character(fragData$sample[seq_len(S)]), as.character(samples)))
+    stop("FullRegionData: the first rows do not hold one row per sample (recast layout expected)")
+  if (anyNA(fragData$N)) stop("FullRegionData: NA counts")
+  ord <- order(match(fragData$sample, samples), fragData$regionID, fragData$otherEndID)
+  nfrag <- nrow(fragData) %/% S
+  if (nfrag * S != nrow(fragData)) stop("FullRegionData: samples do not cover the same (regionID, otherEndID) rows")
+  region <- matrix(fragData$regionID[ord], ncol = S)
+  oe <- matrix(fragData$otherEndID[ord], ncol = S)
+  if (any(region != region[, 1L]) || any(oe != oe[, 1L]))
+    stop("FullRegionData: samples do not cover the same (regionID, otherEndID) rows")
+  ids <- unique(region[, 1L])
+  if (!identical(as.integer(ids), seq_along(ids)))
+    stop("identical(1:nrow(annoData), annoData$regionID) is not TRUE")  # the reference's stopifnot, chicdiff.R:1717
+  list(samples = samples, condition = condition, S = S, n = length(ids),
+       fragN = matrix(as.integer(fragData$N[ord]), ncol = S),
+       fragFullMean = matrix(as.double(fragData$FullMean[ord]), ncol = S),
+       region_ptr = as.double(c(match(ids, region[, 1L]) - 1L, nfrag)))
+}
+
+## annotation columns of the output table, chicdiff.R:1699-1717
+.hipAnnotation <- function(RU, rmapfile, n) {
+  rmap <- data.table::fread(rmapfile)
+  data.table::setnames(rmap, c("chr", "start", "end", "ID"))
+  ru <- RU[, list(baitID = baitID[1L], minOE = min(otherEndID), maxOE = max(otherEndID)), by = "regionID"]
+  data.table::setkey(ru, regionID)
+  lo <- match(ru$minOE, rmap$ID); hi <- match(ru$maxOE, rmap$ID); b <- match(ru$baitID, rmap$ID)
+  keep <- !is.na(lo) & !is.na(hi) & !is.na(b)   # merge() drops regions whose fragments are not on the map
+  anno <- data.table::data.table(baitID = ru$baitID, maxOE = ru$maxOE, minOE = ru$minOE, regionID = ru$regionID,
+                                 OEchr = rmap$chr[lo], OEstart = rmap$start[lo], OEend = rmap$end[hi],
+                                 baitchr = rmap$chr[b], baitstart = rmap$start[b], baitend = rmap$end[b])[keep]
+  stopifnot(identical(seq_len(nrow(anno)), as.integer(anno$regionID)), nrow(anno) == n)
+  anno
+}
+
+DESeq2Wrap <- function(chicdiff.settings, RU, FullRegionData, suffix = "", theta = NULL) {
+
+  if (!identical(chicdiff.settings[["backend"]], "hip"))
+    return(.DESeq2WrapReference(chicdiff.settings, RU, FullRegionData, suffix = suffix, theta = theta))
+
+  Grid <- chicdiff.settings[["theta_grid"]]
+  rmapfile <- chicdiff.settings[["rmapfile"]]
+  saveAux <- chicdiff.settings[["saveAuxData"]]
+  outprefix <- chicdiff.settings[["outprefix"]]
+  device <- if (is.null(chicdiff.settings[["device"]])) 0L else as.integer(chicdiff.settings[["device"]])
+
+  if (is.null(theta) & !is.null(chicdiff.settings[["theta"]])) theta <- chicdiff.settings[["theta"]]
+
+  norm <- chicdiff.settings[["norm"]]
+  if (!norm %in% c("standard", "fullmean", "combined")) stop("DESeq2Wrap error: Unknown normalisation method.")
+
+  if (!is.null(theta)) {
+    if (theta == 1 & norm != "standard") {
+      warning("Mixing parameter theta set to 1, equivalent to norm = \"standard\". The norm method has been reset accordingly.")
+      norm <- "standard"
+    }
+    if (!theta & norm != "fullmean") {
+      warning("Mixing parameter theta set to 0, equivalent to norm = \"fullmean\". The norm method has been reset accordingly.")
+      norm <- "fullmean"
+    }
+  }
+
+  ctx <- .hipContext(device)
+  fr <- .hipDenseFragments(FullRegionData)
+  n <- fr$n; S <- fr$S
+  group <- .hipGroup(fr$condition)
+
+  ## window sums (chicdiff.R:1540-1556): the count and FullMean matrices stay on the device from here on
+  ws <- .Call("chicdiff_hip_window_sums", ctx, fr$fragN, if (norm != "standard") fr$fragFullMean else NULL,
+              fr$region_ptr, S, PACKAGE = "chicdiffhip")
+  on.exit({ .Call("chicdiff_hip_release", ws$N, PACKAGE = "chicdiffhip")
+            if (!is.null(ws$FullMean)) .Call("chicdiff_hip_release", ws$FullMean, PACKAGE = "chicdiffhip") }, add = TRUE)
+
+  cooks <- .hipCooksCutoff(group)
+  fitWith <- function(fullMean, tt)   # size factors -> sc -> estimateDispersions -> nbinomWaldTest -> results()
+    .hipNA(.hipCheckFit(.Call("chicdiff_hip_wald_test", ctx, ws$N, fullMean, group, as.double(tt), NA_real_, cooks, 0.1,
+                              as.double(n), S, PACKAGE = "chicdiffhip")))
+
+  if (norm == "standard") {           # model 1: size factors only (chicdiff.R:1572-1575)
+    fit <- fitWith(NULL, NA_real_)
+    label <- "Standard DESeq2 normalisation"
+  }
+  if (norm == "fullmean") {           # model 3: normFactorsM3 (chicdiff.R:1598-1604)
+    fit <- fitWith(ws$FullMean, NA_real_)
+    label <- "Chicago full mean-based normalisation"
+  }
+  if (norm == "combined") {           # model 5: sc(theta) (chicdiff.R:1612-1674)
+    tt <- theta
+    if (is.null(tt)) {
+      message("Optimising scaling factors...")
+      nullSizeFactors <- .Call("chicdiff_hip_size_factors", ctx, ws$N, as.double(n), S, PACKAGE = "chicdiffhip")
+      deviances <- .Call("chicdiff_hip_theta_grid", ctx, ws$N, ws$FullMean, nullSizeFactors, as.double(Grid), as.double(n), S,
+                         PACKAGE = "chicdiffhip")
+      deviances[is.nan(deviances)] <- NA_real_   # sum() without na.rm over an all-zero row, chicdiff.R:1647
+      message("Total deviances by theta (Fullmean --> Standard):")
+      cat(sprintf("%f", deviances), "\n", file = stderr())
+      tt <- Grid[which(deviances == min(deviances)[1])]
+    }
+    message("Theta=", tt)
+    if (length(tt) != 1L) stop("theta grid: no unique minimum of the total deviance (an all-zero region makes every deviance NA)")
+    fit <- fitWith(ws$FullMean, tt)
+    label <- "combined normalisation"
+  }
+
+  message("Processing model output")
+  annoData <- .hipAnnotation(RU, rmapfile, n)
+
+  message(label, ": # unweighted interactions with padj<0.05: ", sum(fit$padj < 0.05 & !is.na(fit$padj)))
+  if (saveAux == TRUE) {
+    ## the reference saves the DESeqDataSet here; the GPU path has no S4 object, so the fit's own list is saved
+    message(if (norm == "combined") "Saving the final DESeq object" else "Saving the DESeq object")
+    saveRDS(fit, paste0(outprefix, "_DESeqObj", suffix, ".Rds"))
+  }
+
+  out <- cbind(data.table::data.table(baseMean = fit$baseMean, log2FoldChange = fit$log2FoldChange, lfcSE = fit$lfcSE,
+                                      stat = fit$stat, pvalue = fit$pvalue, padj = fit$padj), annoData)
+  if (norm == "combined") attributes(out)$theta <- tt
+  out
 }

@@ -1,0 +1,9 @@
+/* Declaration-only stand-in for R's R.h: SYNTAX CHECK ONLY (see tests/r_stub/README.md). */
+#ifndef R_STUB_R_H
+#define R_STUB_R_H
+#include <math.h>
+void Rf_error(const char *fmt, ...) __attribute__((noreturn, format(printf, 1, 2)));
+int R_IsNA(double x);
+#define ISNA(x) R_IsNA(x)
+#define ISNAN(x) (isnan(x) != 0)
+#endif
