@@ -8,9 +8,13 @@ on a synthetic n x S count matrix (default: configs[2] of BASELINE.json, 2 M x 8
 configuration the metric is quoted on; it fits one GPU).  Inputs are resident in HBM when the
 timed region starts; outputs stay in HBM.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): rows are sharded, every rank
-holds `--rows` rows of one global (N * rows) x S matrix, and the global statistics (size-factor
-medians, trend sums, MAD) go through RCCL sum-all-reduces => "scaling": "weak".
+N > 1: one rank per GPU, rows sharded in contiguous blocks (chicdiff_amd/dist.py:shard_bounds), the
+global statistics (size-factor medians, trend sums, MAD, deviance) go through RCCL sum-all-reduces.
+`python bench.py --gpus N` from a bare shell starts its own ranks (a child `python -m
+torch.distributed.run`, spawned before this process touches a GPU); under an external
+torch.distributed.run (WORLD_SIZE set) it is a rank.  --scaling strong (default: BASELINE.json
+configs[3], "2 M x 8 sharded across 8 MI355X": --rows is the GLOBAL row count, rows/N per rank) or
+weak (--rows per rank).
 
 Prints ONE JSON line on rank 0.
 """
@@ -133,7 +137,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=2_000_000, help="interactions per GPU")
+    ap.add_argument("--rows", type=int, default=2_000_000, help="interactions: global (strong scaling) or per GPU (weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,29 +146,58 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     args = ap.parse_args()
 
+    force_dist = os.environ.get("CHICDIFF_BENCH_FORCE_DIST") == "1"  # rehearse the N > 1 code path with a 1-rank group
+    share_gpu = os.environ.get("CHICDIFF_BENCH_SHARE_GPU") == "1"    # rehearsal on a one-GPU box: all ranks on device 0, gloo transport
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist):
+        # bare shell: start the ranks ourselves, BEFORE anything here initialises a GPU (never exec from a process
+        # that has), and hand their exit code on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import torch
 
     from chicdiff_amd import hip, synth
+    from chicdiff_amd.dist import shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not share_gpu and torch.cuda.device_count() < world:  # device_count() does not initialise the GPU
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
-    force_dist = os.environ.get("CHICDIFF_BENCH_FORCE_DIST") == "1"  # rehearse the N > 1 code path with a 1-rank group
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    n, S = args.rows, args.samples
-    d = synth.make(n, S, start=rank * n)
+    S = args.samples
+    if args.scaling == "strong":
+        lo, hi = shard_bounds(args.rows, world, rank)
+        n, n_global = hi - lo, args.rows
+    else:
+        lo, n, n_global = rank * args.rows, args.rows, world * args.rows
+    d = synth.make(n, S, start=lo)
     ctx = hip.HipContext(local_rank)
-    collectives = "none (single rank)"
+    collectives, comm_ranks = "none (single rank)", 1
     if dist is not None:
+        comm_ranks = dist.get_world_size()
         try:  # the library's own RCCL communicator: ncclAllReduce issued from C++ on the fit's stream
+            if share_gpu:
+                raise RuntimeError("CHICDIFF_BENCH_SHARE_GPU=1: RCCL refuses two ranks on one device")
             if os.environ.get("CHICDIFF_BENCH_COLLECTIVES") == "torch":
                 raise RuntimeError("CHICDIFF_BENCH_COLLECTIVES=torch")
             ctx.init_rccl()
@@ -171,8 +205,9 @@ def main():
         except Exception as e:  # same protocol through torch.distributed (one Python callback per collective)
             if rank == 0:
                 print(f"direct RCCL unavailable ({e}); using the torch.distributed hook", file=sys.stderr)
-            ctx.set_process_group()
-            collectives = "RCCL through torch.distributed.all_reduce (host callback)"
+            ctx.set_process_group(memory="device_via_host" if share_gpu else "device")
+            collectives = ("gloo through torch.distributed.all_reduce, device buffers staged through the host (one-GPU rehearsal)" if share_gpu
+                           else "RCCL through torch.distributed.all_reduce (host callback)")
     dk = ctx.to_device(d["counts"], np.int32)
     dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)  # region-level FullMean (window sums)
     group = d["group"]
@@ -201,12 +236,12 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.enable_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * n / (elapsed / args.steps)
+    value = n_global / (elapsed / args.steps)
 
     # dominant kernel = largest total HIP-event time inside the timed region
     dom = max(ktimes.items(), key=lambda kv: kv[1][0])
@@ -238,11 +273,11 @@ def main():
     result = {
         "metric": "interactions/sec NB-GLM Wald test", "value": round(value, 1), "unit": "interactions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"synthetic {n} interactions x {S} samples ({S // 2}v{S - S // 2}) per GPU, "
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic {n_global} interactions x {S} samples ({S // 2}v{S - S // 2}), "
                                f"size factors + offsets(theta={args.theta}) + dispersions + Wald, design ~condition",
-                   "rows_per_gpu": n, "samples": S, "global_rows": world * n, "parallelism": f"rows-sharded x{world}",
-                   "collectives": collectives},
+                   "rows_per_gpu": n, "samples": S, "global_rows": n_global, "parallelism": f"rows-sharded x{world}",
+                   "collectives": collectives, "ranks_in_communicator": comm_ranks},
         "roofline": roofline,
         "kernels_ms": {k: [round(v[0] / args.steps, 4), v[1] // args.steps] for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
         "fit_status": int(sc["status"]),

@@ -45,6 +45,7 @@ void oracle_nbglm_default_opts(oracle_nbglm_opts *o) {
     o->dispPriorVar = NAN;
     o->nthreads = 1;
     o->_pad = 0;
+    o->trendCoef[0] = o->trendCoef[1] = NAN;
 }
 
 /* ---------------------------------------------------------------------------------- */
@@ -537,7 +538,12 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
         if (!allZero[i] && dispGene[i] > 100 * o.minDisp) { fm[nfit] = baseMean[i]; fd[nfit] = dispGene[i]; nfit++; }
     double coefs[2] = {NAN, NAN};
     int32_t outer = 0;
-    int trc = nfit > 0 ? oracle_parametric_dispersion_fit(fm, fd, nfit, coefs, &outer) : 4;
+    int trc = 0;
+    if (!isnan(o.trendCoef[0]) && !isnan(o.trendCoef[1])) { /* dispersionFunction<- : a caller-supplied trend */
+        coefs[0] = o.trendCoef[0];
+        coefs[1] = o.trendCoef[1];
+    } else
+        trc = nfit > 0 ? oracle_parametric_dispersion_fit(fm, fd, nfit, coefs, &outer) : 4;
     if (trc) status |= ORACLE_ST_TREND_FAILED;
     out->trendCoef[0] = coefs[0];
     out->trendCoef[1] = coefs[1];
@@ -693,4 +699,142 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
     out->status = status;
     free(baseMean); free(baseVar); free(alphaInit); free(dispGene); free(dispFit); free(dispFinal); free(allZero);
     return 0;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* Arbiter for the gene-wise estimates (tests only).  DESeq2 — and the restatement above — evaluates the Cox-Reid
+ * objective with lgamma(y + 1/alpha) - lgamma(1/alpha), which cancels 6-9 digits once 1/alpha reaches 1e6..1e8 (and,
+ * for counts ~1e9, loses as much in the sums), so a few of the line search's accept / stop decisions per million rows
+ * are taken inside rounding noise — in ANY double-precision implementation, the GPU's included.  This twin runs the
+ * SAME control flow (A2.6-A2.7) in IEEE binary128 (libquadmath: 34 digits; lgammaq, and a digamma by recurrence +
+ * asymptotic series): what the algorithm gives when its arithmetic is effectively exact — the referee when the GPU
+ * and the double-precision oracle disagree on a row. */
+#include <quadmath.h>
+typedef __float128 qd;
+static qd digammaq(qd x) { /* x > 0 */
+    qd s = 0;
+    while (x < 40) { s -= 1 / x; x += 1; }
+    const qd i2 = 1 / (x * x);
+    /* B_2k / (2k): 1/12, -1/120, 1/252, -1/240, 1/132, -691/32760, 1/12, -3617/8160, 43867/14364, -174611/6600 */
+    const qd series = i2 * (1.0Q / 12 - i2 * (1.0Q / 120 - i2 * (1.0Q / 252 - i2 * (1.0Q / 240 - i2 * (1.0Q / 132 - i2 * (691.0Q / 32760 -
+                      i2 * (1.0Q / 12 - i2 * (3617.0Q / 8160 - i2 * (43867.0Q / 14364 - i2 * (174611.0Q / 6600))))))))));
+    return s + logq(x) - 0.5Q / x - series;
+}
+static qd lp_exact(qd a, const double *y, const double *mu, const int32_t *g, int S, int p, int use_prior, qd pmean, qd psig) {
+    const qd alpha = expq(a), r = 1 / alpha;
+    qd wA = 0, wB = 0, ll = 0;
+    const qd lgr = lgammaq(r);
+    for (int j = 0; j < S; j++) {
+        const qd w = 1 / (1 / (qd)mu[j] + alpha);
+        if (p == 2 && g[j]) wB += w; else wA += w;
+        ll += lgammaq((qd)y[j] + r) - lgr - (qd)y[j] * logq((qd)mu[j] + r) - r * log1pq((qd)mu[j] * alpha);
+    }
+    qd pr = 0;
+    if (use_prior) pr = -0.5Q * (a - pmean) * (a - pmean) / psig;
+    return ll + pr - 0.5Q * logq(p == 2 ? wA * wB : wA);
+}
+static qd dlp_exact(qd a, const double *y, const double *mu, const int32_t *g, int S, int p, int use_prior, qd pmean, qd psig) {
+    const qd alpha = expq(a), r = 1 / alpha;
+    qd wA = 0, wB = 0, dA = 0, dB = 0, s = 0;
+    const qd dgr = digammaq(r);
+    for (int j = 0; j < S; j++) {
+        const qd t = 1 / (qd)mu[j] + alpha, w = 1 / t, dw = -1 / (t * t);
+        if (p == 2 && g[j]) { wB += w; dB += dw; } else { wA += w; dA += dw; }
+        const qd ma = (qd)mu[j] * alpha;
+        s += dgr + log1pq(ma) - ma / (1 + ma) - digammaq((qd)y[j] + r) + (qd)y[j] / ((qd)mu[j] + r);
+    }
+    const qd cr = -0.5Q * (p == 2 ? dA / wA + dB / wB : dA / wA);
+    return (r * r * s + cr) * alpha + (use_prior ? -(a - pmean) / psig : 0);
+}
+/* stage 0: gene-wise estimate (start = dispInit, no prior); stage 1: MAP estimate (start / prior mean from dispGene,
+ * dispFit as A4 prescribes, prior variance dispPriorVar) */
+int oracle_arbitrate_disp(const int32_t *counts, const double *nf, int64_t n, int32_t S, const int32_t *group,
+                          const int64_t *rows, int64_t nrows, int32_t stage, const double *dispInit, const double *dispGene,
+                          const double *dispFit, double dispPriorVar, const oracle_nbglm_opts *opts_in, double *out) {
+    oracle_nbglm_opts o;
+    if (opts_in) o = *opts_in; else oracle_nbglm_default_opts(&o);
+    if (S < 2 || S > MAXS) return -1;
+    int cellsize[2] = {0, 0};
+    int32_t g[MAXS];
+    for (int j = 0; j < S; j++) { g[j] = group ? (group[j] != 0) : 0; cellsize[g[j]]++; }
+    const int p = cellsize[1] > 0 ? 2 : 1;
+    const double maxDisp = S > 10 ? (double)S : 10.0;
+    int rc = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int64_t t = 0; t < nrows; t++) {
+        const int64_t i = rows[t];
+        if (i < 0 || i >= n) { rc = -2; continue; }
+        double y[MAXS], mu[MAXS], gm[2] = {0, 0};
+        for (int j = 0; j < S; j++) {
+            y[j] = (double)counts[(int64_t)j * n + i];
+            gm[g[j]] += y[j] / nf[(int64_t)j * n + i];
+        }
+        gm[0] /= cellsize[0];
+        if (p == 2) gm[1] /= cellsize[1];
+        for (int j = 0; j < S; j++) mu[j] = fmax(gm[g[j]] * nf[(int64_t)j * n + i], o.minmu);
+        const int up = stage == 1;
+        double a0;
+        qd pmean = 0, psig = 1;
+        if (!up) a0 = dispInit[i];
+        else {
+            a0 = dispGene[i] > 0.1 * dispFit[i] ? dispGene[i] : dispFit[i];
+            pmean = logq((qd)dispFit[i]);
+            psig = dispPriorVar;
+        }
+        /* fitDisp */
+        const qd eps = 1.0e-4Q, min_log_alpha = logq((qd)o.minDisp / 10);
+        qd a = logq((qd)a0), lp = lp_exact(a, y, mu, g, S, p, up, pmean, psig), dlp = dlp_exact(a, y, mu, g, S, p, up, pmean, psig);
+        qd kappa = o.kappa0;
+        const qd initial_lp = lp;
+        int iter = 0, iter_accept = 0;
+        for (int it = 0; it < o.maxit; it++) {
+            iter++;
+            const qd a_propose = a + kappa * dlp;
+            if (a_propose < -30) kappa = (-30 - a) / dlp;
+            if (a_propose > 10) kappa = (10 - a) / dlp;
+            const qd theta_kappa = -lp_exact(a + kappa * dlp, y, mu, g, S, p, up, pmean, psig);
+            const qd theta_hat_kappa = -lp - kappa * eps * dlp * dlp;
+            if (theta_kappa <= theta_hat_kappa) {
+                iter_accept++;
+                a = a + kappa * dlp;
+                const qd lpnew = lp_exact(a, y, mu, g, S, p, up, pmean, psig), change = lpnew - lp;
+                if (change < (qd)o.dispTol) { lp = lpnew; break; }
+                if (a < min_log_alpha) break;
+                lp = lpnew;
+                dlp = dlp_exact(a, y, mu, g, S, p, up, pmean, psig);
+                kappa = fminq(kappa * 1.1Q, o.kappa0);
+                if (iter_accept % 5 == 0) kappa /= 2;
+            } else
+                kappa /= 2;
+        }
+        double d = (double)expq(a);
+        int grid;
+        if (!up) {
+            d = fmin(d, maxDisp);
+            if (lp < initial_lp + fabsq(initial_lp) / 1e6Q) d = a0;
+            const int conv = (iter < o.maxit) && !(iter == 1);
+            grid = !conv && d > o.minDisp * 10;
+        } else
+            grid = !(iter < o.maxit);
+        if (grid) { /* fitDispGrid */
+            const int G = 20;
+            const qd lo = logq(1e-8Q), hi = logq((qd)maxDisp);
+            qd best = -INFINITY, a_hat = lo;
+            const qd delta = (hi - lo) / (G - 1);
+            for (int q = 0; q < G; q++) {
+                const qd aa = lo + (hi - lo) * q / (G - 1), v = lp_exact(aa, y, mu, g, S, p, up, pmean, psig);
+                if (v > best) { best = v; a_hat = aa; }
+            }
+            qd fbest = -INFINITY, fa = a_hat;
+            for (int q = 0; q < G; q++) {
+                const qd aa = (a_hat - delta) + 2 * delta * q / (G - 1), v = lp_exact(aa, y, mu, g, S, p, up, pmean, psig);
+                if (v > fbest) { fbest = v; fa = aa; }
+            }
+            d = (double)expq(fa);
+        }
+        out[t] = fmin(fmax(d, o.minDisp), maxDisp);
+    }
+    return rc;
 }

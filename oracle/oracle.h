@@ -32,6 +32,7 @@ typedef struct {
     double dispPriorVar; /* NaN = estimate (closed form when m-p > 3; see .c)        */
     int32_t nthreads;    /* OpenMP threads over rows (1 = DESeq2-like single thread)  */
     int32_t _pad;
+    double trendCoef[2]; /* NaN = fit; else alpha(mu) = c0 + c1/mu as given (DESeq2: dispersionFunction<-) */
 } oracle_nbglm_opts;
 
 void oracle_nbglm_default_opts(oracle_nbglm_opts *o);
@@ -71,6 +72,13 @@ int oracle_size_factors(const int32_t *counts, int64_t n, int32_t S, double *sf)
 /* a6 + a7: estimateDispersions + nbinomWaldTest for design ~group (two levels) or ~1 (all group==0). */
 int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t S,
                      const int32_t *group, const oracle_nbglm_opts *opts, oracle_nbglm_out *out);
+
+/* binary128 twin of the dispersion line search (A2.6-A2.7, A4) for the listed rows: the referee when the GPU and the
+ * double-precision restatement disagree on a noise-decided row.  stage 0 = gene-wise (needs dispInit), stage 1 = MAP
+ * (needs dispGene, dispFit, dispPriorVar). */
+int oracle_arbitrate_disp(const int32_t *counts, const double *nf, int64_t n, int32_t S, const int32_t *group,
+                          const int64_t *rows, int64_t nrows, int32_t stage, const double *dispInit, const double *dispGene,
+                          const double *dispFit, double dispPriorVar, const oracle_nbglm_opts *opts, double *out);
 
 /* pieces exported for unit tests ------------------------------------------------------------- */
 double oracle_log_posterior(double log_alpha, const double *y, const double *mu, const int32_t *group,

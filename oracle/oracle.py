@@ -34,7 +34,7 @@ class Opts(C.Structure):
     _fields_ = [("minDisp", C.c_double), ("dispTol", C.c_double), ("kappa0", C.c_double),
                 ("maxit", C.c_int32), ("betaMaxit", C.c_int32), ("betaTol", C.c_double),
                 ("minmu", C.c_double), ("outlierSD", C.c_double), ("dispPriorVar", C.c_double),
-                ("nthreads", C.c_int32), ("_pad", C.c_int32)]
+                ("nthreads", C.c_int32), ("_pad", C.c_int32), ("trendCoef", C.c_double * 2)]
 
 
 _PD, _PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)
@@ -83,6 +83,8 @@ def lib():
         P64 = C.POINTER(C.c_int64)
         L.oracle_fragment_background.argtypes = [_PI, _PI, C.c_int64, C.c_int32, C.c_int32, P64, C.c_int32, _PD, _PD, _PI, _PI,
                                                  _PD, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD]
+        L.oracle_arbitrate_disp.argtypes = [_PI, _PD, C.c_int64, C.c_int32, _PI, C.POINTER(C.c_int64), C.c_int64, C.c_int32, _PD, _PD, _PD,
+                                            C.c_double, C.POINTER(Opts), _PD]
         L.oracle_prior_var_mc.restype = C.c_double
         L.oracle_prior_var_mc.argtypes = [_PD, C.c_int32]
         L.oracle_prior_mc_bin.argtypes = [C.c_double]
@@ -119,8 +121,35 @@ def default_opts(**kw) -> Opts:
     o = Opts()
     lib().oracle_nbglm_default_opts(C.byref(o))
     for k, v in kw.items():
-        setattr(o, k, v)
+        if k == "trendCoef":
+            o.trendCoef[0], o.trendCoef[1] = float(v[0]), float(v[1])
+        else:
+            setattr(o, k, v)
     return o
+
+
+def arbitrate_disp(counts, nf, group, rows, fit, stage="gene") -> np.ndarray:
+    """binary128 re-run of the dispersion line search for `rows` (the referee for rows on which the double-precision
+    restatement and the GPU disagree).  fit: the dict nbglm_fit returned (dispInit; for stage "map" also dispGeneEst,
+    dispFit, dispPriorVar — or any dict with those entries, e.g. with arbitrated gene-wise values substituted)."""
+    k = _cm(counts, np.int32)
+    f = _cm(nf, np.float64)
+    n, S = k.shape
+    g = np.ascontiguousarray(group, dtype=np.int32)
+    r = np.ascontiguousarray(rows, dtype=np.int64)
+    col = lambda name: np.ascontiguousarray(fit[name], dtype=np.float64)
+    out = np.empty(len(r))
+    if stage == "gene":
+        di = col("dispInit")
+        rc = lib().oracle_arbitrate_disp(_pi(k), _pd(f), n, S, _pi(g), r.ctypes.data_as(C.POINTER(C.c_int64)), len(r), 0, _pd(di), None, None,
+                                         0.0, None, _pd(out))
+    else:
+        dg, df = col("dispGeneEst"), col("dispFit")
+        rc = lib().oracle_arbitrate_disp(_pi(k), _pd(f), n, S, _pi(g), r.ctypes.data_as(C.POINTER(C.c_int64)), len(r), 1, None, _pd(dg), _pd(df),
+                                         float(fit["dispPriorVar"]), None, _pd(out))
+    if rc:
+        raise RuntimeError(f"oracle_arbitrate_disp rc={rc}")
+    return out
 
 
 def size_factors(counts) -> np.ndarray:

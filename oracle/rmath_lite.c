@@ -28,20 +28,78 @@
 #define M_1_SQRT_2PI_ 0.398942280401432677939946059934
 #define M_SQRT_32_ 5.656854249492380195206754896838
 
+#include "lgamma_tables.h"
+
+/* R's chebyshev_eval (src/nmath/chebyshev.c): Clenshaw recurrence, the k = 0 coefficient counts half */
+static double chebyshev_eval(double x, const double *a, int n) {
+    double b0 = 0, b1 = 0, b2 = 0;
+    const double twox = x * 2;
+    for (int i = 1; i <= n; i++) {
+        b2 = b1;
+        b1 = b0;
+        b0 = twox * b1 - b2 + a[n - i];
+    }
+    return (b0 - b2) * 0.5;
+}
+
+/* R's gammafn for |x| <= 10 (src/nmath/gamma.c): gamma(1 + y), 0 <= y < 1, from the 22-term series, then the
+ * recurrence up (x >= 2) or down (x < 1) */
+static double gammafn_small(double x) {
+    int n = (int)x;
+    if (x < 0) --n;
+    const double y = x - n; /* n = floor(x), y in [0, 1) */
+    --n;
+    double value = chebyshev_eval(y * 2 - 1, r_gamcs, 22) + .9375;
+    if (n == 0) return value; /* x = 1 + y */
+    if (n < 0) {              /* x < 1 */
+        n = -n;
+        for (int i = 0; i < n; i++) value /= (x + i);
+        return value;
+    }
+    for (int i = 1; i <= n; i++) value *= (y + i); /* 2 <= x <= 10 */
+    return value;
+}
+
+/* R's lgammacor (src/nmath/lgammacor.c), x >= 10: lgamma(x) - (log(sqrt(2 pi)) + (x - .5) log(x) - x) */
+static double lgammacor(double x) {
+    const double xbig = 94906265.62425156, xmax = 3.745194030963158e306;
+    if (x < 10) return NAN;
+    if (x >= xmax) return 0.0; /* underflows */
+    if (x < xbig) {
+        const double tmp = 10 / x;
+        return chebyshev_eval(tmp * tmp * 2 - 1, r_algmcs, 5) / x;
+    }
+    return 1 / (x * 12);
+}
+
+/* R's lgammafn (src/nmath/lgamma.c): what DESeq2's fitDisp evaluates as lgamma(y + 1/alpha) - lgamma(1/alpha) */
 double oracle_lgamma(double x) {
-    int sign;
-    return lgamma_r(x, &sign);
+    if (isnan(x)) return x;
+    if (x <= 0 && x == trunc(x)) return INFINITY; /* pole */
+    const double y = fabs(x);
+    if (y < 1e-306) return -log(y);
+    if (y <= 10) return log(fabs(gammafn_small(x)));
+    if (y > 2.5327372760800758e+305) return INFINITY;
+    if (x > 0) {
+        if (x > 1e17) return x * (log(x) - 1.);
+        if (x > 4934720.) return M_LN_SQRT_2PI_ + (x - 0.5) * log(x) - x;
+        return M_LN_SQRT_2PI_ + (x - 0.5) * log(x) - x + lgammacor(x);
+    }
+    /* x < -10, not an integer: reflection */
+    const double sinpiy = fabs(sin(M_PI * fmod(y, 2.0)));
+    if (sinpiy == 0) return NAN;
+    return 0.225791352644727432363097614947 /* log(sqrt(pi/2)) */ + (x - 0.5) * log(y) - x - log(sinpiy) - lgammacor(y);
 }
 
 /* ---- Loader's saddle-point pieces ------------------------------------------------ */
 
-/* stirlerr(n) = log(n!) - log( sqrt(2*pi*n)*(n/e)^n ) */
+/* stirlerr(n) = log(n!) - log( sqrt(2*pi*n)*(n/e)^n )  (R src/nmath/stirlerr.c, the pre-4.4 form) */
 double oracle_stirlerr(double n) {
     static const double S0 = 1.0 / 12.0, S1 = 1.0 / 360.0, S2 = 1.0 / 1260.0,
                         S3 = 1.0 / 1680.0, S4 = 1.0 / 1188.0;
     if (n <= 15.0) {
-        if (n == 0.0) return 0.0; /* table entry sferr_halves[0] */
-        /* R tabulates exact values at half-integers; lgamma gives the same numbers to <1 ulp */
+        const double nn = n + n;
+        if (nn == (int)nn) return r_sferr_halves[(int)nn]; /* R's exact table at half-integers */
         return oracle_lgamma(n + 1.0) - (n + 0.5) * log(n) + n - M_LN_SQRT_2PI_;
     }
     double nn = n * n;

@@ -6,6 +6,8 @@ bit-exact.  The dispersion line search and the IRLS stop on data-dependent toler
 a last-bit difference between libm and the device math can flip one stopping decision in a
 rare row; the tests therefore require >= 99.9 % of rows within 1e-6 AND every row within a
 loose bound, and print the exact counts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -34,13 +36,30 @@ def rel(a, b):
     return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
 
 
-def check_close(name, got, ref, mask, tol=1e-6, frac=0.999, loose=None):
+PARITY_LOG = []  # every comparison of this module; tests/conftest.py writes it to gpurun_out/parity_gpu.json
+
+
+def check_close(name, got, ref, mask, tol=1e-6, frac=None, loose=None, noise_rows=0):
+    """>= `frac` of the rows within `tol` AND every row (but at most `noise_rows` explicitly allowed ones) within
+    `loose`.  frac defaults to 0.9999 from 20 000 rows up, 0.999 below; loose to 1e-3 (p-values 1e-2)."""
+    import inspect
     r = rel(got[mask], ref[mask])
+    n = int(mask.sum())
+    if frac is None:
+        frac = 0.9999 if n >= 20000 else 0.999
+    if loose is None:
+        loose = 1e-2 if "pvalue" in name or "padj" in name else 1e-3
     ok = r <= tol
-    print(f"{name}: n={mask.sum()} max rel {r.max():.3e} within {tol:g}: {ok.mean():.6f} ({(~ok).sum()} rows off)")
+    off_loose = int((r > loose).sum())
+    test = next((f.function for f in inspect.stack() if f.function.startswith("test_")), "?")
+    PARITY_LOG.append(dict(test=test, column=name, rows=n, tol=tol, max_rel=float(r.max()) if n else 0.0, rows_off=int((~ok).sum()),
+                           frac_within=float(ok.mean()) if n else 1.0, required_frac=frac, loose=loose, rows_beyond_loose=off_loose,
+                           noise_rows_allowed=noise_rows))
+    print(f"{name}: n={n} max rel {r.max():.3e} within {tol:g}: {ok.mean():.6f} ({(~ok).sum()} rows off, {off_loose} beyond {loose:g})")
+    if os.environ.get("CHICDIFF_PARITY_RECORD_ONLY") == "1":  # survey run: collect the numbers, judge nothing
+        return
     assert ok.mean() >= frac, name
-    if loose is not None:
-        assert r.max() <= loose, name
+    assert off_loose <= noise_rows, (name, float(r.max()))
 
 
 WANT = ["baseMean", "baseVar", "dispGeneEst", "dispFit", "dispMAP", "dispersion", "log2FoldChange", "lfcSE", "stat",
@@ -75,16 +94,16 @@ def test_fit_parity_two_groups(ctx, oracle, n, S):
     # so only "both at the floor" is required of them
     floor = ref["dispGeneEst"] < 1e-6
     assert np.all(got["dispGeneEst"][nz & floor] < 1e-6)
-    check_close("dispGeneEst", got["dispGeneEst"], ref["dispGeneEst"], nz & ~floor, 1e-6, 0.999)
+    check_close("dispGeneEst", got["dispGeneEst"], ref["dispGeneEst"], nz & ~floor, 1e-6)
     check_close("dispFit", got["dispFit"], ref["dispFit"], nz, 1e-7, 1.0)
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6, 0.999)
-    check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6, 0.999, 1e-2)
-    check_close("lfcSE", got["lfcSE"], ref["lfcSE"], nz, 1e-6, 0.999, 1e-2)
-    check_close("pvalue", got["pvalue"], ref["pvalue"], nz, 1e-6, 0.999, 0.2)
-    check_close("deviance", got["deviance"], ref["deviance"], nz, 1e-6, 0.999)
+    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
+    check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6)
+    check_close("lfcSE", got["lfcSE"], ref["lfcSE"], nz, 1e-6)
+    check_close("pvalue", got["pvalue"], ref["pvalue"], nz, 1e-6)
+    check_close("deviance", got["deviance"], ref["deviance"], nz, 1e-6)
     mc = nz & np.isfinite(ref["maxCooks"])
     assert mc.sum() == nz.sum()
-    check_close("maxCooks", got["maxCooks"], ref["maxCooks"], mc & (ref["maxCooks"] > 1e-12), 1e-5, 0.999)
+    check_close("maxCooks", got["maxCooks"], ref["maxCooks"], mc & (ref["maxCooks"] > 1e-12), 1e-5)
     # rows sitting at alpha = minDisp (1/alpha = 1e8) search on pure cancellation noise in DESeq2 as well:
     # their iteration count is not reproducible across libm implementations, their estimate (1e-8) is.
     interior = nz & (ref["dispGeneEst"] > 1e-6)
@@ -102,9 +121,9 @@ def test_fit_parity_2v2_with_prior(ctx, oracle):
     ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], dispPriorVar=0.8)
     nz = ref["allZero"] == 0
     assert sc["dispPriorVar"] == 0.8
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6, 0.999)
-    check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6, 0.999, 1e-2)
-    check_close("pvalue", got["pvalue"], ref["pvalue"], nz, 1e-6, 0.999, 0.2)
+    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
+    check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6)
+    check_close("pvalue", got["pvalue"], ref["pvalue"], nz, 1e-6)
     assert np.all(np.isnan(got["maxCooks"]))
     # without a caller-supplied prior the closed form is used and flagged
     _, sc2 = run_fit(ctx, d, d["group"])
@@ -121,9 +140,9 @@ def test_fit_parity_intercept_only(ctx, oracle, S):
     got, sc = run_fit(ctx, d, g, dispPriorVar=0.6)
     ref = oracle.nbglm_fit(d["counts"], d["nf"], g, dispPriorVar=0.6)
     nz = np.ones(len(d["counts"]), bool)
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6, 0.999)
+    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
     check_close("intercept", got["intercept"], ref["beta0"], nz, 1e-12, 1.0)
-    check_close("deviance", got["deviance"], ref["deviance"], nz, 1e-6, 0.999)
+    check_close("deviance", got["deviance"], ref["deviance"], nz, 1e-6)
     assert np.isclose(sc["sumDeviance"], ref["sumDeviance"], rtol=1e-7)
     assert np.all(np.isnan(got["log2FoldChange"]))
 
@@ -232,7 +251,7 @@ def test_host_entry_point_and_errors(ctx, oracle):
     res, sc = ctx.nbglm_fit_host(d["counts"], d["nf"], d["group"])
     ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"])
     nz = ref["allZero"] == 0
-    check_close("pvalue(host)", res["pvalue"], ref["pvalue"], nz, 1e-6, 0.999)
+    check_close("pvalue(host)", res["pvalue"], ref["pvalue"], nz, 1e-6)
     with pytest.raises(hip.ChicdiffHipError):
         ctx.nbglm_fit_host(d["counts"], d["nf"], [0, 0, 1, 1, 2, 2, 0, 1])
     with pytest.raises(hip.ChicdiffHipError):
@@ -341,7 +360,7 @@ def test_deseq2wrap_mirror(ctx, oracle, tmp_path, norm):
         assert out.attrs["theta"] == tt
         nf = oracle.offsets(FM, sf, tt)
     ref = oracle.nbglm_fit(N, nf, group)
-    check_close("lfc", out["log2FoldChange"].to_numpy(), ref["log2FoldChange"], np.abs(ref["log2FoldChange"]) > 1e-3, 1e-6, 0.999)
+    check_close("lfc", out["log2FoldChange"].to_numpy(), ref["log2FoldChange"], np.abs(ref["log2FoldChange"]) > 1e-3, 1e-6)
     pv, nout = results.cooks_filter(ref["pvalue"], ref["maxCooks"], ref["cooksArgmax"], lambda idx: N[idx], group)
     got_p = out["pvalue"].to_numpy()
     assert np.array_equal(np.isnan(got_p), np.isnan(pv)) and nout > 0  # Cook's outliers flagged identically (4v4)
@@ -350,12 +369,12 @@ def test_deseq2wrap_mirror(ctx, oracle, tmp_path, norm):
     assert (ref["betaIter"] >= 100).sum() > 0 and np.all(ref["betaConv"][ref["allZero"] == 0] == 1)
     conv = ref["betaConv"] == 1
     ok = ~np.isnan(pv) & conv
-    check_close("pvalue", got_p, pv, ok, 1e-6, 0.999)
+    check_close("pvalue", got_p, pv, ok, 1e-6)
     padj_ref, _ = results.independent_filtering(ref["baseMean"], pv)
     got = out["padj"].to_numpy()
     assert np.array_equal(np.isnan(got), np.isnan(padj_ref))
     okp = ~np.isnan(padj_ref) & conv
-    check_close("padj", got, padj_ref, okp, 1e-6, 0.995)
+    check_close("padj", got, padj_ref, okp, 1e-6)
     # annotation: window bounds and rmap coordinates (chicdiff.R:1703-1714)
     r0 = out.iloc[0]
     assert r0["minOE"] == RU[RU.regionID == 1].otherEndID.min() and r0["OEstart"] == (r0["minOE"] - 1) * 1000 + 1
@@ -433,14 +452,21 @@ def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     """BASELINE.json configs[2] (2 M x 8, 4v4) at full size, every row against the oracle (run on the host
     cores), plus a size-independent property (row permutation).
 
-    At this size a dozen rows (6 per million) take a different branch of the gene-wise line search in the
-    oracle than on the GPU: DESeq2's objective is evaluated as lgamma(y+1/alpha) - lgamma(1/alpha), which
-    cancels ~7 digits for alpha ~ 1e-6..1e-4, and the "change < 1e-6" stopping test then sits inside libm's
-    rounding noise (the GPU uses a cancellation-free difference form).  Those rows move the *global* trend
-    coefficients in their 6th digit, and with them every row's MAP dispersion.  So: (1) the free fit is held
-    to 1e-4; (2) with the two global scalars pinned to the oracle's (DESeq2 exposes both: dispersionFunction<-
-    and dispPriorVar) every row must agree to 1e-6."""
-    import os
+    The line search stops on `change < 1e-6` in a log-likelihood of size 1e2..1e5 and accepts steps on an Armijo
+    inequality: in ANY double-precision implementation a few of these decisions per million rows fall inside rounding
+    noise (DESeq2 evaluates lgamma(y + 1/alpha) - lgamma(1/alpha), the oracle does the same with R's own lgammafn
+    restated, the GPU uses a cancellation-free form), the row then ends somewhere else, and through the global trend
+    fit such a row moves EVERY row's MAP dispersion in the 6th digit.  So the chain is checked link by link:
+    (1) gene-wise estimates: all rows agree to 1e-6 except a listed handful (<= 3 per 100 000); each listed row is
+        re-run in binary128 by the arbiter (oracle_arbitrate_disp), which must side with one of the two — the table
+        (who was right where) is written to gpurun_out/arbiter_2Mx8.json;
+    (2) trend | gene-wise estimates: the oracle's own trend routine, fed the GPU's estimates, returns the GPU's
+        coefficients to 1e-10; fed the arbitrated estimates it lands within 2e-5 of both sides;
+    (3) everything downstream | trend: the oracle, given the GPU's two trend coefficients, reproduces the GPU's FREE
+        fit to 1e-6 on >= 99.99 % of the rows (dispersion, lfc, p); and the GPU, given the oracle's trend and prior
+        variance (DESeq2 exposes both), reproduces the oracle's free fit to 1e-6;
+    (4) permuting the rows permutes the results."""
+    import json
     import torch
     from chicdiff_amd import hip
     n, S = 2_000_000, 8
@@ -449,32 +475,61 @@ def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     want = ["log2FoldChange", "pvalue", "dispersion", "dispGeneEst"]
     out, sc = ctx.nbglm_fit(dk, dn, d["group"], want=want)
     got = {k: v.cpu().numpy() for k, v in out.items()}
-    ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], nthreads=min(16, os.cpu_count() or 1))
+    threads = min(16, os.cpu_count() or 1)
+    ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], nthreads=threads)
     nz = (ref["allZero"] == 0) & (ref["betaConv"] == 1)
     big = nz & (np.abs(ref["log2FoldChange"]) > 1e-2)
     print("trend", sc["trendCoef"], ref["trendCoef"], sc["trendOuterIter"], ref["trendOuterIter"])
-    assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-4) and sc["trendOuterIter"] == ref["trendOuterIter"]
-    interior = nz & (ref["dispGeneEst"] > 1e-6)
-    rg = rel(got["dispGeneEst"][interior], ref["dispGeneEst"][interior])
-    print("gene-wise estimates off by > 1e-6:", int((rg > 1e-6).sum()), "of", int(interior.sum()))
-    assert (rg > 1e-6).sum() <= 1e-4 * interior.sum()
-    # the oracle's own trend routine, fed the GPU's gene-wise estimates, lands on the GPU's coefficients:
+    assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=2e-5) and sc["trendOuterIter"] == ref["trendOuterIter"]
+    # (1) rows that enter the trend on either side (alpha > 1e-6) and differ: list and arbitrate
+    live = (ref["allZero"] == 0) & ((ref["dispGeneEst"] > 1e-6) | (got["dispGeneEst"] > 1e-6))
+    rg = rel(got["dispGeneEst"], ref["dispGeneEst"])
+    bad = np.nonzero(live & (rg > 1e-6))[0]
+    print("gene-wise estimates off by > 1e-6:", len(bad), "of", int(live.sum()))
+    assert len(bad) <= 3e-5 * live.sum()
+    arb = oracle.arbitrate_disp(d["counts"], d["nf"], d["group"], bad, ref)
+    e_gpu, e_ora = rel(got["dispGeneEst"][bad], arb), rel(ref["dispGeneEst"][bad], arb)
+    table = [dict(row=int(i), gpu=float(got["dispGeneEst"][i]), oracle=float(ref["dispGeneEst"][i]), arbiter=float(a),
+                  gpu_vs_arbiter=float(x), oracle_vs_arbiter=float(y)) for i, a, x, y in zip(bad, arb, e_gpu, e_ora)]
+    for t in table:
+        print("  row %(row)d: gpu %(gpu).9e oracle %(oracle).9e arbiter %(arbiter).9e  (gpu-arb %(gpu_vs_arbiter).1e, oracle-arb %(oracle_vs_arbiter).1e)" % t)
+    gpu_right, ora_right = int((e_gpu <= 1e-6).sum()), int((e_ora <= 1e-6).sum())
+    neither = int(((e_gpu > 1e-6) & (e_ora > 1e-6)).sum())
+    print(f"binary128 arbiter: GPU right on {gpu_right}, oracle right on {ora_right}, neither on {neither} of {len(bad)} rows")
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(dict(n=n, S=S, rows_compared=int(live.sum()), disagreeing_rows=table, gpu_matches_arbiter=gpu_right,
+                   oracle_matches_arbiter=ora_right, neither=neither), open("gpurun_out/arbiter_2Mx8.json", "w"), indent=1)
+    assert neither <= 2  # a row both double-precision paths miss would be a systematic error, not rounding noise
+    # (2) trend | gene-wise estimates
     useg = (ref["allZero"] == 0) & (got["dispGeneEst"] > 1e-6)
     cg, itg, rc = oracle.parametric_dispersion_fit(ref["baseMean"][useg], got["dispGeneEst"][useg])
     assert rc == 0 and np.allclose(cg, sc["trendCoef"], rtol=1e-10)
-    check_close("dispersion(2M, free)", got["dispersion"], ref["dispersion"], nz, 1e-4, 0.999)
-    check_close("pvalue(2M, free)", got["pvalue"], ref["pvalue"], nz, 1e-3, 0.999)
-    # (2) global scalars pinned
+    dg = ref["dispGeneEst"].copy()
+    dg[bad] = arb
+    use = (ref["allZero"] == 0) & (dg > 1e-6)
+    c_arb, it_arb, rc = oracle.parametric_dispersion_fit(ref["baseMean"][use], dg[use])
+    print("trend: arbitrated", c_arb, "GPU", sc["trendCoef"], "oracle", ref["trendCoef"])
+    assert rc == 0 and np.allclose(c_arb, sc["trendCoef"], rtol=2e-5) and np.allclose(c_arb, ref["trendCoef"], rtol=2e-5)
+    # (3a) the oracle under the GPU's trend against the GPU's free fit
+    ref_g = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], nthreads=threads, trendCoef=sc["trendCoef"])
+    keep = nz.copy()
+    keep[bad] = False  # listed above; their MAP start value / outlier flag follow each side's own gene-wise estimate
+    assert np.isclose(sc["varLogDispEsts"], ref_g["varLogDispEsts"], rtol=1e-5)
+    check_close("dispersion(2M, free fit | trend)", got["dispersion"], ref_g["dispersion"], keep, 1e-6)
+    check_close("lfc(2M, free fit | trend)", got["log2FoldChange"], ref_g["log2FoldChange"], keep & big, 1e-6)
+    check_close("pvalue(2M, free fit | trend)", got["pvalue"], ref_g["pvalue"], keep, 1e-6)
+    # the two free fits against each other: what the 6th-digit trend shift does to every row
+    check_close("dispersion(2M, free vs free)", got["dispersion"], ref["dispersion"], keep, 2e-5, 0.999)
+    check_close("pvalue(2M, free vs free)", got["pvalue"], ref["pvalue"], keep, 2e-4, 0.999)
+    # (3b) the GPU under the oracle's global scalars against the oracle's free fit
     opts = hip.default_opts(trendCoef=ref["trendCoef"], dispPriorVar=ref["dispPriorVar"])
     out2, sc2 = ctx.nbglm_fit(dk, dn, d["group"], want=want, opts=opts)
     got2 = {k: v.cpu().numpy() for k, v in out2.items()}
     assert np.array_equal(sc2["trendCoef"], ref["trendCoef"]) and sc2["dispPriorVar"] == ref["dispPriorVar"]
-    # a median over 1.75 M residuals spaced ~1e-6 apart: the dozen noise-decided rows move it in the 6th digit
-    assert np.isclose(sc2["varLogDispEsts"], ref["varLogDispEsts"], rtol=1e-4)
-    check_close("dispersion(2M, pinned)", got2["dispersion"], ref["dispersion"], nz, 1e-6, 0.9999)
-    check_close("lfc(2M, pinned)", got2["log2FoldChange"], ref["log2FoldChange"], big, 1e-6, 0.9999)
-    check_close("pvalue(2M, pinned)", got2["pvalue"], ref["pvalue"], nz, 1e-6, 0.9999)
-    # (3) permuting the rows permutes the results (order-free sums, exact medians)
+    check_close("dispersion(2M, pinned)", got2["dispersion"], ref["dispersion"], keep, 1e-6)
+    check_close("lfc(2M, pinned)", got2["log2FoldChange"], ref["log2FoldChange"], keep & big, 1e-6)
+    check_close("pvalue(2M, pinned)", got2["pvalue"], ref["pvalue"], keep, 1e-6)
+    # (4) permuting the rows permutes the results (order-free sums, exact medians)
     perm = torch.randperm(n, device=ctx.device, generator=torch.Generator(device=ctx.device).manual_seed(0))
     p1 = out["pvalue"][perm].cpu().numpy()
     out3, sc3 = ctx.nbglm_fit(dk[:, perm].contiguous(), dn[:, perm].contiguous(), d["group"], want=["pvalue"])
@@ -484,6 +539,35 @@ def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     r = rel(p2[ok], p1[ok])
     print("permutation: max rel", r.max(), "frac within 1e-9", np.mean(r < 1e-9))
     assert np.array_equal(np.isnan(p1), np.isnan(p2)) and np.mean(r < 1e-9) > 0.999 and r.max() < 1e-4
+
+
+def test_full_size_C2_200k_x4_2v2_against_oracle(ctx, oracle):
+    """BASELINE.json configs[1] at full size: 200 000 interactions x 4 samples, 2 v 2 — the reference's own design
+    (Chicdiff.Rmd:42).  Residual d.f. = 2, so dispPriorVar comes from DESeq2's set.seed(2) simulation (prior_mc.h):
+    the device histogram + KL + loess must land on the oracle's value exactly, and dispersions / lfc / p follow."""
+    n, S = 200_000, 4
+    d = synth.make(n, S)
+    got, sc = run_fit(ctx, d, d["group"])
+    ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], nthreads=min(16, os.cpu_count() or 1))
+    assert sc["status"] & 2 and ref["status"] & 2
+    print("dispPriorVar", sc["dispPriorVar"], ref["dispPriorVar"], "trend", sc["trendCoef"], ref["trendCoef"])
+    assert sc["dispPriorVar"] == ref["dispPriorVar"]
+    assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6) and sc["trendOuterIter"] == ref["trendOuterIter"]
+    nz = (ref["allZero"] == 0) & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
+    check_close("dispersion(C2)", got["dispersion"], ref["dispersion"], nz, 1e-6)
+    check_close("lfc(C2)", got["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-2), 1e-6)
+    check_close("pvalue(C2)", got["pvalue"], ref["pvalue"], nz, 1e-6)
+    assert np.all(np.isnan(got["maxCooks"]))  # no group with >= 3 replicates
+    # a heterogeneous 2v2 matrix of the same size: the prior variance lands above DESeq2's 0.25 floor
+    from test_oracle import heterogeneous_counts
+    counts, nf = heterogeneous_counts(n, S, 1.3)
+    got, sc = run_fit(ctx, dict(counts=counts, nf=nf), d["group"])
+    ref = oracle.nbglm_fit(counts, nf, d["group"], nthreads=min(16, os.cpu_count() or 1))
+    print("heterogeneous: dispPriorVar", sc["dispPriorVar"], ref["dispPriorVar"])
+    assert sc["dispPriorVar"] == ref["dispPriorVar"] and sc["dispPriorVar"] > 0.3
+    nz = (ref["allZero"] == 0) & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
+    check_close("dispersion(C2 heterogeneous)", got["dispersion"], ref["dispersion"], nz, 1e-6)
+    check_close("pvalue(C2 heterogeneous)", got["pvalue"], ref["pvalue"], nz, 1e-6)
 
 
 def _two_rank_worker(rank, world, port, n, S, q):
@@ -809,9 +893,9 @@ def test_fit_edge_shapes(ctx, oracle, n, S, nB):
     assert np.array_equal(got["allZero"], ref["allZero"]) and sc["status"] & 1 == 0
     assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6)
     conv = nz & (ref["betaConv"] == 1)
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6, 0.995)
-    check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], conv & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6, 0.995, 1e-2)
-    check_close("pvalue", got["pvalue"], ref["pvalue"], conv, 1e-6, 0.995, 0.2)
+    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
+    check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], conv & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6)
+    check_close("pvalue", got["pvalue"], ref["pvalue"], conv, 1e-6)
 
 
 def test_fit_extreme_counts(ctx, oracle):
@@ -840,13 +924,25 @@ def test_fit_extreme_counts(ctx, oracle):
     isbig = np.zeros(n, bool)
     isbig[big] = True
     check_close("baseMean", got["baseMean"], ref["baseMean"], nz, 1e-12, 1.0)
-    assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-7)
+    # gene-wise estimates: ordinary rows to 1e-6; the ~1e9 rows are noise-decided on BOTH double-precision sides, so
+    # each side is compared with the binary128 arbiter instead
+    check_close("dispGeneEst(ordinary rows)", got["dispGeneEst"], ref["dispGeneEst"], nz & ~isbig & (ref["dispGeneEst"] > 1e-6), 1e-6)
+    bigrows = np.nonzero(nz & isbig)[0]
+    arb = oracle.arbitrate_disp(counts, nf, group, bigrows, ref)
+    eg, eo = rel(got["dispGeneEst"][bigrows], arb), rel(ref["dispGeneEst"][bigrows], arb)
+    print(f"counts ~1e9, gene-wise vs binary128 arbiter: GPU median {np.median(eg):.1e} max {eg.max():.1e}; oracle median {np.median(eo):.1e} max {eo.max():.1e}")
+    assert np.median(eg) < 1e-4 and np.mean(eg < 2e-2) > 0.97
+    # trend | gene-wise estimates, then everything downstream under the GPU's trend
+    useg = nz & (got["dispGeneEst"] > 1e-6)
+    cg, _, rc = oracle.parametric_dispersion_fit(ref["baseMean"][useg], got["dispGeneEst"][useg])
+    assert rc == 0 and np.allclose(cg, sc["trendCoef"], rtol=1e-9)
+    assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-4)
+    ref = oracle.nbglm_fit(counts, nf, group, trendCoef=sc["trendCoef"])
     conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
     assert conv.sum() > 0.98 * nz.sum()
-    check_close("dispGeneEst", got["dispGeneEst"], ref["dispGeneEst"], nz & (ref["dispGeneEst"] > 1e-6), 1e-6, 0.999)
-    check_close("dispersion(ordinary rows)", got["dispersion"], ref["dispersion"], nz & ~isbig, 1e-6, 0.999)
-    check_close("pvalue(ordinary rows)", got["pvalue"], ref["pvalue"], conv & ~isbig, 1e-6, 0.999, 0.2)
-    check_close("dispersion(counts ~1e9)", got["dispersion"], ref["dispersion"], nz & isbig, 2e-2, 1.0)
+    check_close("dispersion(ordinary rows)", got["dispersion"], ref["dispersion"], nz & ~isbig, 1e-6)
+    check_close("pvalue(ordinary rows)", got["pvalue"], ref["pvalue"], conv & ~isbig, 1e-6)
+    check_close("dispersion(counts ~1e9)", got["dispersion"], ref["dispersion"], nz & isbig, 2e-2, 0.97, loose=1.0)
     # the IRLS stops on a relative deviance change of 1e-8 while the deviance itself (~250, the difference of two
     # ~1e10 sums) carries ~1e-5 of noise on both sides: fold changes agree to a few 1e-3 (absolute, log2 units)
     irls = conv & isbig & (ref["betaIter"] < 100) & (got["betaIter"] < 100)
@@ -961,7 +1057,7 @@ def test_prior_variance_by_simulation_matches_oracle(ctx, oracle, S, group):
     assert np.isclose(sc["varLogDispEsts"], ref["varLogDispEsts"], rtol=1e-7)
     assert sc["dispPriorVar"] == ref["dispPriorVar"] and sc["dispPriorVar"] > 0.3, (sc["dispPriorVar"], ref["dispPriorVar"])
     nz = ref["allZero"] == 0
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6, 0.995)
+    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
     if group.any():
         conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
-        check_close("pvalue", got["pvalue"], ref["pvalue"], conv, 1e-6, 0.995)
+        check_close("pvalue", got["pvalue"], ref["pvalue"], conv, 1e-6)
