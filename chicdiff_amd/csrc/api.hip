@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,10 @@ struct KTimer {
 struct chicdiff_hip_ctx {
     int device = 0;
     bool no_persistent_trend = false;  // set after a grid-barrier timeout (see fit_dev_impl)
+    // tuning / test options (chicdiff_hip_set_option); the defaults are what the benchmarks run
+    int opt_spread = 1, opt_min_waves = 2, opt_select_rounds = 0, opt_trend_multilaunch = 0;
+    std::vector<chicdiff_hip_ctx *> lanes;  // theta grid: child contexts (own stream + workspace), one per concurrent fit
+    int opt_grid_lanes = 5;                 // theta grid: fits in flight at once (1 = one after the other)
     int cu_count = 0;  // compute units of the device (the persistent trend kernel needs one resident workgroup per CU it launches)
     hipStream_t own_stream = nullptr, stream = nullptr;
     chicdiff_allreduce_fn allreduce = nullptr;
@@ -109,6 +114,18 @@ void chicdiff_hip_default_opts(chicdiff_nbglm_opts *o) {
     o->trendCoef[0] = o->trendCoef[1] = NAN;
 }
 
+int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return CHICDIFF_E_INVALID;
+    const std::string k(name);
+    if (k == "line_search_spread" && (value == 0 || value == 1)) c->opt_spread = (int)value;
+    else if (k == "line_search_min_waves" && value >= 2 && value <= 4) c->opt_min_waves = (int)value;
+    else if (k == "theta_grid_concurrency" && value >= 1 && value <= 16) c->opt_grid_lanes = (int)value;
+    else if (k == "select_all_rounds" && (value == 0 || value == 1)) c->opt_select_rounds = (int)value;
+    else if (k == "trend_one_launch_per_pass" && (value == 0 || value == 1)) c->opt_trend_multilaunch = (int)value;
+    else return fail(c, CHICDIFF_E_INVALID, "set_option: unknown option or value (%s = %lld)", name, (long long)value);
+    return CHICDIFF_OK;
+}
+
 int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
     if (!out) return fail(nullptr, CHICDIFF_E_INVALID, "ctx out pointer is NULL");
     *out = nullptr;
@@ -152,6 +169,8 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto *l : c->lanes) chicdiff_hip_destroy(l);
+    c->lanes.clear();
     if (c->ws) (void)hipFree(c->ws);
     if (c->aux) (void)hipFree(c->aux);
     if (c->d_sf) (void)hipFree(c->d_sf);
@@ -421,7 +440,7 @@ struct HipBackend {
         launch_sel_step(sa, c->w, c->stream);
     }
     bool sel_shortcut(const SelSpec &) {
-        if (c->allreduce || getenv("CHICDIFF_SELECT_SIXROUNDS")) return false;  // sharded: candidates live on other ranks too
+        if (c->allreduce || c->opt_select_rounds) return false;  // sharded: candidates live on other ranks too
         Scope t(c, "select_shortcut");
         sa.shift = 40;
         launch_sel_shortcut(sa, c->w, c->stream);
@@ -434,7 +453,7 @@ struct HipBackend {
     }
     // sharded shortcut
     int world_size() const { return c->world; }
-    bool sel_can_gather() const { return c->world <= kSelMaxWorld && !getenv("CHICDIFF_SELECT_SIXROUNDS"); }
+    bool sel_can_gather() const { return c->world <= kSelMaxWorld && !c->opt_select_rounds; }
     double *sel_counts() { return c->w.selcnt; }
     void sel_keep_local_hist(const SelSpec &) { launch_sel_keep_local(sa, c->w, c->stream); }
     void sel_gather_counts(const SelSpec &) { launch_sel_gather_counts(sa, c->w, c->world, c->rank, c->stream); }
@@ -472,7 +491,7 @@ static int check_counts_group(chicdiff_hip_ctx *c, int64_t n, int32_t S, const i
     return CHICDIFF_OK;
 }
 
-static Opts make_opts(const chicdiff_nbglm_opts *in, int S) {
+static Opts make_opts(const chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *in, int S) {
     chicdiff_nbglm_opts o;
     if (in) o = *in; else chicdiff_hip_default_opts(&o);
     Opts r;
@@ -481,6 +500,8 @@ static Opts make_opts(const chicdiff_nbglm_opts *in, int S) {
     r.maxDisp = S > 10 ? (double)S : 10.0;
     r.trendIn[0] = o.trendCoef[0];
     r.trendIn[1] = o.trendCoef[1];
+    r.spread = c->opt_spread;
+    r.min_waves = c->opt_min_waves;
     return r;
 }
 
@@ -507,7 +528,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_trend_init(d, w, o, st);
         HIPCHK(c, hipMemcpyAsync(w.sc->coefs, o.trendIn, sizeof(double) * 2, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));  // o.trendIn lives on this frame
-    } else if (!c->allreduce && !c->no_persistent_trend && c->cu_count >= trend_persistent_blocks() && !getenv("CHICDIFF_TREND_MULTILAUNCH")) {
+    } else if (!c->allreduce && !c->no_persistent_trend && c->cu_count >= trend_persistent_blocks() && !c->opt_trend_multilaunch) {
         Scope t(c, "trend_fit");  // single rank: one persistent launch (LDS-resident rows, grid barrier per IRLS pass)
         launch_trend_persistent(d, w, o, st);  // no host round trip: `failed` comes back with the final scalars
     } else {
@@ -627,7 +648,7 @@ int chicdiff_hip_nbglm_fit_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);
-    rc = fit_dev_impl(c, d_counts, d_nf, d, make_opts(opts, S), d_out, scalars);
+    rc = fit_dev_impl(c, d_counts, d_nf, d, make_opts(c, opts, S), d_out, scalars);
     timing_collect(c);
     return rc;
 }
@@ -731,7 +752,7 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
         launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, c->d_nf_tmp, c->stream);
     }
     HIPCHK(c, hipMemcpyAsync(c->h_sf, c->d_sf, sizeof(double) * S, hipMemcpyDeviceToHost, c->stream));  // pinned: no stall
-    rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(opts, S), d_out, scalars);  // ends with a stream sync
+    rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(c, opts, S), d_out, scalars);  // ends with a stream sync
     timing_collect(c);
     if (rc) return rc;
     for (int j = 0; j < S; j++) {
@@ -803,17 +824,63 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);
-    HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
-    const Opts o = make_opts(opts, S);
-    for (int t = 0; t < ntheta; t++) {
-        {
-            Scope s(c, "offsets");
-            launch_offsets(d_fullMean, c->d_sf, n, S, thetas[t], 1, c->d_nf_tmp, c->stream);
+    const Opts o = make_opts(c, opts, S);
+    // Single rank: the |Grid| fits are independent, so they run on child contexts (own stream + workspace), up to
+    // opt_grid_lanes at once, each driven by its own host thread: one fit's straggler tail and its latency-bound
+    // global steps (trend barriers, selects) overlap with the other fits' line searches.  Sharded: one after the other
+    // (every rank must issue its collectives in the same order).
+    const size_t ws_per_lane = sizeof(double) * (size_t)n * (22 + S) + (64u << 20);
+    int lanes = c->allreduce ? 1 : (ntheta < c->opt_grid_lanes ? ntheta : c->opt_grid_lanes);
+    while (lanes > 1 && ws_per_lane * lanes > ((size_t)96 << 30)) lanes--;  // keep the grid's workspaces under 96 GB
+    if (lanes <= 1) {
+        HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
+        for (int t = 0; t < ntheta; t++) {
+            {
+                Scope s(c, "offsets");
+                launch_offsets(d_fullMean, c->d_sf, n, S, thetas[t], 1, c->d_nf_tmp, c->stream);
+            }
+            chicdiff_nbglm_scalars sc;
+            if ((rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, o, nullptr, &sc))) return rc;
+            deviances_host[t] = sc.sumDeviance;
         }
-        chicdiff_nbglm_scalars sc;
-        if ((rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, o, nullptr, &sc))) return rc;
-        deviances_host[t] = sc.sumDeviance;
+        timing_collect(c);
+        return CHICDIFF_OK;
     }
+    while ((int)c->lanes.size() < lanes) {
+        chicdiff_hip_ctx *l = nullptr;
+        if ((rc = chicdiff_hip_create(&l, c->device))) return fail(c, rc, "theta_grid: %s", chicdiff_hip_last_error(nullptr));
+        c->lanes.push_back(l);
+    }
+    hipEvent_t ready;  // the inputs are produced on the caller's stream
+    HIPCHK(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(ready, c->stream));
+    std::vector<int> lane_rc(lanes, CHICDIFF_OK);
+    std::vector<std::thread> workers;
+    for (int k = 0; k < lanes; k++) {
+        chicdiff_hip_ctx *l = c->lanes[k];
+        l->opt_spread = c->opt_spread;
+        l->opt_min_waves = c->opt_min_waves;
+        l->opt_select_rounds = c->opt_select_rounds;
+        l->opt_trend_multilaunch = c->opt_trend_multilaunch;
+        l->no_persistent_trend = true;  // a grid barrier needs its workgroups co-resident: not guaranteed beside other fits
+        workers.emplace_back([=, &lane_rc]() {
+            int r = CHICDIFF_OK;
+            if (hipSetDevice(l->device) != hipSuccess || hipStreamWaitEvent(l->stream, ready, 0) != hipSuccess) r = CHICDIFF_E_HIP;
+            if (!r) r = ensure_workspace(l, n, S);
+            if (!r && hipMemcpyAsync(l->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, l->stream) != hipSuccess) r = CHICDIFF_E_HIP;
+            for (int t = k; t < ntheta && !r; t += lanes) {
+                launch_offsets(d_fullMean, l->d_sf, n, S, thetas[t], 1, l->d_nf_tmp, l->stream);
+                chicdiff_nbglm_scalars sc;
+                r = fit_dev_impl(l, d_counts, l->d_nf_tmp, d, o, nullptr, &sc);
+                if (!r) deviances_host[t] = sc.sumDeviance;
+            }
+            lane_rc[k] = r;
+        });
+    }
+    for (auto &w : workers) w.join();
+    (void)hipEventDestroy(ready);
+    for (int k = 0; k < lanes; k++)
+        if (lane_rc[k]) return fail(c, lane_rc[k], "theta_grid: %s", c->lanes[k]->err[0] ? c->lanes[k]->err : "a concurrent fit failed");
     timing_collect(c);
     return CHICDIFF_OK;
 }

@@ -192,9 +192,15 @@ struct DispArgs {
     FitDims d;
     FitWork w;
     Opts o;
-    unsigned long long *stamps;  // diagnostic only (CHICDIFF_DISP_STAMPS=file): per wave start / queue-empty / exit
-    int spread;                  // 0 = row-per-lane evaluation only (CHICDIFF_DISP_NOSPREAD=1, for the bit-identity test)
+    unsigned long long *stamps;  // CHICDIFF_DIAG builds only (make DIAG=1): per wave timestamps and tick counts
+    int spread;                  // 0 = row-per-lane evaluation only (option "line_search_spread", for the bit-identity test)
 };
+#ifdef CHICDIFF_DIAG
+#define DIAG(...) __VA_ARGS__
+constexpr int kStampSlots = 8;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks
+#else
+#define DIAG(...)
+#endif
 
 // log posterior of a = log(alpha) and its derivative for one row held in LDS (A2.6).
 //
@@ -422,9 +428,9 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     int is_outlier = 0;
     bool queue_empty = false;
     unsigned long long chunk_next = 0, chunk_end = 0;
-    const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;
-    bool stamped = false;
-    if (A.stamps && lane == 0) A.stamps[gwave * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    DIAG(const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;)
+    DIAG(bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0;
+         if (A.stamps && lane == 0) A.stamps[gwave * kStampSlots + 0] = __builtin_amdgcn_s_memrealtime();)
 
     for (;;) {
         // ---- refill: lanes without a row pull the next ones from the queue -----------------
@@ -492,13 +498,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
         }
         if (__ballot(phase != PH_DONE) == 0ull) break;
-        if (A.stamps && queue_empty && !stamped) {
+        DIAG(if (A.stamps && queue_empty && !stamped) {
             stamped = true;
+            const int live = __popcll(__ballot(phase != PH_DONE && phase != PH_NEED));
             if (lane == 0) {
-                A.stamps[gwave * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-                A.stamps[gwave * 4 + 3] = __popcll(__ballot(phase != PH_DONE && phase != PH_NEED));
+                A.stamps[gwave * kStampSlots + 1] = __builtin_amdgcn_s_memrealtime();
+                A.stamps[gwave * kStampSlots + 3] = live;
             }
-        }
+        })
 
         // ---- choose this tick's evaluation point -------------------------------------------
         double a_eval = a;
@@ -552,6 +559,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         double l_new = 0, dl_new = 0, alpha_new = 0;
         const bool active = phase != PH_DONE && phase != PH_NEED;
         const unsigned long long actmask = __ballot(active);
+        DIAG(tk_all++; if (queue_empty) { if (burst_owner >= 0) tk_burst++; else if (spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) tk_spread++; else tk_row++; })
         if (burst_owner < 0 && queue_empty && spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) {
             eval_point_spread(s_nf, s_y, lane, S, spread_lg, gmask, p2, o.minmu, actmask, active, a_eval, gm0, gm1, MAP,
                               prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab);
@@ -674,15 +682,20 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             phase = PH_NEED;
         }
     }
-    if (A.stamps && lane == 0) A.stamps[gwave * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    DIAG(if (A.stamps && lane == 0) {
+        A.stamps[gwave * kStampSlots + 2] = __builtin_amdgcn_s_memrealtime();
+        A.stamps[gwave * kStampSlots + 4] = tk_row;
+        A.stamps[gwave * kStampSlots + 5] = tk_spread;
+        A.stamps[gwave * kStampSlots + 6] = tk_burst;
+        A.stamps[gwave * kStampSlots + 7] = tk_all;
+    })
 }
 
 static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                         hipStream_t st) {
     if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o);
     else disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o);
-    DispArgs A{counts, nf, d, w, o, nullptr, getenv("CHICDIFF_DISP_NOSPREAD") ? 0 : 1};
-    const char *stamp_file = getenv("CHICDIFF_DISP_STAMPS");
+    DispArgs A{counts, nf, d, w, o, nullptr, o.spread};
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks
     int threads = 128;
@@ -694,14 +707,15 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     const int64_t max_blocks = 256 * (int64_t)(160 * 1024 / (lds > 0 ? lds : 1) < 8 ? 160 * 1024 / lds : 8);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
+#ifdef CHICDIFF_DIAG
+    const char *stamp_file = getenv("CHICDIFF_DISP_STAMPS");  // diagnostic build only: blocking, never timed
+    const size_t stamp_words = (size_t)blocks * (threads / 64) * kStampSlots;
     if (stamp_file) {
-        (void)hipMalloc((void **)&A.stamps, (size_t)blocks * (threads / 64) * 4 * 8);
-        (void)hipMemsetAsync(A.stamps, 0, (size_t)blocks * (threads / 64) * 4 * 8, st);
+        (void)hipMalloc((void **)&A.stamps, stamp_words * 8);
+        (void)hipMemsetAsync(A.stamps, 0, stamp_words * 8, st);
     }
-    static const int variant = [] {
-        const char *e = getenv("CHICDIFF_DISP_MINW");  // tuning knob: min waves/SIMD the kernel is built for
-        return e ? atoi(e) : 2;
-    }();
+#endif
+    const int variant = o.min_waves;
 #define LAUNCH(M, W) disp_fit_kernel<M, W><<<(unsigned)blocks, threads, lds, st>>>(A)
     if (map) {
         if (variant >= 4) LAUNCH(true, 4); else if (variant == 3) LAUNCH(true, 3); else LAUNCH(true, 2);
@@ -709,19 +723,21 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
         if (variant >= 4) LAUNCH(false, 4); else if (variant == 3) LAUNCH(false, 3); else LAUNCH(false, 2);
     }
 #undef LAUNCH
-    if (stamp_file) {  // diagnostic: blocking, never used in timed runs
+#ifdef CHICDIFF_DIAG
+    if (stamp_file) {
         (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h((size_t)blocks * (threads / 64) * 4);
+        std::vector<unsigned long long> h(stamp_words);
         (void)hipMemcpy(h.data(), A.stamps, h.size() * 8, hipMemcpyDeviceToHost);
         FILE *f = fopen(stamp_file, map ? "ab" : "wb");
         if (f) {
-            unsigned long long hdr[2] = {map ? 1ull : 0ull, h.size() / 4};
+            unsigned long long hdr[2] = {map ? 1ull : 0ull, h.size() / kStampSlots};
             fwrite(hdr, 8, 2, f);
             fwrite(h.data(), 8, h.size(), f);
             fclose(f);
         }
         (void)hipFree(A.stamps);
     }
+#endif
 }
 
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {

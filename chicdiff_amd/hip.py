@@ -23,7 +23,7 @@ ST_TREND_FAILED, ST_PRIORVAR_MC, ST_BETA_NONCONV, ST_ALLZERO_ROWS = 1, 2, 4, 8
 # every symbol include/chicdiff_hip.h declares (tests check the library exports each)
 EXPORTS = [
     "chicdiff_hip_create", "chicdiff_hip_destroy", "chicdiff_hip_last_error", "chicdiff_hip_set_stream",
-    "chicdiff_hip_set_allreduce", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
+    "chicdiff_hip_set_allreduce", "chicdiff_hip_set_option", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
     "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
@@ -98,6 +98,7 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_last_error.restype = C.c_char_p
     L.chicdiff_hip_set_stream.argtypes = [vp, vp]
     L.chicdiff_hip_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32, i32]
+    L.chicdiff_hip_set_option.argtypes = [vp, C.c_char_p, i64]
     L.chicdiff_hip_default_opts.argtypes = [C.POINTER(Opts)]
     L.chicdiff_hip_default_opts.restype = None
     L.chicdiff_hip_size_factors_dev.argtypes = [vp, vp, i64, i32, C.POINTER(dbl)]
@@ -192,6 +193,10 @@ class HipContext:
 
     def use_stream(self, stream):
         self._check(self.lib.chicdiff_hip_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def set_option(self, name: str, value: int):
+        """Tuning / test options of include/chicdiff_hip.h (results never depend on them)."""
+        self._check(self.lib.chicdiff_hip_set_option(self.h, name.encode(), int(value)))
 
     def enable_timing(self, on=True):
         self.lib.chicdiff_hip_enable_timing(self.h, int(on))

@@ -61,6 +61,14 @@ int chicdiff_hip_set_stream(chicdiff_hip_ctx *ctx, void *hip_stream);
 int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, void *user,
                                int32_t world_size, int32_t rank);
 
+/* Tuning / test options; results never depend on them, the defaults are what bench.py measures.
+ *   "line_search_spread"        1 (default) | 0: evaluate straggler rows with their samples spread across lanes
+ *   "line_search_min_waves"     2 (default) .. 4: waves per SIMD the line-search kernel variant is built for
+ *   "theta_grid_concurrency"    5 (default), 1 .. 16: fits of the theta grid in flight at once (single rank only)
+ *   "select_all_rounds"         0 (default) | 1: exact medians by histogram rounds only (no candidate-sort shortcut)
+ *   "trend_one_launch_per_pass" 0 (default) | 1: trend fit as one launch per IRLS pass instead of one persistent kernel */
+int chicdiff_hip_set_option(chicdiff_hip_ctx *ctx, const char *name, int64_t value);
+
 /* Direct RCCL (backend of choice on one node: RCCL over xGMI).  The library dlopen()s librccl (librccl_path, or
  * "librccl.so" when NULL/empty — pass the copy the host process already uses, e.g. torch's), creates its own
  * communicator and from then on calls ncclAllReduce(ncclFloat64, ncclSum) itself, in place on its stream: no host

@@ -235,6 +235,26 @@ def test_theta_grid(ctx, oracle):
     print(got, ref)
     assert np.allclose(got, ref, rtol=1e-7)
     assert np.argmin(got) == np.argmin(ref)
+    # the fits of the grid run concurrently (child contexts, one stream each) by default: same numbers one after the
+    # other, with 2 and with 7 thetas in flight
+    thetas7 = [0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 1.0]
+    base = None
+    for lanes in (1, 2, 5, 7):
+        ctx.set_option("theta_grid_concurrency", lanes)
+        g = ctx.theta_grid(dk, dF, sf, thetas7)
+        base = g if base is None else base
+        assert np.allclose(g, base, rtol=1e-10), (lanes, g, base)
+    ctx.set_option("theta_grid_concurrency", 5)
+    assert np.allclose(base[[0, 2, 3, 4, 6]], got, rtol=1e-10)
+    # design ~1 with 4 samples: residual d.f. 3, the simulated prior variance (prior_mc.h) inside every fit of the grid
+    d4 = synth.make(5000, 4, fragments=3)
+    keep4 = d4["counts"].sum(1) > 0
+    _, FM4 = oracle.window_sums(None, d4["fragFullMean"], d4["region_ptr"])
+    c4, FM4 = d4["counts"][keep4], FM4[keep4]
+    sf4 = oracle.size_factors(c4)
+    got4 = ctx.theta_grid(ctx.to_device(c4, np.int32), ctx.to_device(FM4, np.float64), sf4, thetas)
+    ref4 = np.array([oracle.nbglm_fit(c4, oracle.offsets(FM4, sf4, th), np.zeros(4, np.int32))["sumDeviance"] for th in thetas])
+    assert np.allclose(got4, ref4, rtol=1e-7), (got4, ref4)
 
 
 def test_pvalues_against_reference_golden_table(ctx, golden):
@@ -518,9 +538,11 @@ def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     check_close("dispersion(2M, free fit | trend)", got["dispersion"], ref_g["dispersion"], keep, 1e-6)
     check_close("lfc(2M, free fit | trend)", got["log2FoldChange"], ref_g["log2FoldChange"], keep & big, 1e-6)
     check_close("pvalue(2M, free fit | trend)", got["pvalue"], ref_g["pvalue"], keep, 1e-6)
-    # the two free fits against each other: what the 6th-digit trend shift does to every row
-    check_close("dispersion(2M, free vs free)", got["dispersion"], ref["dispersion"], keep, 2e-5, 0.999)
-    check_close("pvalue(2M, free vs free)", got["pvalue"], ref["pvalue"], keep, 2e-4, 0.999)
+    # the two free fits against each other: what the 6th-digit trend shift does to every row — plus the few rows
+    # (<= 3 per 100 000) sitting within that shift of the outlier threshold log(dispFit) + 2 sd, which flip between
+    # their gene-wise and their MAP estimate
+    check_close("dispersion(2M, free vs free)", got["dispersion"], ref["dispersion"], keep, 2e-5, 0.999, noise_rows=60)
+    check_close("pvalue(2M, free vs free)", got["pvalue"], ref["pvalue"], keep, 2e-4, 0.999, noise_rows=60)
     # (3b) the GPU under the oracle's global scalars against the oracle's free fit
     opts = hip.default_opts(trendCoef=ref["trendCoef"], dispPriorVar=ref["dispPriorVar"])
     out2, sc2 = ctx.nbglm_fit(dk, dn, d["group"], want=want, opts=opts)
@@ -644,11 +666,11 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
 
     a = run()
     b = run()
-    os.environ["CHICDIFF_DISP_NOSPREAD"] = "1"
+    ctx.set_option("line_search_spread", 0)
     try:
         c = run()
     finally:
-        del os.environ["CHICDIFF_DISP_NOSPREAD"]
+        ctx.set_option("line_search_spread", 1)
     assert (a["dispGeneIter"] >= 100).sum() > 10  # the stragglers this is about are present
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), f"{k}: two runs differ"

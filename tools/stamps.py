@@ -1,17 +1,23 @@
-import sys, numpy as np
+"""Diagnostic: per-wave timestamps and tick counts of the two line-search launches (needs the DIAG build:
+make -C chicdiff_amd/csrc DIAG=1).  Usage on the GPU box: python tools/stamps.py [rows] [samples]"""
+import os, sys, numpy as np
 sys.path.insert(0, '.')
-import os
 os.environ["CHICDIFF_DISP_STAMPS"] = "gpurun_out/stamps.bin"
+os.environ["CHICDIFF_HIP_LIB"] = "chicdiff_amd/lib/libchicdiff_hip_diag.so"
 from chicdiff_amd import hip, synth
-d = synth.make(2_000_000, 8)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+d = synth.make(n, S)
+print('n', n, 'S', S)
 ctx = hip.HipContext(0)
 dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64)
 ctx.nbglm_fit(dk, dn, d["group"])
 raw = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64)
 pos = 0
+K = 8
 while pos < len(raw):
     kind, nw = int(raw[pos]), int(raw[pos + 1]); pos += 2
-    st = raw[pos:pos + nw * 4].reshape(nw, 4).astype(np.int64); pos += nw * 4
+    st = raw[pos:pos + nw * K].reshape(nw, K).astype(np.int64); pos += nw * K
     t0 = st[:, 0].min()
     us = lambda x: (x - t0) / 100.0  # s_memrealtime: 100 MHz
     ran = st[:, 2] > 0
@@ -20,6 +26,16 @@ while pos < len(raw):
     qe = st[:, 1] > 0
     print("  q-empty us: min %.1f p10 %.1f med %.1f p90 %.1f max %.1f" % tuple(np.percentile(us(st[qe, 1]), [0, 10, 50, 90, 100])))
     print("  exit   us: min %.1f p10 %.1f med %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(us(st[ran, 2]), [0, 10, 50, 90, 99, 100])))
-    print("  active lanes at q-empty: mean %.1f" % st[qe, 3].mean())
+    print("  live rows at q-empty: mean %.1f max %d" % (st[qe, 3].mean(), st[qe, 3].max()))
     dr = us(st[qe, 2]) - us(st[qe, 1])
     print("  drain (exit - q-empty) us: med %.1f p90 %.1f max %.1f" % tuple(np.percentile(dr, [50, 90, 100])))
+    tk = st[qe, 4:7]
+    print("  ticks after q-empty (row-per-lane / spread / burst): mean %.1f / %.1f / %.1f, max %d / %d / %d" % (*tk.mean(0), *tk.max(0)))
+    tot = tk.sum(1)
+    ok = tot > 20
+    print("  us per drain tick: med %.2f (waves with > 20 drain ticks)" % np.median(dr[ok] / tot[ok]))
+    # least squares: drain = a*row + b*spread + c*burst
+    coef = np.linalg.lstsq(tk[ok].astype(float), dr[ok], rcond=None)[0]
+    print("  fitted us per tick: row-per-lane %.2f, spread %.2f, burst %.2f" % tuple(coef))
+    bulk = us(st[qe, 1]) / np.maximum(st[qe, 7] - tot, 1)
+    print("  us per tick before q-empty: med %.2f; total ticks per wave: med %d" % (np.median(bulk), np.median(st[qe, 7])))
