@@ -34,6 +34,10 @@ struct chicdiff_hip_ctx {
     bool no_persistent_trend = false;  // set after a grid-barrier timeout (see fit_dev_impl)
     // tuning / test options (chicdiff_hip_set_option); the defaults are what the benchmarks run
     int opt_spread = 1, opt_min_waves = 2, opt_select_rounds = 0, opt_trend_multilaunch = 0;
+    // host-buffer entry point: device arena + pinned staging, both grow-only (no allocation per call once warm)
+    char *io_dev = nullptr, *io_pin = nullptr;
+    size_t io_dev_bytes = 0, io_pin_bytes = 0;
+    int opt_host_threads = 8;               // host threads that move caller buffers to / from the pinned staging area
     std::vector<chicdiff_hip_ctx *> lanes;  // theta grid: child contexts (own stream + workspace), one per concurrent fit
     int opt_grid_lanes = 5;                 // theta grid: fits in flight at once (1 = one after the other)
     int cu_count = 0;  // compute units of the device (the persistent trend kernel needs one resident workgroup per CU it launches)
@@ -120,6 +124,7 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     if (k == "line_search_spread" && (value == 0 || value == 1)) c->opt_spread = (int)value;
     else if (k == "line_search_min_waves" && value >= 2 && value <= 4) c->opt_min_waves = (int)value;
     else if (k == "theta_grid_concurrency" && value >= 1 && value <= 16) c->opt_grid_lanes = (int)value;
+    else if (k == "host_copy_threads" && value >= 1 && value <= 64) c->opt_host_threads = (int)value;
     else if (k == "select_all_rounds" && (value == 0 || value == 1)) c->opt_select_rounds = (int)value;
     else if (k == "trend_one_launch_per_pass" && (value == 0 || value == 1)) c->opt_trend_multilaunch = (int)value;
     else return fail(c, CHICDIFF_E_INVALID, "set_option: unknown option or value (%s = %lld)", name, (long long)value);
@@ -169,6 +174,8 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->io_dev) (void)hipFree(c->io_dev);
+    if (c->io_pin) (void)hipHostFree(c->io_pin);
     for (auto *l : c->lanes) chicdiff_hip_destroy(l);
     c->lanes.clear();
     if (c->ws) (void)hipFree(c->ws);
@@ -610,6 +617,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     HIPCHK(c, hipMemcpyAsync(hs, sums_of(w), sizeof hs, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
+    if (c->h_sc->neg_counts) return fail(c, CHICDIFF_E_INVALID, "counts contain a negative value or NA_integer_");
     if (c->h_sc->failed == 3) {
         // the persistent trend kernel's workgroups were not all resident within the barrier's patience (a GPU shared
         // with other work): fit again with one launch per IRLS pass, and stay with that for this context
@@ -653,50 +661,130 @@ int chicdiff_hip_nbglm_fit_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
     return rc;
 }
 
+// Host-buffer entry point (what R's .Call shim passes: INTEGER(counts), REAL(nf)).  The caller's pageable buffers go
+// through a pinned staging area in slices: host threads copy a slice in (checking the counts for NA / negatives on
+// the way) and enqueue its DMA at once, so the CPU copy of slice k+1 overlaps the PCIe transfer of slice k; results
+// come back the same way.  Device arena and staging area live in the context and only ever grow.
+static int ensure_io(chicdiff_hip_ctx *c, size_t dev_bytes, size_t pin_bytes) {
+    if (c->io_dev_bytes < dev_bytes) {
+        if (c->io_dev) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->io_dev); c->io_dev = nullptr; c->io_dev_bytes = 0; }
+        hipError_t e = hipMalloc((void **)&c->io_dev, dev_bytes);
+        if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "device arena of %zu bytes: %s", dev_bytes, hipGetErrorString(e));
+        c->io_dev_bytes = dev_bytes;
+    }
+    if (c->io_pin_bytes < pin_bytes) {
+        if (c->io_pin) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->io_pin); c->io_pin = nullptr; c->io_pin_bytes = 0; }
+        hipError_t e = hipHostMalloc((void **)&c->io_pin, pin_bytes);
+        if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "pinned staging of %zu bytes: %s", pin_bytes, hipGetErrorString(e));
+        c->io_pin_bytes = pin_bytes;
+    }
+    return CHICDIFF_OK;
+}
+
 int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const double *nf, int64_t n, int32_t S,
                            const int32_t *group, const chicdiff_nbglm_opts *opts, const chicdiff_nbglm_out *out,
                            chicdiff_nbglm_scalars *scalars) {
     if (!c) return CHICDIFF_E_INVALID;
     if (!counts || !nf) return fail(c, CHICDIFF_E_INVALID, "counts / nf pointer is NULL");
     if (n < 1 || S < 2 || S > kMaxS) return fail(c, CHICDIFF_E_INVALID, "need n >= 1 and 2 <= S <= %d", kMaxS);
-    for (int64_t k = 0; k < n * S; k++)
-        if (counts[k] < 0) return fail(c, CHICDIFF_E_INVALID, "counts[%lld] is negative or NA_integer_", (long long)k);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t cb = sizeof(int32_t) * (size_t)n * S, fb = sizeof(double) * (size_t)n * S;
-    const size_t nd = (sizeof(double) * (size_t)n + 255) & ~(size_t)255;
-    char *buf = nullptr;
-    HIPCHK(c, hipMalloc((void **)&buf, ((cb + 255) & ~(size_t)255) + fb + 256 + nd * 22));
-    int32_t *d_counts = (int32_t *)buf;
-    double *d_nf = (double *)(buf + ((cb + 255) & ~(size_t)255));
-    char *po = (char *)d_nf + ((fb + 255) & ~(size_t)255);
-    chicdiff_nbglm_out dout{};
+    const size_t nd = align256(sizeof(double) * (size_t)n);
     static const chicdiff_nbglm_out none{};
     const chicdiff_nbglm_out &ho = out ? *out : none;
     double *const *hd[] = {&ho.baseMean, &ho.baseVar, &ho.dispGeneEst, &ho.dispFit, &ho.dispMAP, &ho.dispersion, &ho.log2FoldChange,
                            &ho.lfcSE, &ho.stat, &ho.pvalue, &ho.intercept, &ho.interceptSE, &ho.deviance, &ho.maxCooks};
+    int32_t *const *hi[] = {&ho.dispGeneIter, &ho.dispIter, &ho.dispOutlier, &ho.betaConv, &ho.betaIter, &ho.allZero, &ho.cooksArgmax};
+    int nout = 0;
+    for (int k = 0; k < 14; k++) nout += *hd[k] != nullptr;
+    for (int k = 0; k < 7; k++) nout += *hi[k] != nullptr;
+    const size_t in_bytes = align256(cb) + align256(fb), out_bytes = nd * (size_t)nout;
+    int rc = ensure_io(c, in_bytes + out_bytes, in_bytes > out_bytes ? in_bytes : out_bytes);
+    if (rc) return rc;
+    int32_t *d_counts = (int32_t *)c->io_dev;
+    double *d_nf = (double *)(c->io_dev + align256(cb));
+    char *po = c->io_dev + in_bytes;
+    chicdiff_nbglm_out dout{};
     double **dd[] = {&dout.baseMean, &dout.baseVar, &dout.dispGeneEst, &dout.dispFit, &dout.dispMAP, &dout.dispersion,
                      &dout.log2FoldChange, &dout.lfcSE, &dout.stat, &dout.pvalue, &dout.intercept, &dout.interceptSE,
                      &dout.deviance, &dout.maxCooks};
-    int32_t *const *hi[] = {&ho.dispGeneIter, &ho.dispIter, &ho.dispOutlier, &ho.betaConv, &ho.betaIter, &ho.allZero, &ho.cooksArgmax};
     int32_t **di[] = {&dout.dispGeneIter, &dout.dispIter, &dout.dispOutlier, &dout.betaConv, &dout.betaIter, &dout.allZero, &dout.cooksArgmax};
-    for (int k = 0; k < 14; k++) { if (*hd[k]) *dd[k] = (double *)po; po += nd; }
-    for (int k = 0; k < 7; k++) { if (*hi[k]) *di[k] = (int32_t *)po; po += nd; }
-    int rc = CHICDIFF_OK;
-    hipError_t e;
-    if ((e = hipMemcpyAsync(d_counts, counts, cb, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(d_nf, nf, fb, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-        rc = fail(c, CHICDIFF_E_HIP, "H2D copy: %s", hipGetErrorString(e));
-    if (!rc) rc = chicdiff_hip_nbglm_fit_dev(c, d_counts, d_nf, n, S, group, opts, &dout, scalars);
-    if (!rc) {
-        for (int k = 0; k < 14 && !rc; k++)
-            if (*hd[k] && (e = hipMemcpy(*hd[k], *dd[k], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess)
-                rc = fail(c, CHICDIFF_E_HIP, "D2H copy: %s", hipGetErrorString(e));
-        for (int k = 0; k < 7 && !rc; k++)
-            if (*hi[k] && (e = hipMemcpy(*hi[k], *di[k], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess)
-                rc = fail(c, CHICDIFF_E_HIP, "D2H copy: %s", hipGetErrorString(e));
+    for (int k = 0; k < 14; k++) if (*hd[k]) { *dd[k] = (double *)po; po += nd; }
+    for (int k = 0; k < 7; k++) if (*hi[k]) { *di[k] = (int32_t *)po; po += nd; }
+
+    // ---- H2D: slices of the two input matrices, copied and enqueued by a few host threads ----
+    const size_t slice = (size_t)8 << 20;
+    struct Piece { const char *src; char *pin, *dev; size_t bytes; bool is_counts; };
+    std::vector<Piece> pieces;
+    for (size_t off = 0; off < cb; off += slice)
+        pieces.push_back({(const char *)counts + off, c->io_pin + off, (char *)d_counts + off, cb - off < slice ? cb - off : slice, true});
+    for (size_t off = 0; off < fb; off += slice)
+        pieces.push_back({(const char *)nf + off, c->io_pin + align256(cb) + off, (char *)d_nf + off, fb - off < slice ? fb - off : slice, false});
+    int nthreads = c->opt_host_threads;
+    if ((size_t)nthreads > pieces.size()) nthreads = (int)pieces.size();
+    if (nthreads < 1) nthreads = 1;
+    std::vector<int64_t> bad(nthreads, -1);
+    std::vector<int> trc(nthreads, 0);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++)
+            th.emplace_back([&, t]() {
+                if (hipSetDevice(c->device) != hipSuccess) { trc[t] = 1; return; }
+                for (size_t k = t; k < pieces.size(); k += nthreads) {
+                    const Piece &p = pieces[k];
+                    if (p.is_counts) {  // copy + NA / negative check in one pass over the slice
+                        const int32_t *s = (const int32_t *)p.src;
+                        int32_t *d = (int32_t *)p.pin;
+                        const size_t m = p.bytes / 4;
+                        int32_t acc = 0;
+                        for (size_t i = 0; i < m; i++) { d[i] = s[i]; acc |= s[i]; }
+                        if (acc < 0 && bad[t] < 0)
+                            for (size_t i = 0; i < m; i++)
+                                if (s[i] < 0) { bad[t] = (int64_t)(s - counts) + (int64_t)i; break; }
+                    } else
+                        memcpy(p.pin, p.src, p.bytes);
+                    if (hipMemcpyAsync(p.dev, p.pin, p.bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) trc[t] = 1;
+                }
+            });
+        for (auto &w : th) w.join();
     }
-    (void)hipFree(buf);
-    return rc;
+    for (int t = 0; t < nthreads; t++) {
+        if (bad[t] >= 0) {
+            (void)hipStreamSynchronize(c->stream);
+            return fail(c, CHICDIFF_E_INVALID, "counts[%lld] is negative or NA_integer_", (long long)bad[t]);
+        }
+        if (trc[t]) return fail(c, CHICDIFF_E_HIP, "H2D copy failed");
+    }
+    rc = chicdiff_hip_nbglm_fit_dev(c, d_counts, d_nf, n, S, group, opts, &dout, scalars);  // ends with a stream sync: the staging area is free again
+    if (rc) return rc;
+
+    // ---- D2H: one DMA per column into the staging area, host threads copy out as the columns land ----
+    struct Col { void *host; const void *dev; char *pin; size_t bytes; hipEvent_t ev; };
+    std::vector<Col> cols;
+    char *pp = c->io_pin;
+    for (int k = 0; k < 14; k++) if (*hd[k]) { cols.push_back({*hd[k], *dd[k], pp, sizeof(double) * (size_t)n, nullptr}); pp += nd; }
+    for (int k = 0; k < 7; k++) if (*hi[k]) { cols.push_back({*hi[k], *di[k], pp, sizeof(int32_t) * (size_t)n, nullptr}); pp += nd; }
+    hipError_t e = hipSuccess;
+    for (auto &q : cols) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&q.ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMemcpyAsync(q.pin, q.dev, q.bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(q.ev, c->stream);
+    }
+    if (e == hipSuccess && !cols.empty()) {
+        int nt = c->opt_host_threads < (int)cols.size() ? c->opt_host_threads : (int)cols.size();
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                for (size_t k = t; k < cols.size(); k += nt) {
+                    if (hipEventSynchronize(cols[k].ev) != hipSuccess) { trc[0] = 1; continue; }
+                    memcpy(cols[k].host, cols[k].pin, cols[k].bytes);
+                }
+            });
+        for (auto &w : th) w.join();
+    }
+    for (auto &q : cols) if (q.ev) (void)hipEventDestroy(q.ev);
+    if (e != hipSuccess || trc[0]) return fail(c, CHICDIFF_E_HIP, "D2H copy: %s", e != hipSuccess ? hipGetErrorString(e) : "event wait failed");
+    return CHICDIFF_OK;
 }
 
 // size factors -> c->d_sf (device) ; no host synchronisation

@@ -50,11 +50,13 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
         double q[16];
         double s = 0, g0 = 0, g1 = 0;
         int64_t tot = 0;
+        int32_t sign = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             q[j] = 0;
             if (j < S) {
                 const int32_t k = counts[(int64_t)j * n + i];
+                sign |= k;
                 q[j] = (double)k / nf[(int64_t)j * n + i];
                 tot += k;
                 s += q[j];
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
                 est += ((q[j] - mj) * (q[j] - mj) - mj) * (g ? i1 : i0);
             }
         prep_store(d, w, i, s, g0, g1, v, est, tot);
+        if (sign < 0) w.sc->neg_counts = 1;  // NA_integer_ / negative count: the fit is refused (include/chicdiff_hip.h)
     }
 }
 
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const int32_t *__restrict__ c
         int64_t tot = 0;
         for (int j = 0; j < S; j++) {
             const int32_t k = counts[(int64_t)j * n + i];
+            if (k < 0) w.sc->neg_counts = 1;
             const double q = (double)k / nf[(int64_t)j * n + i];
             tot += k;
             s += q;

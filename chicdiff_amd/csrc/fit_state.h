@@ -35,7 +35,7 @@ struct FitScalars {
     double coefs[2];       // outer-loop coefficients (define the `good` set)
     double b[2];           // inner IRLS iterate
     double devold;
-    int32_t inner_it, outer_it, phase, finished, failed, conv, _pad0, _pad1;
+    int32_t inner_it, outer_it, phase, finished, failed, conv, neg_counts /* a count < 0 (NA_integer_) was seen by prep */, _pad1;
     double nfit;
     // MAD / prior
     double med, mad, varLogDispEsts, dispPriorVar;

@@ -278,8 +278,28 @@ def test_host_entry_point_and_errors(ctx, oracle):
         ctx.nbglm_fit_host(d["counts"], d["nf"], [1] * 8)
     bad = d["counts"].copy()
     bad[5, 2] = np.iinfo(np.int32).min  # NA_integer_
-    with pytest.raises(hip.ChicdiffHipError):
+    with pytest.raises(hip.ChicdiffHipError, match="negative or NA_integer_"):
         ctx.nbglm_fit_host(bad, d["nf"], d["group"])
+    # the device-pointer entry points refuse such counts too (prep raises a flag that comes back with the scalars)
+    dkb, dnb = ctx.to_device(bad, np.int32), ctx.to_device(d["nf"], np.float64)
+    with pytest.raises(hip.ChicdiffHipError, match="negative"):
+        ctx.nbglm_fit(dkb, dnb, d["group"])
+    with pytest.raises(hip.ChicdiffHipError, match="negative"):
+        ctx.wald_test(dkb, dnb, d["group"], theta=0.5)
+    with pytest.raises(hip.ChicdiffHipError, match="negative"):
+        ctx.theta_grid(dkb, dnb, np.ones(8), [0.0, 0.5])
+    # a larger host-buffer call (several staging slices, several copy threads) and its repeat on the warm arena
+    d2 = synth.make(700_000, 8)
+    want = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue", "betaConv", "allZero"]
+    r1, s1 = ctx.nbglm_fit_host(d2["counts"], d2["nf"], d2["group"], want=want)
+    r2, s2 = ctx.nbglm_fit_host(d2["counts"], d2["nf"], d2["group"], want=want)
+    o3, s3 = ctx.nbglm_fit(ctx.to_device(d2["counts"], np.int32), ctx.to_device(d2["nf"], np.float64), d2["group"], want=want)
+    for k in want:
+        assert np.array_equal(r1[k], r2[k], equal_nan=True) and np.array_equal(r1[k], o3[k].cpu().numpy(), equal_nan=True), k
+    bad2 = d2["counts"].copy()
+    bad2[654_321, 7] = -1
+    with pytest.raises(hip.ChicdiffHipError, match=r"counts\[%d\]" % (7 * 700_000 + 654_321)):
+        ctx.nbglm_fit_host(bad2, d2["nf"], d2["group"])
 
 
 def test_allreduce_hook_on_device_single_rank(ctx, oracle):
@@ -956,8 +976,12 @@ def test_fit_extreme_counts(ctx, oracle):
     assert np.median(eg) < 1e-4 and np.mean(eg < 2e-2) > 0.97
     # trend | gene-wise estimates, then everything downstream under the GPU's trend
     useg = nz & (got["dispGeneEst"] > 1e-6)
-    cg, _, rc = oracle.parametric_dispersion_fit(ref["baseMean"][useg], got["dispGeneEst"][useg])
-    assert rc == 0 and np.allclose(cg, sc["trendCoef"], rtol=1e-9)
+    cg, itg, rc = oracle.parametric_dispersion_fit(ref["baseMean"][useg], got["dispGeneEst"][useg])
+    print("trend: oracle routine on the GPU's estimates", cg, itg, rc, "GPU", sc["trendCoef"], sc["trendOuterIter"], sc["status"], "oracle", ref["trendCoef"], ref["trendOuterIter"], ref["status"])
+    # (this matrix makes DESeq2's parametric fit stop on its second pass — both sides report it and carry on with the
+    # coefficients reached, which is what is compared)
+    assert (rc != 0) == bool(sc["status"] & 1) == bool(ref["status"] & 1) and itg == sc["trendOuterIter"]
+    assert np.allclose(cg, sc["trendCoef"], rtol=1e-9)
     assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-4)
     ref = oracle.nbglm_fit(counts, nf, group, trendCoef=sc["trendCoef"])
     conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
