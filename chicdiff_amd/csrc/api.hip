@@ -37,7 +37,7 @@ struct chicdiff_hip_ctx {
     // host-buffer entry point: device arena + pinned staging, both grow-only (no allocation per call once warm)
     char *io_dev = nullptr, *io_pin = nullptr;
     size_t io_dev_bytes = 0, io_pin_bytes = 0;
-    int opt_host_threads = 8;               // host threads that move caller buffers to / from the pinned staging area
+    int opt_host_threads = 12;              // host threads that move caller buffers to / from the pinned staging area
     std::vector<chicdiff_hip_ctx *> lanes;  // theta grid: child contexts (own stream + workspace), one per concurrent fit
     int opt_grid_lanes = 5;                 // theta grid: fits in flight at once (1 = one after the other)
     int cu_count = 0;  // compute units of the device (the persistent trend kernel needs one resident workgroup per CU it launches)

@@ -215,6 +215,12 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
     }
 }
 
+// (Measured and dropped, round 2: the same IRLS with the row held in registers — exec-masked refill loads, 64-row chunks,
+// no LDS staging.  Bit-identical, but slower at every S: 0.60 against 0.50 ms at 2 M x 8, 0.48 against 0.34 ms at S = 4,
+// 1.21 against 0.83 ms at S = 16.  The kernel is issue-bound at ~6.6 cycles per wave instruction like the line
+// searches; what idles half its lanes is the end of each wave's allotment — a third of the waves carry one row that
+// needs 20-100 ticks — not the refill, and refilling on every tick only adds instructions.)
+
 // Fallback for rows whose IRLS diverged or ran out of iterations.  DESeq2 hands them to
 // optim(L-BFGS-B, bounds +-30) on the log2-scale negative log posterior (fitNbinomGLMsOptim); what is
 // reproduced here is that optimiser's target — the posterior mode inside the box — by damped Fisher

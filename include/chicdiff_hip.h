@@ -65,7 +65,7 @@ int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, 
  *   "line_search_spread"        1 (default) | 0: evaluate straggler rows with their samples spread across lanes
  *   "line_search_min_waves"     2 (default) .. 4: waves per SIMD the line-search kernel variant is built for
  *   "theta_grid_concurrency"    5 (default), 1 .. 16: fits of the theta grid in flight at once (single rank only)
- *   "host_copy_threads"         8 (default), 1 .. 64: host threads staging caller buffers in chicdiff_hip_nbglm_fit
+ *   "host_copy_threads"         12 (default), 1 .. 64: host threads staging caller buffers in chicdiff_hip_nbglm_fit
  *   "select_all_rounds"         0 (default) | 1: exact medians by histogram rounds only (no candidate-sort shortcut)
  *   "trend_one_launch_per_pass" 0 (default) | 1: trend fit as one launch per IRLS pass instead of one persistent kernel */
 int chicdiff_hip_set_option(chicdiff_hip_ctx *ctx, const char *name, int64_t value);

@@ -7,6 +7,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 d = synth.make(n, S)
 ctx = hip.HipContext(0)
+for kv in sys.argv[3:]:  # option=value pairs of chicdiff_hip_set_option
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
 dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64)
 out = {}
 for _ in range(2):
