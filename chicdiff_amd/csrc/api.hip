@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -116,6 +117,8 @@ void chicdiff_hip_default_opts(chicdiff_nbglm_opts *o) {
     o->outlierSD = 2.0;
     o->dispPriorVar = NAN;
     o->trendCoef[0] = o->trendCoef[1] = NAN;
+    o->fitType = 0;
+    o->_pad = 0;
 }
 
 int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value) {
@@ -145,7 +148,7 @@ int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_sc, sizeof(FitScalars))) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_sf, sizeof(double) * kMaxS)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_sf, sizeof(double) * kMaxS)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_sf, sizeof(double) * (kMaxS + 1))) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_logfact, sizeof(double) * kLogFactN)) != hipSuccess) {
         fail(nullptr, CHICDIFF_E_HIP, "context setup: %s", hipGetErrorString(e));
         delete c;
@@ -498,6 +501,31 @@ static int check_counts_group(chicdiff_hip_ctx *c, int64_t n, int32_t S, const i
     return CHICDIFF_OK;
 }
 
+// Sharded fits: an argument error on ONE rank (e.g. an empty shard when n < world size) must not leave its peers blocked
+// in the first collective.  Every rank therefore contributes its local verdict to one sum-all-reduce before the fit
+// starts, and all return together.  (Single process: the local verdict.)
+static int shard_consensus(chicdiff_hip_ctx *c, int local_rc) {
+    if (!c->allreduce) return local_rc;
+    char keep[sizeof c->err];
+    memcpy(keep, c->err, sizeof keep);
+    double flag = local_rc ? 1.0 : 0.0;
+    double *d_flag = c->d_sf + kMaxS;  // one spare double behind the size factors
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_flag, &flag, sizeof flag, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, CHICDIFF_E_HIP, "shard consensus: %s", hipGetErrorString(e));
+    if (do_allreduce(c, d_flag, 1)) return CHICDIFF_E_COMM;
+    e = hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, CHICDIFF_E_HIP, "shard consensus: %s", hipGetErrorString(e));
+    if (local_rc) {
+        memcpy(c->err, keep, sizeof keep);
+        return local_rc;
+    }
+    if (flag > 0) return fail(c, CHICDIFF_E_INVALID, "%d rank(s) of the sharded fit rejected their arguments (e.g. an empty shard): nothing was fitted", (int)flag);
+    return CHICDIFF_OK;
+}
+
 static Opts make_opts(const chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *in, int S) {
     chicdiff_nbglm_opts o;
     if (in) o = *in; else chicdiff_hip_default_opts(&o);
@@ -507,6 +535,7 @@ static Opts make_opts(const chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *in, 
     r.maxDisp = S > 10 ? (double)S : 10.0;
     r.trendIn[0] = o.trendCoef[0];
     r.trendIn[1] = o.trendCoef[1];
+    r.fit_type = o.fitType;
     r.spread = c->opt_spread;
     r.min_waves = c->opt_min_waves;
     return r;
@@ -535,6 +564,32 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_trend_init(d, w, o, st);
         HIPCHK(c, hipMemcpyAsync(w.sc->coefs, o.trendIn, sizeof(double) * 2, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));  // o.trendIn lives on this frame
+    } else if (o.fit_type == 1) {
+        // fitType = "mean" (DESeq2 estimateDispersionsFit): one value for every row, the 0.1 %-trimmed mean of the gene-wise
+        // estimates above 10 minDisp — an explicit, rarely used alternative, so the order statistics are taken on the host
+        if (c->allreduce) return fail(c, CHICDIFF_E_INVALID, "fitType \"mean\" is not available for sharded fits");
+        std::vector<double> g((size_t)d.n);
+        HIPCHK(c, hipMemcpyAsync(g.data(), w.dispGene, sizeof(double) * (size_t)d.n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        size_t m = 0;
+        for (size_t i = 0; i < g.size(); i++)
+            if (g[i] > 10 * o.minDisp) g[m++] = g[i];  // NaN (all-zero rows) fails the comparison
+        if (m == 0) return fail(c, CHICDIFF_E_NUMERIC, "fitType \"mean\": no gene-wise estimate above 10 * minDisp");
+        // R mean(x, trim): lo = floor(n trim) + 1, hi = n + 1 - lo, mean(sort(x)[lo:hi]) with long double accumulation
+        const size_t lo = (size_t)floor((double)m * 0.001), hi = m - lo;  // 0-based half-open [lo, hi)
+        if (lo > 0) {
+            std::nth_element(g.begin(), g.begin() + lo, g.begin() + m);
+            std::nth_element(g.begin() + lo, g.begin() + (hi - 1), g.begin() + m);
+        }
+        long double acc = 0;
+        for (size_t i = lo; i < hi; i++) acc += g[i];
+        long double mean = acc / (long double)(hi - lo), t = 0;
+        for (size_t i = lo; i < hi; i++) t += g[i] - mean;
+        mean += t / (long double)(hi - lo);
+        const double coefs[2] = {(double)mean, 0.0};
+        launch_trend_init(d, w, o, st);
+        HIPCHK(c, hipMemcpyAsync(w.sc->coefs, coefs, sizeof coefs, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
     } else if (!c->allreduce && !c->no_persistent_trend && c->cu_count >= trend_persistent_blocks() && !c->opt_trend_multilaunch) {
         Scope t(c, "trend_fit");  // single rank: one persistent launch (LDS-resident rows, grid barrier per IRLS pass)
         launch_trend_persistent(d, w, o, st);  // no host round trip: `failed` comes back with the final scalars
@@ -649,10 +704,9 @@ int chicdiff_hip_nbglm_fit_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
                                const int32_t *group, const chicdiff_nbglm_opts *opts, const chicdiff_nbglm_out *d_out,
                                chicdiff_nbglm_scalars *scalars) {
     if (!c) return CHICDIFF_E_INVALID;
-    if (!d_counts || !d_nf) return fail(c, CHICDIFF_E_INVALID, "counts / nf pointer is NULL");
     FitDims d;
-    int rc = check_counts_group(c, n, S, group, d);
-    if (rc) return rc;
+    int rc = (!d_counts || !d_nf) ? fail(c, CHICDIFF_E_INVALID, "counts / nf pointer is NULL") : check_counts_group(c, n, S, group, d);
+    if ((rc = shard_consensus(c, rc))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);
@@ -803,10 +857,10 @@ static int size_factors_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, int64
 
 int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S, double *sf_host) {
     if (!c) return CHICDIFF_E_INVALID;
-    if (!d_counts || !sf_host || n < 1 || S < 1 || S > kMaxS) return fail(c, CHICDIFF_E_INVALID, "size_factors: bad arguments");
+    int rc = (!d_counts || !sf_host || n < 1 || S < 1 || S > kMaxS) ? fail(c, CHICDIFF_E_INVALID, "size_factors: bad arguments") : CHICDIFF_OK;
+    if ((rc = shard_consensus(c, rc))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = ensure_workspace(c, n, S);
-    if (rc) return rc;
+    if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);
     if ((rc = size_factors_impl(c, d_counts, n, S))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_sc, c->w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, c->stream));
@@ -826,10 +880,9 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
                                const int32_t *group, double theta, const chicdiff_nbglm_opts *opts,
                                const chicdiff_nbglm_out *d_out, chicdiff_nbglm_scalars *scalars, double *sf_host) {
     if (!c) return CHICDIFF_E_INVALID;
-    if (!d_counts) return fail(c, CHICDIFF_E_INVALID, "counts pointer is NULL");
     FitDims d;
-    int rc = check_counts_group(c, n, S, group, d);
-    if (rc) return rc;
+    int rc = !d_counts ? fail(c, CHICDIFF_E_INVALID, "counts pointer is NULL") : check_counts_group(c, n, S, group, d);
+    if ((rc = shard_consensus(c, rc))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);
@@ -904,11 +957,11 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
                                 int64_t n, int32_t S, const double *thetas, int32_t ntheta, const chicdiff_nbglm_opts *opts,
                                 double *deviances_host) {
     if (!c) return CHICDIFF_E_INVALID;
-    if (!d_counts || !d_fullMean || !sf_host || !thetas || !deviances_host || ntheta < 1)
-        return fail(c, CHICDIFF_E_INVALID, "theta_grid: bad arguments");
     FitDims d;
-    int rc = check_counts_group(c, n, S, nullptr, d);  // design ~ 1  ("sic!", chicdiff.R:1629-1631)
-    if (rc) return rc;
+    int rc = (!d_counts || !d_fullMean || !sf_host || !thetas || !deviances_host || ntheta < 1)
+                 ? fail(c, CHICDIFF_E_INVALID, "theta_grid: bad arguments")
+                 : check_counts_group(c, n, S, nullptr, d);  // design ~ 1  ("sic!", chicdiff.R:1629-1631)
+    if ((rc = shard_consensus(c, rc))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);

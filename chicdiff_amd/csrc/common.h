@@ -36,6 +36,7 @@ constexpr int kLogFactN = 1024;
 struct Opts {
     double minDisp, dispTol, kappa0, betaTol, minmu, outlierSD, dispPriorVarIn, maxDisp, trendIn[2];
     int32_t maxit, betaMaxit;
+    int32_t fit_type = 0;  // 0 parametric trend, 1 mean (chicdiff_nbglm_opts.fitType)
     // tuning (chicdiff_hip_set_option): not part of the algorithm, results do not depend on them
     int32_t spread = 1;     // line search: samples-across-lanes evaluation for straggler waves (0 = row per lane only)
     int32_t min_waves = 2;  // line search: waves per SIMD the kernel variant is built for

@@ -27,7 +27,6 @@ import warnings
 
 import numpy as np
 
-from . import results as _results
 
 
 def message(*a):
@@ -155,7 +154,14 @@ def DESeq2Wrap(chicdiff_settings, RU, FullRegionData, suffix="", theta=None, ctx
 
         out, sc = ctx.nbglm_fit(d_N, d_nf, group, want=want)
         if sc["status"] & hip.ST_TREND_FAILED:
-            raise RuntimeError("parametric dispersion trend failed; DESeq2 would fall back to a local fit (unsupported)")
+            # DESeq2 switches to fitType = "local" (locfit) here, which the library does not restate; its other
+            # documented alternative, fitType = "mean", is available on request (new optional setting)
+            if chicdiff_settings.get("trendFallback") != "mean":
+                raise RuntimeError('parametric dispersion trend failed; DESeq2 would fall back to a local fit: set '
+                                   'chicdiff_settings["trendFallback"] = "mean" to refit with fitType = "mean"')
+            message("-- note: fitType='parametric', but the dispersion trend was not well captured by the function: "
+                    'y = a/x + b, and fitType = "mean" was substituted (DESeq2 itself would substitute a local regression fit).')
+            out, sc = ctx.nbglm_fit(d_N, d_nf, group, want=want, opts=hip.default_opts(fitType=1))
 
         message("Processing model output")
         rmap = _read_rmap(rmapfile)

@@ -37,7 +37,8 @@ extern "C" {
 #define CHICDIFF_E_NUMERIC 5   /* e.g. every row has a zero (size factors undefined)          */
 
 /* status bits reported in chicdiff_nbglm_scalars.status (fit completed, with caveats) */
-#define CHICDIFF_ST_TREND_FAILED 1 /* parametric trend failed; DESeq2 would switch to locfit   */
+#define CHICDIFF_ST_TREND_FAILED 1 /* parametric trend failed; DESeq2 would switch to fitType "local" (locfit, not restated):
+                                      the results use the coefficients reached — refit with opts.fitType = 1 ("mean") or supply trendCoef */
 #define CHICDIFF_ST_PRIORVAR_MC 2  /* m-p<=3 and no dispPriorVar given: matched by simulation as DESeq2 does it (its set.seed(2) stream, hist(), loess()) */
 #define CHICDIFF_ST_BETA_NONCONV 4 /* some rows hit betaMaxit (DESeq2 would call optim)        */
 #define CHICDIFF_ST_ALLZERO_ROWS 8 /* some rows are all zero: their outputs are NaN (R: NA)    */
@@ -98,6 +99,10 @@ typedef struct {
     double outlierSD;    /* 2.0  */
     double dispPriorVar; /* NaN = estimate; DESeq2's estimateDispersionsMAP(dispPriorVar=) */
     double trendCoef[2]; /* NaN = fit; else use alpha(mu) = c0 + c1/mu as given (DESeq2: dispersionFunction<-) */
+    int32_t fitType;     /* 0 = "parametric" (DESeq2's and Chicdiff's default; a failed fit sets CHICDIFF_ST_TREND_FAILED);
+                            1 = "mean": dispFit = mean(dispGeneEst[dispGeneEst > 10 minDisp], trim = 0.001) for every row,
+                            DESeq2's estimateDispersions(fitType = "mean") (single process only) */
+    int32_t _pad;
 } chicdiff_nbglm_opts;
 void chicdiff_hip_default_opts(chicdiff_nbglm_opts *opts);
 

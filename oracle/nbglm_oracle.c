@@ -46,6 +46,8 @@ void oracle_nbglm_default_opts(oracle_nbglm_opts *o) {
     o->nthreads = 1;
     o->_pad = 0;
     o->trendCoef[0] = o->trendCoef[1] = NAN;
+    o->fitType = 0;
+    o->_pad2 = 0;
 }
 
 /* ---------------------------------------------------------------------------------- */
@@ -542,6 +544,25 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
     if (!isnan(o.trendCoef[0]) && !isnan(o.trendCoef[1])) { /* dispersionFunction<- : a caller-supplied trend */
         coefs[0] = o.trendCoef[0];
         coefs[1] = o.trendCoef[1];
+    } else if (o.fitType == 1) {
+        /* estimateDispersionsFit(fitType = "mean"): useForMean <- dispGeneEst > 10*minDisp;
+         * meanDisp <- mean(dispGeneEst[useForMean], na.rm = TRUE, trim = 0.001); dispFit <- meanDisp for every row.
+         * R's mean(x, trim): lo <- floor(n*trim) + 1; hi <- n + 1 - lo; mean(sort(x)[lo:hi]) */
+        int64_t m = 0;
+        for (int64_t i = 0; i < n; i++)
+            if (!allZero[i] && dispGene[i] > 10 * o.minDisp) fd[m++] = dispGene[i];
+        if (m == 0) trc = 4;
+        else {
+            qsort(fd, (size_t)m, sizeof(double), cmp_double);
+            const int64_t lo = (int64_t)floor((double)m * 0.001), hi = m - lo;
+            long double acc = 0;
+            for (int64_t k = lo; k < hi; k++) acc += fd[k];
+            long double mean = acc / (long double)(hi - lo), t = 0;
+            for (int64_t k = lo; k < hi; k++) t += fd[k] - mean;
+            mean += t / (long double)(hi - lo);
+            coefs[0] = (double)mean;
+            coefs[1] = 0.0;
+        }
     } else
         trc = nfit > 0 ? oracle_parametric_dispersion_fit(fm, fd, nfit, coefs, &outer) : 4;
     if (trc) status |= ORACLE_ST_TREND_FAILED;

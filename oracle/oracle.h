@@ -33,6 +33,8 @@ typedef struct {
     int32_t nthreads;    /* OpenMP threads over rows (1 = DESeq2-like single thread)  */
     int32_t _pad;
     double trendCoef[2]; /* NaN = fit; else alpha(mu) = c0 + c1/mu as given (DESeq2: dispersionFunction<-) */
+    int32_t fitType;     /* 0 parametric; 1 "mean": dispFit = mean(dispGeneEst[> 10 minDisp], trim = .001) (DESeq2 fitType="mean") */
+    int32_t _pad2;
 } oracle_nbglm_opts;
 
 void oracle_nbglm_default_opts(oracle_nbglm_opts *o);

@@ -41,9 +41,20 @@
   fit
 }
 
-.hipCheckFit <- function(fit) {
-  if (bitwAnd(fit$status, 1L))
-    stop("the parametric dispersion trend did not converge; DESeq2 would switch to a local fit here (fitType = \"local\")")
+## DESeq2 reacts to a failed parametric trend by switching to fitType = "local" (locfit), which the library does not
+## restate.  options(chicdiff.hip.trendFallback = "mean") refits such a data set with DESeq2's other documented
+## alternative, fitType = "mean", and says so; the default is to stop.
+.hipTrendFailed <- function(fit) bitwAnd(fit$status, 1L) != 0L
+.hipFitWithFallback <- function(run) {
+  fit <- run(0L)
+  if (.hipTrendFailed(fit)) {
+    if (!identical(getOption("chicdiff.hip.trendFallback"), "mean"))
+      stop("the parametric dispersion trend did not converge; DESeq2 would switch to a local fit here (fitType = \"local\"): ",
+           "set options(chicdiff.hip.trendFallback = \"mean\") to refit with fitType = \"mean\"")
+    message("-- note: fitType='parametric', but the dispersion trend was not well captured by the function: y = a/x + b, ",
+            "and fitType = \"mean\" was substituted (DESeq2 itself would substitute a local regression fit).")
+    fit <- run(1L)
+  }
   fit
 }
 
@@ -53,10 +64,10 @@ DESeq2Hip <- function(regionDataMatrix, normFactors, condition, device = 0L, alp
   storage.mode(regionDataMatrix) <- "integer"   # n x S, column-major = sample-major
   storage.mode(normFactors) <- "double"
   group <- .hipGroup(condition)
-  fit <- .Call("chicdiff_hip_fit", .hipContext(device), regionDataMatrix, normFactors, group, as.double(dispPriorVar),
-               .hipCooksCutoff(group), as.double(alpha), as.double(nrow(regionDataMatrix)), ncol(regionDataMatrix),
-               PACKAGE = "chicdiffhip")
-  .hipNA(.hipCheckFit(fit))
+  .hipNA(.hipFitWithFallback(function(fitType)
+    .Call("chicdiff_hip_fit", .hipContext(device), regionDataMatrix, normFactors, group, as.double(dispPriorVar), fitType,
+          .hipCooksCutoff(group), as.double(alpha), as.double(nrow(regionDataMatrix)), ncol(regionDataMatrix),
+          PACKAGE = "chicdiffhip")))
 }
 
 ## long "recast" table -> dense per-sample fragment columns in (regionID, otherEndID) order + region offsets.
@@ -142,8 +153,9 @@ DESeq2Wrap <- function(chicdiff.settings, RU, FullRegionData, suffix = "", theta
 
   cooks <- .hipCooksCutoff(group)
   fitWith <- function(fullMean, tt)   # size factors -> sc -> estimateDispersions -> nbinomWaldTest -> results()
-    .hipNA(.hipCheckFit(.Call("chicdiff_hip_wald_test", ctx, ws$N, fullMean, group, as.double(tt), NA_real_, cooks, 0.1,
-                              as.double(n), S, PACKAGE = "chicdiffhip")))
+    .hipNA(.hipFitWithFallback(function(fitType)
+      .Call("chicdiff_hip_wald_test", ctx, ws$N, fullMean, group, as.double(tt), NA_real_, fitType, cooks, 0.1,
+            as.double(n), S, PACKAGE = "chicdiffhip")))
 
   if (norm == "standard") {           # model 1: size factors only (chicdiff.R:1572-1575)
     fit <- fitWith(NULL, NA_real_)

@@ -154,9 +154,10 @@ static SEXP named_list(int n, const char **names) {
     UNPROTECT(2);
     return l;
 }
-static void set_opts(chicdiff_nbglm_opts *o, SEXP dispPriorVar) {
+static void set_opts(chicdiff_nbglm_opts *o, SEXP dispPriorVar, SEXP fitType) {
     chicdiff_hip_default_opts(o);
     if (Rf_length(dispPriorVar) == 1 && !ISNAN(Rf_asReal(dispPriorVar))) o->dispPriorVar = Rf_asReal(dispPriorVar);
+    o->fitType = Rf_asInteger(fitType); /* 0 "parametric", 1 "mean" (DESeq2 estimateDispersions(fitType = )) */
 }
 static void check_group(SEXP group, int S) {
     if (!Rf_isInteger(group) || LENGTH(group) != S) Rf_error("chicdiff_hip: group must be an integer vector with one 0/1 entry per sample");
@@ -326,10 +327,11 @@ static void fit_columns(SEXP ctx, R_xlen_t n, SEXP cols[], SEXP icols[], chicdif
 
 /* .Call(chicdiff_hip_wald_test, ctx, counts (integer n x S, host or device), fullMean (double n x S, host or device, or
  *       NULL: norm = "standard"), group (integer S, 0/1), theta (NA: norm = "fullmean"), dispPriorVar (NA = estimate),
- *       cooksCutoff (NA = no Cook's filtering), alpha, n, S)  ->  named list of host vectors / scalars.
+ *       fitType (0 "parametric", 1 "mean"), cooksCutoff (NA = no Cook's filtering), alpha, n, S)
+ *   ->  named list of host vectors / scalars.
  * estimateSizeFactors -> sc(theta) -> estimateDispersions -> nbinomWaldTest -> results(), resident on the device. */
-SEXP chicdiff_hip_wald_test(SEXP ctx, SEXP counts, SEXP fullMean, SEXP group, SEXP theta, SEXP dispPriorVar, SEXP cooksCutoff,
-                            SEXP alpha, SEXP nrow, SEXP nsamples) {
+SEXP chicdiff_hip_wald_test(SEXP ctx, SEXP counts, SEXP fullMean, SEXP group, SEXP theta, SEXP dispPriorVar, SEXP fitType,
+                            SEXP cooksCutoff, SEXP alpha, SEXP nrow, SEXP nsamples) {
     const R_xlen_t n = (R_xlen_t)Rf_asReal(nrow);
     const int S = Rf_asInteger(nsamples);
     check_group(group, S);
@@ -342,7 +344,7 @@ SEXP chicdiff_hip_wald_test(SEXP ctx, SEXP counts, SEXP fullMean, SEXP group, SE
     chicdiff_nbglm_out o;
     fit_columns(ctx, n, cols, icols, &o, &np);
     chicdiff_nbglm_opts opts;
-    set_opts(&opts, dispPriorVar);
+    set_opts(&opts, dispPriorVar, fitType);
     chicdiff_nbglm_scalars sc;
     double sf[64];
     if (S > 64) Rf_error("chicdiff_hip_wald_test: at most 64 samples");
@@ -360,10 +362,10 @@ SEXP chicdiff_hip_wald_test(SEXP ctx, SEXP counts, SEXP fullMean, SEXP group, SE
 }
 
 /* .Call(chicdiff_hip_fit, ctx, counts, nf (normalizationFactors, double n x S, host or device), group, dispPriorVar,
- *       cooksCutoff, alpha, n, S): estimateDispersions + nbinomWaldTest + results() for given normalisation factors
+ *       fitType, cooksCutoff, alpha, n, S): estimateDispersions + nbinomWaldTest + results() for given normalisation factors
  * (chicdiff.R:1573-1574, 1602-1603, 1673-1674) */
-SEXP chicdiff_hip_fit(SEXP ctx, SEXP counts, SEXP nf, SEXP group, SEXP dispPriorVar, SEXP cooksCutoff, SEXP alpha, SEXP nrow,
-                      SEXP nsamples) {
+SEXP chicdiff_hip_fit(SEXP ctx, SEXP counts, SEXP nf, SEXP group, SEXP dispPriorVar, SEXP fitType, SEXP cooksCutoff, SEXP alpha,
+                      SEXP nrow, SEXP nsamples) {
     const R_xlen_t n = (R_xlen_t)Rf_asReal(nrow);
     const int S = Rf_asInteger(nsamples);
     check_group(group, S);
@@ -374,7 +376,7 @@ SEXP chicdiff_hip_fit(SEXP ctx, SEXP counts, SEXP nf, SEXP group, SEXP dispPrior
     chicdiff_nbglm_out o;
     fit_columns(ctx, n, cols, icols, &o, &np);
     chicdiff_nbglm_opts opts;
-    set_opts(&opts, dispPriorVar);
+    set_opts(&opts, dispPriorVar, fitType);
     chicdiff_nbglm_scalars sc;
     check_rc(ctx, chicdiff_hip_nbglm_fit_dev(ctx_of(ctx), (const int32_t *)dptr(dK), (const double *)dptr(dF), (int64_t)n, S, INTEGER(group), &opts, &o,
                                              &sc),
@@ -482,8 +484,8 @@ static const R_CallMethodDef call_methods[] = {{"chicdiff_hip_open", (DL_FUNC)&c
                                                {"chicdiff_hip_size_factors", (DL_FUNC)&chicdiff_hip_size_factors, 4},
                                                {"chicdiff_hip_offsets", (DL_FUNC)&chicdiff_hip_offsets, 6},
                                                {"chicdiff_hip_theta_grid", (DL_FUNC)&chicdiff_hip_theta_grid, 7},
-                                               {"chicdiff_hip_wald_test", (DL_FUNC)&chicdiff_hip_wald_test, 10},
-                                               {"chicdiff_hip_fit", (DL_FUNC)&chicdiff_hip_fit, 9},
+                                               {"chicdiff_hip_wald_test", (DL_FUNC)&chicdiff_hip_wald_test, 11},
+                                               {"chicdiff_hip_fit", (DL_FUNC)&chicdiff_hip_fit, 10},
                                                {"chicdiff_hip_padj", (DL_FUNC)&chicdiff_hip_padj, 4},
                                                {"chicdiff_hip_ihw_apply", (DL_FUNC)&chicdiff_hip_ihw_apply, 5},
                                                {"chicdiff_hip_region_universe", (DL_FUNC)&chicdiff_hip_region_universe, 5},

@@ -9,8 +9,10 @@ it with no arguments (chicdiff.R:1721/1730/1739):
     rejections exceed max(fit) - RMS residual);
   * ``padj`` = BH over the survivors, NA for the filtered rows.
 
-Host side (numpy): O(n log n) once + O(n) per quantile; pinned by the reference's golden table
-(tests/test_results_postprocessing.py: 24 863 real (baseMean, pvalue, padj) triples).
+TEST INFRASTRUCTURE (a numpy twin the device entry points chicdiff_hip_cooks_filter_dev /
+chicdiff_hip_independent_filtering_dev are checked against), not product code: O(n log n) once + O(n) per
+quantile; pinned by the reference's golden table (tests/test_results_postprocessing.py: 24 863 real
+(baseMean, pvalue, padj) triples).
 """
 from __future__ import annotations
 

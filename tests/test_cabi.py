@@ -32,7 +32,7 @@ def test_struct_layouts_match_header(lib):
     assert (o.minDisp, o.dispTol, o.kappa0, o.maxit, o.betaMaxit, o.betaTol, o.minmu, o.outlierSD) == \
         (1e-8, 1e-6, 1.0, 100, 100, 1e-8, 0.5, 2.0)
     assert o.dispPriorVar != o.dispPriorVar and o.trendCoef[0] != o.trendCoef[0]  # NaN = estimate
-    assert C.sizeof(hip.Opts) == 80 and C.sizeof(hip.Out) == 21 * 8 and C.sizeof(hip.Scalars) == 56
+    assert C.sizeof(hip.Opts) == 88 and o.fitType == 0 and C.sizeof(hip.Out) == 21 * 8 and C.sizeof(hip.Scalars) == 56
     # the compiler's view of the header (gcc, plain C): sizes and a few offsets against the ctypes mirrors
     import subprocess
     import tempfile

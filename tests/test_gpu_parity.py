@@ -374,7 +374,7 @@ def _make_tables(n, S, F, tmp_path, seed=0):
 @pytest.mark.parametrize("norm", ["combined", "fullmean", "standard"])
 def test_deseq2wrap_mirror(ctx, oracle, tmp_path, norm):
     """The host mirror of DESeq2Wrap() (chicdiff.R:1494) against the same pipeline composed from the oracle."""
-    from chicdiff_amd import results
+    import results_twin as results
     from chicdiff_amd.deseq2wrap import DESeq2Wrap
     RU, long, rmapfile, counts, _, group, fN, fM = _make_tables(2500, 8, 5, tmp_path)
     n = len(counts)
@@ -629,6 +629,22 @@ def _two_rank_worker(rank, world, port, n, S, q):
         dk, dF = c.to_device(d["counts"][lo:hi], np.int32), c.to_device(fm[lo:hi], np.float64)
         out, sc = c.wald_test(dk, dF, d["group"], theta=0.5)
         assert c._hook.error is None and c._hook.calls > 20
+        # a shard one rank cannot fit (here: empty on rank 1, n < 1) must fail on EVERY rank, not hang the others in
+        # their first collective
+        msgs = []
+        for call in (lambda a, b: c.wald_test(a, b, d["group"], theta=0.5), lambda a, b: c.nbglm_fit(a, b, d["group"])):
+            try:
+                if rank == 1:
+                    e0 = c.torch.empty((S, 0), dtype=c.torch.int32, device=c.device)
+                    call(e0, c.torch.empty((S, 0), dtype=c.torch.float64, device=c.device))
+                else:
+                    call(dk, dF)
+                msgs.append("no error")
+            except hip.ChicdiffHipError as e:
+                msgs.append(str(e))
+        assert all(("NULL" in m or "n >= 1" in m) if rank == 1 else ("rejected their arguments" in m) for m in msgs), msgs
+        out2, _ = c.wald_test(dk, dF, d["group"], theta=0.5)  # and the context still works afterwards
+        assert all(c.torch.equal(out[k], out2[k]) or c.torch.allclose(out[k], out2[k], equal_nan=True, rtol=0, atol=0) for k in out)
         q.put((rank, lo, hi, {k: v.cpu().numpy() for k, v in out.items()}, sc["trendCoef"], sc["sizeFactors"], sc["dispPriorVar"]))
         c.close()
     finally:
@@ -940,6 +956,33 @@ def test_fit_edge_shapes(ctx, oracle, n, S, nB):
     check_close("pvalue", got["pvalue"], ref["pvalue"], conv, 1e-6)
 
 
+def test_fit_type_mean_and_trend_failure(ctx, oracle):
+    """DESeq2's estimateDispersions(fitType = "mean") (opts.fitType = 1): one fitted dispersion for every row, the
+    0.1 %-trimmed mean of the gene-wise estimates above 10 minDisp.  Also the way out when the parametric trend fails
+    (DESeq2 itself switches to fitType = "local" there, which is not restated): the failure is reported in the status
+    bits, the refit with fitType = 1 is clean."""
+    d = synth.make(30000, 8)
+    got, sc = run_fit(ctx, d, d["group"], fitType=1)
+    ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], fitType=1)
+    assert sc["trendCoef"][1] == 0.0 and ref["trendCoef"][1] == 0.0 and not (sc["status"] & 1)
+    assert np.isclose(sc["trendCoef"][0], ref["trendCoef"][0], rtol=1e-9)
+    nz = ref["allZero"] == 0
+    assert np.nanmax(got["dispFit"]) == np.nanmin(got["dispFit"]) == sc["trendCoef"][0]
+    check_close("dispersion(fitType mean)", got["dispersion"], ref["dispersion"], nz, 1e-6)
+    check_close("pvalue(fitType mean)", got["pvalue"], ref["pvalue"], nz & (ref["betaConv"] == 1), 1e-6)
+    # a matrix on which the parametric fit fails (300 rows with counts ~1e9): status bit 1 on both sides, none after the refit
+    rng = np.random.default_rng(17)
+    counts, nf = synth.make(4000, 6)["counts"].copy(), synth.make(4000, 6)["nf"]
+    counts[rng.choice(4000, 300, replace=False)] = rng.integers(2 ** 20, 2 ** 30, size=(300, 6))
+    group = synth.groups(6)
+    _, sc1 = run_fit(ctx, dict(counts=counts, nf=nf), group)
+    ref1 = oracle.nbglm_fit(counts, nf, group)
+    assert (sc1["status"] & 1) and (ref1["status"] & 1)
+    got2, sc2 = run_fit(ctx, dict(counts=counts, nf=nf), group, fitType=1)
+    ref2 = oracle.nbglm_fit(counts, nf, group, fitType=1)
+    assert not (sc2["status"] & 1) and not (ref2["status"] & 1) and np.isclose(sc2["trendCoef"][0], ref2["trendCoef"][0], rtol=1e-4)
+
+
 def test_fit_extreme_counts(ctx, oracle):
     """Counts up to 2^30 next to zeros, offsets over four decades: no overflow in the integer sums, no lost rows,
     the same NA pattern as the oracle.
@@ -1017,7 +1060,7 @@ def test_results_on_device(ctx, golden, oracle):
     quantile index 6, the BH values) and, on a synthetic 300 k table with ties and NA, the host restatement that the
     golden table pins; Cook's filter against the host restatement."""
     import torch
-    from chicdiff_amd import results
+    import results_twin as results
     dev = lambda a, t=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(ctx.device)
     padj, info = ctx.independent_filtering(dev(golden["baseMean"]), dev(golden["pvalue"]))
     got, ref = padj.cpu().numpy(), golden["padj"]

@@ -3,7 +3,7 @@
 2 411 NA rows, the chosen quantile index (6 of 50) and the BH values."""
 import numpy as np
 
-from chicdiff_amd import results
+import results_twin as results
 
 
 def test_independent_filtering_reproduces_golden_padj(golden):
