@@ -23,6 +23,14 @@
 
 using namespace cd;
 
+namespace cd {  // chinput.hip
+struct ChinputCols {
+    std::vector<int32_t> bait, oe, N;
+    std::string error;
+};
+int64_t chinput_parse(const char *path, int nthreads, ChinputCols &c);
+}  // namespace cd
+
 struct KTimer {
     std::string name;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -39,6 +47,7 @@ struct chicdiff_hip_ctx {
     char *io_dev = nullptr, *io_pin = nullptr;
     size_t io_dev_bytes = 0, io_pin_bytes = 0;
     int opt_host_threads = 12;              // host threads that move caller buffers to / from the pinned staging area
+    ChinputCols *chin = nullptr;            // columns of the .chinput file read last (chicdiff_hip_chinput_read)
     std::vector<chicdiff_hip_ctx *> lanes;  // theta grid: child contexts (own stream + workspace), one per concurrent fit
     int opt_grid_lanes = 5;                 // theta grid: fits in flight at once (1 = one after the other)
     int cu_count = 0;  // compute units of the device (the persistent trend kernel needs one resident workgroup per CU it launches)
@@ -177,6 +186,7 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    delete c->chin;
     if (c->io_dev) (void)hipFree(c->io_dev);
     if (c->io_pin) (void)hipHostFree(c->io_pin);
     for (auto *l : c->lanes) chicdiff_hip_destroy(l);
@@ -1205,6 +1215,50 @@ extern "C" int chicdiff_hip_count_table_dev(chicdiff_hip_ctx *c, const int32_t *
     timing_collect(c);
     *nkeys_host = (int64_t)h;
     return CHICDIFF_OK;
+}
+
+// host-side self test of the .chinput parser (no device, no context): the three columns of up to `cap` rows
+extern "C" int chicdiff_hip_selftest_chinput(const char *path, int32_t nthreads, int64_t cap, int32_t *bait, int32_t *oe, int32_t *N,
+                                             int64_t *nrows, char *err, int32_t errcap) {
+    if (!path || !nrows) return CHICDIFF_E_INVALID;
+    ChinputCols cols;
+    const int64_t n = chinput_parse(path, nthreads, cols);
+    if (n < 0) {
+        if (err && errcap > 0) snprintf(err, (size_t)errcap, "%s", cols.error.c_str());
+        return CHICDIFF_E_INVALID;
+    }
+    *nrows = n;
+    const size_t m = (size_t)(n < cap ? n : cap);
+    if (bait) memcpy(bait, cols.bait.data(), 4 * m);
+    if (oe) memcpy(oe, cols.oe.data(), 4 * m);
+    if (N) memcpy(N, cols.N.data(), 4 * m);
+    return CHICDIFF_OK;
+}
+
+// f2 — the text side: fread(chinput) + column pick (chicdiff.R:828, :849) with host threads (chinput.hip), then the key
+// table of the count join on the device
+extern "C" int chicdiff_hip_chinput_read(chicdiff_hip_ctx *c, const char *path, int32_t nthreads, int64_t *nrows_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!path || !nrows_host) return fail(c, CHICDIFF_E_INVALID, "chinput_read: bad arguments");
+    if (!c->chin) c->chin = new ChinputCols();
+    const int64_t n = chinput_parse(path, nthreads > 0 ? nthreads : c->opt_host_threads, *c->chin);
+    if (n < 0) return fail(c, CHICDIFF_E_INVALID, "chinput_read: %s", c->chin->error.c_str());
+    *nrows_host = n;
+    return CHICDIFF_OK;
+}
+extern "C" int chicdiff_hip_chinput_table_dev(chicdiff_hip_ctx *c, const uint8_t *d_bait_in_RU, int32_t max_id, int64_t *d_keys,
+                                              int32_t *d_vals, int64_t *nkeys_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!c->chin || c->chin->bait.empty()) return fail(c, CHICDIFF_E_INVALID, "chinput_table: no rows read (call chicdiff_hip_chinput_read first)");
+    const size_t n = c->chin->bait.size(), col = align256(sizeof(int32_t) * n);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_io(c, 3 * col, 0);
+    if (rc) return rc;
+    int32_t *d_b = (int32_t *)c->io_dev, *d_o = (int32_t *)(c->io_dev + col), *d_n = (int32_t *)(c->io_dev + 2 * col);
+    HIPCHK(c, hipMemcpyAsync(d_b, c->chin->bait.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_o, c->chin->oe.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_n, c->chin->N.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
+    return chicdiff_hip_count_table_dev(c, d_b, d_o, d_n, (int64_t)n, d_bait_in_RU, max_id, d_keys, d_vals, nkeys_host);
 }
 
 // ---- device memory for hosts without their own GPU arrays (the R shim) ---------------------------------------

@@ -27,12 +27,13 @@ EXPORTS = [
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
     "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
+    "chicdiff_hip_chinput_read", "chicdiff_hip_chinput_table_dev",
     "chicdiff_hip_malloc", "chicdiff_hip_free", "chicdiff_hip_memcpy_h2d", "chicdiff_hip_memcpy_d2h",
     "chicdiff_hip_rccl_unique_id", "chicdiff_hip_rccl_init", "chicdiff_hip_cooks_filter_dev",
     "chicdiff_hip_independent_filtering_dev",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
     "chicdiff_hip_wald_pvalues_dev", "chicdiff_hip_selftest_math_dev", "chicdiff_hip_selftest_r_random",
-    "chicdiff_hip_selftest_prior_mc", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
+    "chicdiff_hip_selftest_prior_mc", "chicdiff_hip_selftest_chinput", "chicdiff_hip_kernel_times", "chicdiff_hip_enable_timing",
 ]
 
 
@@ -116,6 +117,8 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_memcpy_h2d.argtypes = [vp, vp, vp, C.c_uint64]
     L.chicdiff_hip_memcpy_d2h.argtypes = [vp, vp, vp, C.c_uint64]
     L.chicdiff_hip_count_table_dev.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, vp, C.POINTER(i64)]
+    L.chicdiff_hip_chinput_read.argtypes = [vp, C.c_char_p, i32, C.POINTER(i64)]
+    L.chicdiff_hip_chinput_table_dev.argtypes = [vp, vp, i32, vp, vp, C.POINTER(i64)]
     L.chicdiff_hip_bh_adjust_dev.argtypes = [vp, vp, i64, vp]
     L.chicdiff_hip_ihw_apply_dev.argtypes = [vp, vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl), i32, vp, vp, vp, vp]
     L.chicdiff_hip_region_universe_count_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, C.POINTER(i64)]
@@ -324,6 +327,20 @@ class HipContext:
             d_bait_in_RU.data_ptr() if d_bait_in_RU is not None else None,
             d_bait_in_RU.numel() - 1 if d_bait_in_RU is not None else 0, keys.data_ptr(), vals.data_ptr(), C.byref(nk)))
         return keys[: nk.value], vals[: nk.value]
+
+    def read_chinput(self, path, d_bait_in_RU=None, nthreads=0):
+        """fread(chinput)[, c("baitID", "otherEndID", "N")] restricted to the RU baits -> (keys, vals) of ``count_join``
+        (chicdiff.R:828-831, :849): text parsed by host threads, bait filter + sort on the device."""
+        torch = self.torch
+        nrows = C.c_int64(0)
+        self._check(self.lib.chicdiff_hip_chinput_read(self.h, os.fsencode(path), int(nthreads), C.byref(nrows)))
+        keys = torch.empty(nrows.value, dtype=torch.int64, device=self.device)
+        vals = torch.empty(nrows.value, dtype=torch.int32, device=self.device)
+        nk = C.c_int64(0)
+        self._check(self.lib.chicdiff_hip_chinput_table_dev(
+            self.h, d_bait_in_RU.data_ptr() if d_bait_in_RU is not None else None,
+            d_bait_in_RU.numel() - 1 if d_bait_in_RU is not None else 0, keys.data_ptr(), vals.data_ptr(), C.byref(nk)))
+        return keys[: nk.value], vals[: nk.value], nrows.value
 
     # -- a9: results() ---------------------------------------------------------------------------
     def cooks_filter(self, d_counts, group, d_maxCooks, d_cooksArgmax, d_pvalue, cutoff):

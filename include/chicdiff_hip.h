@@ -187,6 +187,15 @@ int chicdiff_hip_count_table_dev(chicdiff_hip_ctx *ctx, const int32_t *d_bait, c
                                  int64_t nrows, const uint8_t *d_bait_in_RU, int32_t max_id, int64_t *d_keys,
                                  int32_t *d_vals, int64_t *nkeys_host);
 
+/* f2 (text part) — `x <- fread(chinput)` and the column pick `x[, c("baitID", "otherEndID", "N")]` (chicdiff.R:828, :849).
+ * _read parses the file with host threads (optional '#' comment lines, a header naming the columns, tab / blank / comma
+ * separated integer rows; nthreads <= 0 = the context's default) and keeps the three columns in the context;
+ * *nrows_host = rows read.  _table_dev moves them to the device and builds the key table exactly as
+ * chicdiff_hip_count_table_dev does (d_keys / d_vals must hold *nrows_host entries). */
+int chicdiff_hip_chinput_read(chicdiff_hip_ctx *ctx, const char *path, int32_t nthreads, int64_t *nrows_host);
+int chicdiff_hip_chinput_table_dev(chicdiff_hip_ctx *ctx, const uint8_t *d_bait_in_RU, int32_t max_id, int64_t *d_keys,
+                                   int32_t *d_vals, int64_t *nkeys_host);
+
 /* f1/f3 — p.adjust(p, method = "BH") (DESeq2 results() on the independent-filtering survivors; chicdiff.R:2049
  * on the weighted p-values).  NaN = NA: not counted, stays NaN.  n < 2^32. */
 int chicdiff_hip_bh_adjust_dev(chicdiff_hip_ctx *ctx, const double *d_p, int64_t n, double *d_padj);
@@ -281,6 +290,10 @@ int chicdiff_hip_selftest_math_dev(chicdiff_hip_ctx *ctx, int32_t op, const doub
  * _prior_mc: DESeq2 estimateDispersionsPriorVar for residual d.f. df in 1..3: dens_out (200 x 40, row-major, may be
  * NULL) = the densities of its 200 simulated residual distributions; *prior_var_out (may be NULL) = the prior
  * variance matched to hist40, the counts of hist(residuals, breaks = -20:20/2). */
+/* _chinput: the parser behind chicdiff_hip_chinput_read on its own: the three columns of up to `cap` rows, *nrows = rows in
+ * the file; on a parse error the message goes to err[errcap]. */
+int chicdiff_hip_selftest_chinput(const char *path, int32_t nthreads, int64_t cap, int32_t *bait, int32_t *oe, int32_t *N,
+                                  int64_t *nrows, char *err, int32_t errcap);
 int chicdiff_hip_selftest_r_random(int32_t kind, uint32_t seed, double a, double b, int64_t n, double *out);
 int chicdiff_hip_selftest_prior_mc(int32_t df, const double *hist40, double *dens_out, double *prior_var_out);
 

@@ -48,6 +48,7 @@ void oracle_nbglm_default_opts(oracle_nbglm_opts *o) {
     o->trendCoef[0] = o->trendCoef[1] = NAN;
     o->fitType = 0;
     o->_pad2 = 0;
+    o->varLogDispEsts = NAN;
 }
 
 /* ---------------------------------------------------------------------------------- */
@@ -587,7 +588,7 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
     double med = oracle_median(fd, nres);
     for (int64_t k = 0; k < nres; k++) fd[k] = fabs(fm[k] - med);
     double madv = 1.4826 * oracle_median(fd, nres);
-    double varLogDispEsts = madv * madv;
+    double varLogDispEsts = isnan(o.varLogDispEsts) ? madv * madv : o.varLogDispEsts;
     free(fm);
     free(fd);
     out->varLogDispEsts = varLogDispEsts;

@@ -35,6 +35,8 @@ typedef struct {
     double trendCoef[2]; /* NaN = fit; else alpha(mu) = c0 + c1/mu as given (DESeq2: dispersionFunction<-) */
     int32_t fitType;     /* 0 parametric; 1 "mean": dispFit = mean(dispGeneEst[> 10 minDisp], trim = .001) (DESeq2 fitType="mean") */
     int32_t _pad2;
+    double varLogDispEsts; /* NaN = estimate (mad^2 of the log residuals); else as given: lets a SLICE of a larger fit be checked with
+                              all three global scalars (trend, prior variance, this) pinned to the whole fit's */
 } oracle_nbglm_opts;
 
 void oracle_nbglm_default_opts(oracle_nbglm_opts *o);

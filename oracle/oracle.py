@@ -35,7 +35,7 @@ class Opts(C.Structure):
                 ("maxit", C.c_int32), ("betaMaxit", C.c_int32), ("betaTol", C.c_double),
                 ("minmu", C.c_double), ("outlierSD", C.c_double), ("dispPriorVar", C.c_double),
                 ("nthreads", C.c_int32), ("_pad", C.c_int32), ("trendCoef", C.c_double * 2), ("fitType", C.c_int32),
-                ("_pad2", C.c_int32)]
+                ("_pad2", C.c_int32), ("varLogDispEsts", C.c_double)]
 
 
 _PD, _PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)

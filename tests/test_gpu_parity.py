@@ -1150,3 +1150,135 @@ def test_prior_variance_by_simulation_matches_oracle(ctx, oracle, S, group):
     if group.any():
         conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
         check_close("pvalue", got["pvalue"], ref["pvalue"], conv, 1e-6)
+
+
+def test_chinput_ingestion_on_device(ctx, oracle, tmp_path):
+    """f2 end to end: a .chinput text file (format of chicdiff.R:828) -> host-thread parser ->
+    bait filter + radix sort on the device -> count join, against the oracle fed the same rows (bit-exact)."""
+    import time
+    import torch
+    from test_chinput import make_rows, write_chinput
+    bait, oe, N = make_rows(400_000, seed=9)
+    keep = np.sort(np.unique(np.stack([bait, oe], 1), axis=0, return_index=True)[1])
+    bait, oe, N = bait[keep], oe[keep], N[keep]
+    path = tmp_path / "big.chinput"
+    write_chinput(path, bait, oe, N)
+    rng = np.random.default_rng(5)
+    ru_baits = np.unique(rng.choice(bait, 4000))
+    flags = np.zeros(int(bait.max()) + 1, np.uint8)
+    flags[ru_baits] = 1
+    t0 = time.perf_counter()
+    keys, vals, nrows = ctx.read_chinput(path, torch.as_tensor(flags).to(ctx.device))
+    dt = time.perf_counter() - t0
+    print(f"chinput: {os.path.getsize(path) / 1e6:.1f} MB, {nrows} rows read, {keys.numel()} kept, {dt * 1e3:.1f} ms")
+    assert nrows == len(bait)
+    rk, rv = oracle.count_table(bait, oe, N, flags)
+    assert np.array_equal(keys.cpu().numpy(), rk) and np.array_equal(vals.cpu().numpy(), rv)
+    pick = rng.choice(len(rk), 50_000)
+    qb = (rk[pick] >> 32).astype(np.int32)
+    qo = ((rk[pick] & 0xFFFFFFFF) + rng.integers(0, 2, len(pick))).astype(np.int32)  # half of them one fragment off
+    order = np.lexsort((qo, qb))
+    qb, qo = qb[order], qo[order]
+    got = ctx.count_join(torch.as_tensor(qb).to(ctx.device), torch.as_tensor(qo).to(ctx.device), keys, vals).cpu().numpy()
+    assert np.array_equal(got, oracle.count_join(qb, qo, rk, rv)) and (got > 0).sum() > 1000 and (got == 0).sum() > 1000
+
+
+def test_full_size_C5_20M_x16_pipeline_properties_and_slice_parity(ctx, oracle):
+    """BASELINE.json configs[4] on one GPU: 20 M interactions x 16 samples (8 v 8) through the composed path — size factors
+    -> sc(theta) -> dispersions -> Wald test (one call) -> results(): Cook's cutoff + independent filtering + BH -> the
+    application side of IHWcorrection.  At this size the oracle cannot run on every row, so: size-independent properties
+    (size factors against torch's own medians, NA pattern, BH monotone in p, weights average 1, row permutation), and
+    oracle parity on a 200 000-row slice with the three global scalars of the fit (trend, prior variance,
+    varLogDispEsts) pinned to the whole fit's."""
+    import torch
+    from scipy import stats
+    n, S, chunk = 20_000_000, 16, 2_000_000
+    dev = ctx.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(20190123)
+    group = synth.groups(S)
+    gt = torch.as_tensor(group, device=dev, dtype=torch.float64)
+    dk = torch.empty((S, n), dtype=torch.int32, device=dev)
+    dfm = torch.empty((S, n), dtype=torch.float64, device=dev)
+    sj = torch.exp(torch.randn(S, dtype=torch.float64, device=dev, generator=g) * 0.2)
+    for lo in range(0, n, chunk):  # the generator of chicdiff_amd/synth.py, on the device
+        m = min(chunk, n - lo)
+        mu = torch.exp(torch.randn(m, dtype=torch.float64, device=dev, generator=g) * 1.4 + np.log(19.0))
+        alpha = (0.05 + 2.0 / mu) * torch.exp(torch.randn(m, dtype=torch.float64, device=dev, generator=g) * 0.5)
+        lfc = torch.where(torch.rand(m, dtype=torch.float64, device=dev, generator=g) < 0.10,
+                          torch.randn(m, dtype=torch.float64, device=dev, generator=g), torch.zeros((), dtype=torch.float64, device=dev))
+        r = sj[:, None] * torch.exp(torch.randn((S, m), dtype=torch.float64, device=dev, generator=g) * 0.25)
+        r = r / torch.exp(torch.log(r).mean(0, keepdim=True))
+        mean = mu[None, :] * torch.exp2(lfc[None, :] * gt[:, None]) * r
+        lam = torch._standard_gamma((1.0 / alpha)[None, :].expand(S, m).contiguous(), generator=g) * (alpha[None, :] * mean)
+        dk[:, lo:lo + m] = torch.poisson(lam, generator=g).to(torch.int32)
+        dfm[:, lo:lo + m] = r * (mu[None, :] / S)  # region-level FullMean
+        del mu, alpha, lfc, r, mean, lam
+    want = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue", "maxCooks", "cooksArgmax", "allZero", "betaConv"]
+    out, sc = ctx.wald_test(dk, dfm, group, theta=0.5, want=want)
+    print("C5 scalars", {k: sc[k] for k in ("trendCoef", "varLogDispEsts", "dispPriorVar", "nAllZero", "status")})
+    assert not (sc["status"] & 1) and not (sc["status"] & 2)
+    # size factors: median of ratios over the rows without a zero, by torch
+    lk = torch.log(dk.to(torch.float64))
+    okrow = torch.isfinite(lk).all(0)
+    ratio = (lk - lk.mean(0, keepdim=True))[:, okrow]
+    m = ratio.shape[1]
+    srt = torch.sort(ratio, dim=1).values
+    med = (srt[:, (m - 1) // 2] + srt[:, m // 2]) / 2
+    assert np.allclose(sc["sizeFactors"], torch.exp(med).cpu().numpy(), rtol=1e-12)
+    del lk, ratio, srt
+    # results(): Cook's cutoff (8 v 8: applies) + independent filtering + BH
+    p_raw = out["pvalue"].clone()
+    nout = ctx.cooks_filter(dk, group, out["maxCooks"], out["cooksArgmax"], out["pvalue"], stats.f.ppf(0.99, 2, S - 2))
+    padj, info = ctx.independent_filtering(out["baseMean"], out["pvalue"])
+    p, q = out["pvalue"], padj
+    az = out["allZero"] != 0
+    assert int(az.sum()) == sc["nAllZero"] and bool(torch.isnan(p_raw)[az].all()) and not bool(torch.isnan(p_raw)[~az].any())
+    assert int(torch.isnan(p).sum()) == int(az.sum()) + nout and 0 < nout < 0.02 * n
+    assert bool(torch.isnan(q)[torch.isnan(p)].all())
+    filtered = torch.isnan(q) & ~torch.isnan(p)
+    assert bool((out["baseMean"][filtered] < info["filterThreshold"]).all()) and bool((out["baseMean"][~torch.isnan(q)] >= info["filterThreshold"]).all())
+    ok = ~torch.isnan(q)
+    order = torch.argsort(p[ok])
+    qs = q[ok][order]
+    assert bool((qs[1:] >= qs[:-1]).all()) and bool((q[ok] >= p[ok]).all()) and float(qs.max()) <= 1.0
+    print(f"C5 results(): {nout} Cook's outliers, {int(filtered.sum())} rows filtered at baseMean < {info['filterThreshold']:.3f}, {int((q < 0.05).sum())} with padj < 0.05")
+    # IHW application side (chicdiff.R:2038-2049) with a 5-group weight table
+    av = torch.exp(torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 6 + 9)
+    breaks = np.array([-np.inf, 10.5, 11.5, 12.5, 13.5, np.inf])
+    ihw = ctx.ihw_apply(av, p, breaks, np.array([2.0, 1.5, 1.0, 0.6, 0.3]))
+    w = ihw["weight"]
+    assert abs(float(w.mean()) - 1.0) < 1e-9 and int(ihw["group"].min()) == 1 and int(ihw["group"].max()) == 5
+    wp = ihw["weighted_pvalue"]
+    okw = ~torch.isnan(wp)
+    assert torch.equal(okw, ~torch.isnan(p)) and bool(torch.allclose(wp[okw], p[okw] / w[okw], rtol=1e-15))
+    wq = ihw["weighted_padj"][okw][torch.argsort(wp[okw])]
+    assert bool((wq[1:] >= wq[:-1]).all())
+    # oracle parity on a slice, global scalars pinned
+    lo, hi = 7_000_000, 7_200_000
+    d_nf = ctx.offsets(dfm, sc["sizeFactors"], 0.5)
+    cs, nfs = dk[:, lo:hi].T.cpu().numpy(), d_nf[:, lo:hi].T.cpu().numpy()
+    del d_nf
+    ref = oracle.nbglm_fit(cs, nfs, group, nthreads=min(16, os.cpu_count() or 1), trendCoef=sc["trendCoef"], dispPriorVar=sc["dispPriorVar"],
+                           varLogDispEsts=sc["varLogDispEsts"])
+    sl = {k: out[k][lo:hi].cpu().numpy() for k in ("baseMean", "dispersion", "log2FoldChange", "lfcSE", "maxCooks", "betaConv")}
+    praw = p_raw[lo:hi].cpu().numpy()
+    nz = (ref["allZero"] == 0) & (ref["betaConv"] == 1) & (sl["betaConv"] == 1)
+    check_close("baseMean(C5 slice)", sl["baseMean"], ref["baseMean"], nz, 1e-13, 1.0)
+    check_close("dispersion(C5 slice)", sl["dispersion"], ref["dispersion"], nz, 1e-6)
+    check_close("lfc(C5 slice)", sl["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-2), 1e-6)
+    check_close("pvalue(C5 slice)", praw, ref["pvalue"], nz, 1e-6)
+    check_close("maxCooks(C5 slice)", sl["maxCooks"], ref["maxCooks"], nz & (ref["maxCooks"] > 1e-12), 1e-5)
+    # row permutation
+    del av, ihw, w, wp
+    perm = torch.randperm(n, device=dev, generator=g)
+    p1 = p_raw[perm].cpu().numpy()
+    dk2, dfm2 = dk[:, perm].contiguous(), dfm[:, perm].contiguous()
+    del dk, dfm
+    out3, sc3 = ctx.wald_test(dk2, dfm2, group, theta=0.5, want=["pvalue"])
+    assert np.allclose(sc3["trendCoef"], sc["trendCoef"], rtol=1e-11) and np.array_equal(sc3["sizeFactors"], sc["sizeFactors"])
+    p2 = out3["pvalue"].cpu().numpy()
+    okp = ~np.isnan(p1)
+    r = rel(p2[okp], p1[okp])
+    print("C5 permutation: max rel", r.max(), "frac within 1e-9", np.mean(r < 1e-9))
+    assert np.array_equal(np.isnan(p1), np.isnan(p2)) and np.mean(r < 1e-9) > 0.999 and r.max() < 1e-3
