@@ -369,7 +369,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
         c->ws = nullptr;
     }
     const size_t nd = align256(sizeof(double) * (size_t)n), ni = align256(sizeof(int32_t) * (size_t)n);
-    const size_t n_double_arrays = 15, n_int_arrays = 6;
+    const size_t n_double_arrays = 15, n_int_arrays = 7;
     const size_t partials = align256(sizeof(double) * ((size_t)kRedBlocks * 72 + 128));
     const size_t hist = align256(sizeof(double) * (size_t)kMaxS * 2 * kSelBins);
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
@@ -385,7 +385,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     takeD(w.baseMean); takeD(w.baseVar); takeD(w.gm0); takeD(w.gm1); takeD(w.rough); takeD(w.binit0); takeD(w.binit1);
     takeD(w.crow); takeD(w.dispGene); takeD(w.dispFit); takeD(w.dispMAP); takeD(w.disp); takeD(w.beta0); takeD(w.beta1);
     takeD(w.resid);
-    takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter); takeI(w.optimConv);
+    takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter); takeI(w.optimConv); takeI(w.optimList);
     w.partials = (double *)p; p += partials;
     w.hist = (double *)p; p += hist;
     w.hist_local = (double *)p; p += hist;
@@ -495,7 +495,8 @@ static int run_select(chicdiff_hip_ctx *c, SelArgs a) {
 }
 
 static int check_counts_group(chicdiff_hip_ctx *c, int64_t n, int32_t S, const int32_t *group, FitDims &d) {
-    if (n < 1 || S < 2 || S > kMaxS) return fail(c, CHICDIFF_E_INVALID, "need n >= 1 and 2 <= S <= %d (got n=%lld, S=%d)", kMaxS, (long long)n, S);
+    if (n < 1 || n > 2147483647ll || S < 2 || S > kMaxS)
+        return fail(c, CHICDIFF_E_INVALID, "need 1 <= n < 2^31 and 2 <= S <= %d (got n=%lld, S=%d)", kMaxS, (long long)n, S);
     d.n = n;
     d.S = S;
     d.gmask = 0;

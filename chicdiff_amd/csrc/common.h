@@ -22,6 +22,7 @@ struct FitWork {
     double *baseMean, *baseVar, *gm0, *gm1, *rough, *binit0, *binit1, *crow;
     double *dispGene, *dispFit, *dispMAP, *disp, *beta0, *beta1, *resid;
     int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter, *optimConv;
+    int32_t *optimList;           // rows the IRLS left for the optim fallback (count in queue[16])
     double *partials;             // kRedBlocks x 72 doubles
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
     double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
                 A.w.beta0[row] = b0;
                 A.w.beta1[row] = b1;
                 A.w.betaIter[row] = iter_out;
-                if (iter_out >= o.betaMaxit) atomicAdd(A.w.queue + 16, 1ull);  // rows for the optim fallback (rare)
+                if (iter_out >= o.betaMaxit) A.w.optimList[atomicAdd(A.w.queue + 16, 1ull)] = (int32_t)row;  // rows for the optim fallback (rare)
                 need = true;
             }
         }
@@ -247,18 +247,15 @@ __global__ __launch_bounds__(256) void wald_optim_kernel(const int32_t *__restri
     const int S = d.S;
     const double lam = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
     const double bound = 30.0 * 0.69314718055994530942;
-    const bool any = w.queue[16] != 0;  // no row left by the IRLS: only the flags are written
+    const int64_t todo = (int64_t)w.queue[16];  // rows the IRLS listed (a few per million): the others need nothing here
     // the few hundred serial objective evaluations of a fallback row read the row from LDS, not from L2
     extern __shared__ double s_optim[];  // [S][256] offsets, then [S][256] counts (empty when S is too large)
     const bool in_lds = lds_rows != 0;
     double *s_f = s_optim + threadIdx.x;
     int32_t *s_y = reinterpret_cast<int32_t *>(s_optim + (size_t)S * 256) + threadIdx.x;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t t = blockIdx.x * 256 + threadIdx.x; t < todo; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = w.optimList[t];
         int flag = -1;  // not attempted
-        if (!any) {
-            w.optimConv[i] = flag;
-            continue;
-        }
         if (!w.allZero[i] && !(w.betaIter[i] < o.betaMaxit)) {
             const double alpha = w.disp[i], size = rcp(alpha), la = flog(alpha), crow = w.crow[i];
             const int32_t *y_ = counts + i;
@@ -313,7 +310,8 @@ __global__ __launch_bounds__(256) void wald_optim_kernel(const int32_t *__restri
 void launch_wald_optim(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
     const size_t lds = (size_t)d.S * 256 * 12;
     const int lds_rows = lds <= 48 * 1024;
-    wald_optim_kernel<<<kRedBlocks, 256, lds_rows ? lds : 0, st>>>(counts, nf, d, w, o, lds_rows);
+    // the rows to do are a device-side list (count in queue[16], normally a few per million): a small grid walks it
+    wald_optim_kernel<<<64, 256, lds_rows ? lds : 0, st>>>(counts, nf, d, w, o, lds_rows);
 }
 
 __device__ __forceinline__ int trim_lo(int n) {
@@ -364,7 +362,8 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
             const double alpha = w.disp[i], size = rcp(alpha);
             const double b0 = w.beta0[i], b1 = w.beta1[i];
             biter = w.betaIter[i];
-            const int oc = w.optimConv[i];  // -1 IRLS converged, else the optim fallback ran (1 = reached the mode)
+            // rows the IRLS gave up on went through the optim fallback, which left 1 (reached the mode) or 0 there; -1 = IRLS converged
+            const int oc = biter < o.betaMaxit ? -1 : w.optimConv[i];
             bconv = (biter < o.betaMaxit) || oc == 1;
             const double E0 = exp(b0), E1 = exp(b0 + b1);
             const double la = flog(alpha);
