@@ -201,7 +201,7 @@ struct DispArgs {
 };
 #ifdef CHICDIFF_DIAG
 #define DIAG(...) __VA_ARGS__
-constexpr int kStampSlots = 8;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks
+constexpr int kStampSlots = 12;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
 #else
 #define DIAG(...)
 #endif
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     bool queue_empty = false;
     unsigned long long chunk_next = 0, chunk_end = 0;
     DIAG(const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;)
-    DIAG(bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0;
+    DIAG(bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
          if (A.stamps && lane == 0) A.stamps[gwave * kStampSlots + 0] = __builtin_amdgcn_s_memrealtime();)
 
     for (;;) {
@@ -563,7 +563,18 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         double l_new = 0, dl_new = 0, alpha_new = 0;
         const bool active = phase != PH_DONE && phase != PH_NEED;
         const unsigned long long actmask = __ballot(active);
-        DIAG(tk_all++; if (queue_empty) { if (burst_owner >= 0) tk_burst++; else if (spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) tk_spread++; else tk_row++; })
+        DIAG({
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (tk_kind == 0) cy_row += now - cy_last; else if (tk_kind == 1) cy_spread += now - cy_last; else if (tk_kind == 2) cy_burst += now - cy_last;
+            cy_last = now;
+            tk_all++;
+            tk_kind = -1;
+            if (queue_empty) {
+                if (burst_owner >= 0) { tk_burst++; tk_kind = 2; }
+                else if (spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) { tk_spread++; tk_kind = 1; }
+                else { tk_row++; tk_kind = 0; }
+            }
+        })
         if (burst_owner < 0 && queue_empty && spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) {
             eval_point_spread(s_nf, s_y, lane, S, spread_lg, gmask, p2, o.minmu, actmask, active, a_eval, gm0, gm1, MAP,
                               prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab);
@@ -692,6 +703,9 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         A.stamps[gwave * kStampSlots + 5] = tk_spread;
         A.stamps[gwave * kStampSlots + 6] = tk_burst;
         A.stamps[gwave * kStampSlots + 7] = tk_all;
+        A.stamps[gwave * kStampSlots + 8] = cy_row;
+        A.stamps[gwave * kStampSlots + 9] = cy_spread;
+        A.stamps[gwave * kStampSlots + 10] = cy_burst;
     })
 }
 

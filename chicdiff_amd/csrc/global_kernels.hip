@@ -720,10 +720,17 @@ void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, hi
 // larger S re-reads the row from L1/L2.  log() keeps R's semantics for NA/0/negative inputs, the
 // common positive-finite case takes the cheaper flog().
 __device__ __forceinline__ double rlog(double x) { return (x > 0.0 && x < 1.7e308) ? flog(x) : log(x); }
+__device__ __forceinline__ double rlog_t(double x, const LogEntry *lt) { return (x > 2.3e-308 && x < 1.7e308) ? tlog(x, lt) : log(x); }
 
+// 2 S logarithms, 2 exponentials and 2 S quotients per row sit beside 16 S bytes of traffic: the kernel is only
+// HBM-bound if that arithmetic is lean — table-driven log (devmath.h tlog, 1 KB table in LDS) and one reciprocal per
+// geometric mean instead of S divisions (x * (1/g) against x / g: <= 1.5 ulp, far inside the 1e-13 the parity test asks).
 __global__ __launch_bounds__(256) void offsets16_kernel(const double *__restrict__ fm, const double *__restrict__ sf,
                                                         int64_t n, int S, double theta, int mix,
                                                         double *__restrict__ out) {
+    __shared__ LogEntry s_lt[64];
+    log_table_to_lds(s_lt);
+    const double iS = 1.0 / S;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double v[16];
 #pragma unroll
@@ -731,13 +738,14 @@ __global__ __launch_bounds__(256) void offsets16_kernel(const double *__restrict
         double sl = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            if (j < S) sl += rlog(v[j]);
-        const double gmean = exp(sl / S);
+            if (j < S) sl += rlog_t(v[j], s_lt);
+        const double gmean = exp(sl * iS);
+        const double ig = (gmean > 1e-300 && gmean < 1e300) ? rcp(gmean) : 1.0 / gmean;
         bool anyna = false;
 #pragma unroll
         for (int j = 0; j < 16; j++)
             if (j < S) {
-                v[j] = v[j] / gmean;
+                v[j] = v[j] * ig;
                 anyna |= (v[j] != v[j]);
             }
         double sl2 = 0;
@@ -747,13 +755,17 @@ __global__ __launch_bounds__(256) void offsets16_kernel(const double *__restrict
                 if (anyna) v[j] = sf[j];
                 if (mix) {
                     v[j] = v[j] * (1 - theta) + sf[j] * theta;
-                    sl2 += rlog(v[j]);
+                    sl2 += rlog_t(v[j], s_lt);
                 }
             }
-        const double g2 = mix ? exp(sl2 / S) : 1.0;
+        double i2 = 1.0;
+        if (mix) {
+            const double g2 = exp(sl2 * iS);
+            i2 = (g2 > 1e-300 && g2 < 1e300) ? rcp(g2) : 1.0 / g2;
+        }
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            if (j < S) out[(int64_t)j * n + i] = mix ? v[j] / g2 : v[j];
+            if (j < S) out[(int64_t)j * n + i] = mix ? v[j] * i2 : v[j];
     }
 }
 

@@ -1290,5 +1290,6 @@ def test_full_size_C5_20M_x16_pipeline_properties_and_slice_parity(ctx, oracle):
     p2 = out3["pvalue"].cpu().numpy()
     okp = ~np.isnan(p1)
     r = rel(p2[okp], p1[okp])
-    print("C5 permutation: max rel", r.max(), "frac within 1e-9", np.mean(r < 1e-9))
-    assert np.array_equal(np.isnan(p1), np.isnan(p2)) and np.mean(r < 1e-9) > 0.999 and r.max() < 1e-3
+    print("C5 permutation: max rel", r.max(), "frac within 1e-9", np.mean(r < 1e-9), "within 1e-8", np.mean(r < 1e-8), "trend", sc3["trendCoef"], sc["trendCoef"])
+    # 20 M-term sums in another order move the trend in its 12th digit, which a p-value of 1e-50 shows in its 9th
+    assert np.array_equal(np.isnan(p1), np.isnan(p2)) and np.mean(r < 1e-8) > 0.999 and r.max() < 1e-3

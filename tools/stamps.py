@@ -14,7 +14,7 @@ dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64
 ctx.nbglm_fit(dk, dn, d["group"])
 raw = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64)
 pos = 0
-K = 8
+K = 12
 while pos < len(raw):
     kind, nw = int(raw[pos]), int(raw[pos + 1]); pos += 2
     st = raw[pos:pos + nw * K].reshape(nw, K).astype(np.int64); pos += nw * K
@@ -37,5 +37,9 @@ while pos < len(raw):
     # least squares: drain = a*row + b*spread + c*burst
     coef = np.linalg.lstsq(tk[ok].astype(float), dr[ok], rcond=None)[0]
     print("  fitted us per tick: row-per-lane %.2f, spread %.2f, burst %.2f" % tuple(coef))
+    cy = st[qe, 8:11].astype(float)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        per = np.nansum(cy, 0) / np.maximum(tk.sum(0), 1)
+    print("  s_memtime cycles per tick (tick start to next tick start): row-per-lane %.0f, spread %.0f, burst %.0f  (100 MHz clock? ratio to us: %.1f)" % (*per, np.nansum(cy) / max(dr.sum(), 1e-9)))
     bulk = us(st[qe, 1]) / np.maximum(st[qe, 7] - tot, 1)
     print("  us per tick before q-empty: med %.2f; total ticks per wave: med %d" % (np.median(bulk), np.median(st[qe, 7])))
