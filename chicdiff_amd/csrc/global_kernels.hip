@@ -696,10 +696,15 @@ __global__ __launch_bounds__(256) void row_ratio_kernel(const int32_t *__restric
 }
 __global__ __launch_bounds__(256) void row_ratio16_kernel(const int32_t *__restrict__ counts, int64_t n, int S,
                                                           double *__restrict__ ratio) {
+    __shared__ LogEntry s_lt[64];
+    log_table_to_lds(s_lt);
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double l[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) l[j] = j < S ? log((double)counts[(int64_t)j * n + i]) : 0.0;
+        for (int j = 0; j < 16; j++) {
+            const int32_t k = j < S ? counts[(int64_t)j * n + i] : 1;
+            l[j] = k > 0 ? tlog((double)k, s_lt) : (k == 0 ? -INFINITY : NAN);  // log(0) = -Inf drops the row, as in R
+        }
         double s = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++)

@@ -22,8 +22,9 @@ constexpr double kLog2e = 1.4426950408889634074;
 __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restrict__ counts,
                                                         const double *__restrict__ nf, FitDims d, FitWork w) {
     __shared__ double s_logfact[kLogFactN];  // log(y!) for ordinary counts: a look-up instead of a Stirling difference
+    __shared__ LogEntry s_lt[64];
     for (int k = threadIdx.x; k < kLogFactN; k += 256) s_logfact[k] = w.logfact[k];
-    __syncthreads();
+    log_table_to_lds(s_lt);  // (ends with the barrier)
     const int64_t n = d.n;
     const int S = d.S;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -34,14 +35,14 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
         for (int j = 0; j < S; j++) {
             const int yi = counts[(int64_t)j * n + i];
             const double nfj = nf[(int64_t)j * n + i];
-            const double l = flog((double)yi / nfj + 0.1);
+            const double l = tlog((double)yi / nfj + 0.1, s_lt);
             if ((d.gmask >> j) & 1) lB += l; else lA += l;
             if (yi > 0) {
                 // lgamma(y+size) - lgamma(size) - lgamma(y+1): the mu-independent part of log dnbinom
                 c += lgr_eval(cs, yi) - (yi < kLogFactN ? s_logfact[yi] : lgr_eval(c1, yi));
                 // sum_j y_j (log alpha + log nf_j): with mu = nf e^eta the rest of sum_j y_j log(alpha mu_j) is
                 // eta_A sum_A y + eta_B sum_B y, so the IRLS ticks need no log(mu)
-                cst = fma((double)yi, la + flog(nfj), cst);
+                cst = fma((double)yi, la + tlog(nfj, s_lt), cst);
             }
         }
         lA /= d.nA;
