@@ -96,7 +96,7 @@ __global__ void trend_step_kernel(FitWork w) { trend_step(w.sc, w.partials + (si
 // publishes 8 partial sums, a grid barrier (monotonic counter, agent-scope release/acquire, cdna guide
 // G16) follows, and every workgroup adds the partials in the same fixed order and advances its own copy
 // of the state machine (fit_state.h) — identical in all workgroups, no broadcast needed.
-constexpr int kTpBlocks = 256, kTpThreads = 1024, kTpCap = 8000;  // rows cached per workgroup (2 x 64 000 B of LDS)
+constexpr int kTpBlocks = 256, kTpThreads = 1024, kTpCap = 8000, kTpMinRows = 2048;  // rows cached per workgroup (2 x 64 000 B of LDS)
 
 // Two-level grid barrier: workgroups arrive at one of 8 group counters (blockIdx % 8, i.e. one per XCD under
 // round-robin dispatch — different cache lines, so the arrivals of different groups do not serialise behind one
@@ -210,7 +210,9 @@ void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
     // (the barrier counters were zeroed with the fit's scalars; the trend runs once per fit)
     // as few workgroups as keep every row LDS-resident: the pass time is the grid barrier plus the all-partials sum,
     // both of which grow with the number of workgroups (small fits are latency-bound by these ~20 passes)
-    int64_t blocks = (d.n + kTpCap - 1) / kTpCap;
+    // rows per workgroup: at most kTpCap (LDS), at least ~2 per thread — with 8 per thread the row loop (4 us) was as long
+    // as the grid barrier of a small fit, with 2 it is 1 us and the barrier of the 4x larger grid costs less than that saved
+    int64_t blocks = (d.n + kTpMinRows - 1) / kTpMinRows;
     if (blocks < 1) blocks = 1;
     if (blocks > kTpBlocks) blocks = kTpBlocks;
     trend_persistent_kernel<<<(unsigned)blocks, kTpThreads, 0, st>>>(d, w, o.minDisp);
