@@ -974,7 +974,6 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
                  : check_counts_group(c, n, S, nullptr, d);  // design ~ 1  ("sic!", chicdiff.R:1629-1631)
     if ((rc = shard_consensus(c, rc))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);
     const Opts o = make_opts(c, opts, S);
     // Single rank: the |Grid| fits are independent, so they run on child contexts (own stream + workspace), up to
@@ -985,6 +984,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
     int lanes = c->allreduce ? 1 : (ntheta < c->opt_grid_lanes ? ntheta : c->opt_grid_lanes);
     while (lanes > 1 && ws_per_lane * lanes > ((size_t)96 << 30)) lanes--;  // keep the grid's workspaces under 96 GB
     if (lanes <= 1) {
+        if ((rc = ensure_workspace(c, n, S))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
         for (int t = 0; t < ntheta; t++) {
             {
