@@ -55,7 +55,32 @@ static inline double *sums_of(const FitWork &w) { return w.partials + (size_t)kR
 // trend (state machine: fit_state.h)
 __global__ void trend_init_kernel(FitWork w) { trend_init(w.sc); }
 
+// One row's contribution to a trend pass (fit_state.h trend_row, which the CPU harness runs as written) with the device's
+// lean arithmetic: x = 1/baseMean comes in ready, the two quotients become reciprocals (rcp: <= 1 ulp) and the
+// logarithm the table-driven tlog — about 55 instructions instead of about 200 (five IEEE divisions and a library log),
+// which was half of a pass of the persistent kernel at 2 M rows.
+__device__ __forceinline__ void trend_row_dev(const FitScalars *sc, double x, double disp, double *v, const LogEntry *lt) {
+    const double r = disp * rcp(fma(sc->coefs[1], x, sc->coefs[0]));
+    if (!(r > 1e-4 && r < 15)) return;
+    const double mu = fma(sc->b[1], x, sc->b[0]);
+    if (!(mu > 0) || !isfinite(mu)) {
+        v[7] += 1;
+        return;
+    }
+    const double rmu = rcp(mu), q = disp * rmu;
+    v[0] += -2.0 * (tlog(q, lt) - fma(-mu, rmu, q));  // Gamma deviance residual: log(y/mu) - (y - mu)/mu
+    const double wt = rmu * rmu;                        // glm.fit weight for Gamma/identity
+    v[1] += wt;
+    v[2] += wt * x;
+    v[3] += wt * x * x;
+    v[4] += wt * disp;
+    v[5] += wt * x * disp;
+    v[6] += 1;
+}
+
 __global__ __launch_bounds__(256) void trend_pass_kernel(FitDims d, FitWork w, double minDisp) {
+    __shared__ LogEntry s_lt[64];
+    log_table_to_lds(s_lt);
     const FitScalars *sc = w.sc;
     if (sc->finished) return;
     double v[kTrendSums] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -63,7 +88,7 @@ __global__ __launch_bounds__(256) void trend_pass_kernel(FitDims d, FitWork w, d
         if (w.allZero[i]) continue;
         const double y = w.dispGene[i];
         if (!(y > 100 * minDisp)) continue;  // useForFit <- dispGeneEst > 100*minDisp
-        trend_row(sc, w.baseMean[i], y, v);
+        trend_row_dev(sc, 1.0 / w.baseMean[i], y, v, s_lt);
     }
     block_reduce_store<kTrendSums>(v, w.partials + (size_t)blockIdx.x * kTrendSums);
 }
@@ -131,9 +156,11 @@ __device__ __forceinline__ bool grid_sync(unsigned int *top, unsigned int *group
 }
 
 __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d, FitWork w, double minDisp) {
-    __shared__ double s_bm[kTpCap], s_y[kTpCap];
+    __shared__ double s_bm[kTpCap], s_y[kTpCap];  // 1 / baseMean and dispGeneEst (NaN = not used for the fit)
     __shared__ double red[kTrendSums][16];
     __shared__ FitScalars st;  // only the trend fields are used
+    __shared__ LogEntry s_lt[64];
+    if (threadIdx.x < 64) s_lt[threadIdx.x] = kLogTable[threadIdx.x];  // (the barrier below covers it)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t per = (d.n + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = (r0 + per < d.n) ? r0 + per : d.n;
@@ -143,7 +170,7 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
         const int64_t i = r0 + k;
         const double y = w.dispGene[i];
         const bool use = !w.allZero[i] && (y > 100 * minDisp);  // useForFit
-        s_bm[k] = w.baseMean[i];
+        s_bm[k] = 1.0 / w.baseMean[i];
         s_y[k] = use ? y : NAN;
     }
     if (tid == 0) trend_init(&st);
@@ -156,11 +183,11 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
         double v[kTrendSums] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = tid; k < ncache; k += kTpThreads) {
             const double y = s_y[k];
-            if (y == y) trend_row(&st, s_bm[k], y, v);
+            if (y == y) trend_row_dev(&st, s_bm[k], y, v, s_lt);
         }
         for (int64_t i = r0 + kTpCap + tid; i < r1; i += kTpThreads) {  // rows beyond the LDS cache stream from HBM
             const double y = w.dispGene[i];
-            if (!w.allZero[i] && (y > 100 * minDisp)) trend_row(&st, w.baseMean[i], y, v);
+            if (!w.allZero[i] && (y > 100 * minDisp)) trend_row_dev(&st, 1.0 / w.baseMean[i], y, v, s_lt);
         }
 #pragma unroll
         for (int k = 0; k < kTrendSums; k++) {
