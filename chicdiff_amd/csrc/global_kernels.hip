@@ -381,12 +381,26 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(SelArgs a, FitWork w, int
     const bool same = (p0 == p1);
     const uint64_t mask = (1ull << bits) - 1ull;
     uint64_t key;
+    // Run-length accumulation per thread: the first digit is the sign and exponent of the key, which a whole column
+    // shares but for a handful of values — 64 lanes adding 1 to the same LDS word serialise, so a thread adds a run of
+    // equal digits at once (order-free sums: the histogram is the same).
+    int cur = -1;
+    unsigned cnt = 0;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
         if (!sel_key(a, sc, col, i, key)) continue;
         const unsigned dig = (unsigned)((key >> a.shift) & mask);
-        if (sel_match(key, p0, hi)) atomicAdd(&h[0][dig], 1u);
-        else if (!same && sel_match(key, p1, hi)) atomicAdd(&h[1][dig], 1u);
+        int bin;
+        if (sel_match(key, p0, hi)) bin = (int)dig;
+        else if (!same && sel_match(key, p1, hi)) bin = (int)(kSelBins + dig);
+        else continue;
+        if (bin == cur) cnt++;
+        else {
+            if (cnt) atomicAdd(&(&h[0][0])[cur], cnt);
+            cur = bin;
+            cnt = 1;
+        }
     }
+    if (cnt) atomicAdd(&(&h[0][0])[cur], cnt);
     __syncthreads();
     double *g = w.hist + (size_t)col * 2 * kSelBins;
     for (int k = threadIdx.x; k < 2 * kSelBins; k += 256) {
