@@ -1297,3 +1297,34 @@ def test_full_size_C5_20M_x16_pipeline_properties_and_slice_parity(ctx, oracle):
     # 20 M-term sums in another order, through ~20 IRLS passes, move the trend in its 9th-10th digit; a dispersion shows
     # that as it is, a p-value of 1e-100 (|stat| ~ 21) amplifies it by stat^2
     assert np.array_equal(np.isnan(p1), np.isnan(p2)) and np.mean(ra < 1e-8) > 0.999 and np.mean(r < 1e-6) > 0.999 and r.max() < 1e-3
+
+
+def test_soak_changing_shapes_no_leak_and_run_to_run_identity(ctx):
+    """Many fits of changing shape on one context (workspace regrowth both ways, theta-grid child contexts, host path):
+    identical results whenever a shape comes back, and no device memory lost along the way."""
+    import torch
+    shapes = [(5000, 4), (120000, 8), (300, 6), (64, 16), (40000, 3), (1, 8), (30000, 33)]
+    ref, free_mid = {}, None
+    for it in range(42):
+        n, S = shapes[it % len(shapes)]
+        d = synth.make(n, S)
+        g = np.zeros(S, np.int32) if S == 3 else d["group"]
+        dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64)
+        out, sc = ctx.nbglm_fit(dk, dn, g, want=["pvalue", "dispersion"])
+        p = out["dispersion"].cpu().numpy()
+        if (n, S) in ref:
+            assert np.array_equal(ref[(n, S)], p, equal_nan=True), (n, S)
+        ref[(n, S)] = p
+        if it % 7 == 1:
+            keep = d["counts"].sum(1) > 0
+            fm = d["nf"] * (d["mu"][:, None] / S)
+            dev = ctx.theta_grid(ctx.to_device(d["counts"][keep], np.int32), ctx.to_device(fm[keep], np.float64), np.ones(S), [0.0, 0.4, 1.0])
+            assert np.all(np.isfinite(dev))
+            r, _ = ctx.nbglm_fit_host(d["counts"], d["nf"], g, want=["dispersion"])
+            assert np.array_equal(r["dispersion"], p, equal_nan=True)
+        del dk, dn, out
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        if it == 20:
+            free_mid = free
+    assert free_mid - free < 64 * 2 ** 20, (free_mid, free)
