@@ -138,3 +138,124 @@ def loess_interpolate(x, y, z, span=0.2, cell=0.2):
         val.append(b[0])
         slope.append(b[1])
     return CubicHermiteSpline(v, val, slope)(np.asarray(z, float)), v
+
+
+# ------------------------------------------------------------------------------------------------
+# Control-flow twins: the whole per-row procedures (not only their objectives), written against a
+# general design matrix with numpy's QR / lstsq and scipy's special functions, so that they share
+# neither code nor algebraic shortcuts (closed-form 2x2 normal equations, group means) with oracle/*.c.
+def dcr_apl(log_alpha, y, mu, X, prior=None):
+    """d/d log(alpha) of cr_apl: the analytic form DESeq2's line search uses (A2.6)."""
+    a = np.exp(log_alpha)
+    r = 1.0 / a
+    ll = r * r * np.sum(special.digamma(r) + np.log1p(mu * a) - mu * a / (1.0 + mu * a)
+                        - special.digamma(y + r) + y / (mu + r))
+    w = 1.0 / (1.0 / mu + a)
+    B = X.T @ (w[:, None] * X)
+    dB = X.T @ ((-w * w)[:, None] * X)
+    cr = -0.5 * np.trace(np.linalg.solve(B, dB))
+    pr = 0.0 if prior is None else -(log_alpha - prior[0]) / prior[1]
+    return (ll + cr) * a + pr
+
+
+def fit_disp(y, mu, X, log_alpha0, prior=None, min_log_alpha=np.log(1e-9), kappa0=1.0, tol=1e-6, maxit=100):
+    """Backtracking gradient ascent in log(alpha); returns (log_alpha, iterations, initial lp, last lp)."""
+    eps = 1.0e-4
+    a = log_alpha0
+    lp = cr_apl(a, y, mu, X, prior)
+    dlp = dcr_apl(a, y, mu, X, prior)
+    first = lp
+    kappa, it, acc = kappa0, 0, 0
+    for _ in range(maxit):
+        it += 1
+        prop = a + kappa * dlp
+        if prop < -30.0:
+            kappa = (-30.0 - a) / dlp
+        if prop > 10.0:
+            kappa = (10.0 - a) / dlp
+        if -cr_apl(a + kappa * dlp, y, mu, X, prior) <= -lp - kappa * eps * dlp * dlp:
+            acc += 1
+            a = a + kappa * dlp
+            new = cr_apl(a, y, mu, X, prior)
+            change = new - lp
+            if change < tol:
+                lp = new
+                break
+            if a < min_log_alpha:  # lp keeps its previous value on this exit
+                break
+            lp = new
+            dlp = dcr_apl(a, y, mu, X, prior)
+            kappa = min(kappa * 1.1, kappa0)
+            if acc % 5 == 0:
+                kappa /= 2.0
+        else:
+            kappa /= 2.0
+    return a, it, first, lp
+
+
+def fit_disp_grid(y, mu, X, S, prior=None):
+    grid = np.linspace(np.log(1e-8), np.log(max(10.0, S)), 20)
+    v = [cr_apl(t, y, mu, X, prior) for t in grid]
+    a_hat = grid[int(np.argmax(v))]
+    delta = grid[1] - grid[0]
+    fine = np.linspace(a_hat - delta, a_hat + delta, 20)
+    v = [cr_apl(t, y, mu, X, prior) for t in fine]
+    return np.exp(fine[int(np.argmax(v))])
+
+
+def gene_dispersion(counts_row, nf_row, X, xim, min_disp=1e-8, minmu=0.5, maxit=100):
+    """estimateDispersionsGeneEst for one row: rough / moments start, linear-model mu, line search, the
+    noIncrease and grid rules.  Returns (dispInit, dispGeneEst, iterations)."""
+    S, p = X.shape
+    y = counts_row.astype(float)
+    q = y / nf_row
+    max_disp = max(10.0, S)
+    fitted = X @ np.linalg.lstsq(X, q, rcond=None)[0]       # hat-matrix fit of the normalised counts
+    m = np.maximum(fitted, 1.0)
+    rough = max(np.sum(((q - m) ** 2 - m) / m ** 2) / (S - p), 0.0)
+    bm, bv = q.mean(), q.var(ddof=1)
+    a0 = min(max(min_disp, min(rough, (bv - xim * bm) / bm ** 2)), max_disp)
+    mu = np.maximum(fitted * nf_row, minmu)
+    a, it, first, last = fit_disp(y, mu, X, np.log(a0), None, np.log(min_disp / 10), maxit=maxit)
+    d = min(np.exp(a), max_disp)
+    if last < first + abs(first) / 1e6:
+        d = a0
+    if not (it < maxit and it != 1) and d > min_disp * 10:
+        d = fit_disp_grid(y, mu, X, S)
+    return a0, min(max(d, min_disp), max_disp), it
+
+
+def fit_beta(y, nf, X, alpha, lam, beta0, minmu=0.5, tol=1e-8, maxit=100, large=30.0):
+    """fitBeta's IRLS the way DESeq2 writes it: QR of the ridge-augmented weighted design, natural-log beta.
+    Returns (beta, iterations, deviance at the last iterate, var(beta) sandwich diagonal, mu)."""
+    n, p = X.shape
+    beta = np.array(beta0, float)
+    mu = np.maximum(nf * np.exp(X @ beta), minmu)
+    ridge = np.diag(np.full(p, lam) if np.isscalar(lam) else lam)
+    dev = dev_old = 0.0
+    it = 0
+    size = 1.0 / alpha
+    for t in range(maxit):
+        it += 1
+        w = mu / (1.0 + alpha * mu)
+        A = np.vstack([X * np.sqrt(w)[:, None], np.sqrt(ridge)])
+        Q, R = np.linalg.qr(A)
+        z = np.log(mu / nf) + (y - mu) / mu
+        rhs = np.concatenate([z * np.sqrt(w), np.zeros(p)])
+        beta = np.linalg.solve(R, Q.T @ rhs)
+        if np.any(np.abs(beta) > large):
+            it = maxit
+            break
+        mu = np.maximum(nf * np.exp(X @ beta), minmu)
+        dev = -2.0 * stats.nbinom.logpmf(y, size, size / (size + mu)).sum()
+        conv = abs(dev - dev_old) / (abs(dev) + 0.1)
+        if np.isnan(conv):
+            it = maxit
+            break
+        if t > 0 and conv < tol:
+            break
+        dev_old = dev
+    w = mu / (1.0 + alpha * mu)
+    xtwx = X.T @ (w[:, None] * X)
+    inv = np.linalg.inv(xtwx + ridge)
+    return beta, it, dev, np.diag(inv @ xtwx @ inv), mu

@@ -383,3 +383,86 @@ def test_fit_with_three_residual_df_uses_the_simulated_prior():
     assert out1["status"] & 2 and 0.4 < out1["dispPriorVar"] < 3.0
     d = synth.make(4000, 4)
     assert oracle.nbglm_fit(d["counts"], d["nf"], d["group"])["dispPriorVar"] == 0.25  # the benchmark generator sits at the floor
+
+
+# ---------------------------------------------------------------- control flow against the numpy twins
+@pytest.mark.parametrize("S", [4, 5, 8])
+def test_gene_dispersion_search_matches_procedure_twin(S):
+    """The whole gene-wise procedure (start values, Armijo search with its kappa schedule, the noIncrease and
+    grid rules) re-run row by row with numpy lstsq / scipy gammaln+digamma on a general design matrix: same
+    iteration counts, and estimates equal to well inside the search's own 1e-6 objective tolerance."""
+    d = synth.make(1500, S, start=10000 * S)
+    r = oracle.nbglm_fit(d["counts"], d["nf"], d["group"])
+    X = np_twin.design(d["group"])
+    rows = np.nonzero(r["allZero"] == 0)[0]
+    xim = np.mean(1.0 / d["nf"][rows].mean(axis=0))  # estimateDispersionsGeneEst works on object[!allZero, ]
+    # every kind of row: first rows, the rows that ran long or went to the grid, and the floor rows
+    special_rows = rows[(r["dispGeneIter"][rows] >= 30) | (r["dispGeneIter"][rows] == 1) | (r["dispGeneEst"][rows] < 1e-7)]
+    pick = np.unique(np.concatenate([rows[:250], special_rows[:150]]))
+    it_same = n_cmp = 0
+    for i in pick:
+        a0, est, it = np_twin.gene_dispersion(d["counts"][i], d["nf"][i], X, xim)
+        assert np.isclose(a0, r["dispInit"][i], rtol=1e-12), i
+        if a0 <= 1e-8:
+            # a search started on the floor: at alpha = 1e-8 the gradient is (digamma differences) * 1e16, all
+            # cancellation noise in double precision, so the walk differs between any two implementations; where
+            # it ends is what DESeq2 keeps
+            assert np.isclose(np.log(est), np.log(r["dispGeneEst"][i]), atol=5e-2), (i, est, r["dispGeneEst"][i])
+            continue
+        n_cmp += 1
+        it_same += it == r["dispGeneIter"][i]
+        if it == r["dispGeneIter"][i]:
+            assert np.isclose(est, r["dispGeneEst"][i], rtol=1e-7), (i, est, r["dispGeneEst"][i])
+        else:  # a comparison decided by rounding: both answers sit on the same flat top
+            assert np.isclose(np.log(est), np.log(r["dispGeneEst"][i]), atol=5e-2), (i, est, r["dispGeneEst"][i])
+    assert n_cmp > 80 and it_same >= n_cmp - 2, (it_same, n_cmp)
+
+
+@pytest.mark.parametrize("S", [4, 7, 8])
+def test_wald_irls_matches_qr_twin(S):
+    """fitBeta as DESeq2 writes it (QR of the ridge-augmented weighted design) against the oracle's closed-form
+    normal equations: same iteration count, coefficients, standard errors, deviance, fitted means."""
+    d = synth.make(1200, S, start=7000 * S)
+    r = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], want_mu=True)
+    X = np_twin.design(d["group"])
+    lam = np.array([1e-6, 1e-6]) / np_twin.LN2 ** 2
+    rows = np.nonzero((r["allZero"] == 0) & (r["betaConv"] == 1) & (r["betaIter"] < 100))[0]
+    pick = np.unique(np.concatenate([rows[:200], rows[np.argsort(-r["betaIter"][rows])[:60]]]))
+    for i in pick:
+        y = d["counts"][i].astype(float)
+        nf = d["nf"][i]
+        start = np.linalg.lstsq(X, np.log(y / nf + 0.1), rcond=None)[0]
+        b, it, dev, var, mu = np_twin.fit_beta(y, nf, X, r["dispersion"][i], lam, start)
+        assert it == r["betaIter"][i], (i, it, r["betaIter"][i])
+        assert np.allclose(b / np_twin.LN2, [r["beta0"][i], r["beta1"][i]], rtol=1e-8, atol=1e-10), i
+        assert np.allclose(np.sqrt(var) / np_twin.LN2, [r["se0"][i], r["se1"][i]], rtol=1e-9), i
+        unfloored = nf * np.exp(X @ b)
+        assert np.allclose(r["mu"][i], unfloored, rtol=1e-8)
+        assert np.isclose(r["deviance"][i], -2 * np_twin.nb_loglik(y, unfloored, r["dispersion"][i]), rtol=1e-8, atol=1e-8)
+
+
+def test_map_search_matches_procedure_twin():
+    """The MAP stage: same search with the log-normal prior centred on the trend, started from the gene-wise
+    estimate (or the trend when that is below a tenth of it)."""
+    S = 8
+    d = synth.make(1500, S, start=77000)
+    r = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], want_mu=False)
+    X = np_twin.design(d["group"])
+    rows = np.nonzero(r["allZero"] == 0)[0]
+    pick = np.unique(np.concatenate([rows[:150], rows[np.argsort(-r["dispIter"][rows])[:50]]]))
+    same = 0
+    for i in pick:
+        y = d["counts"][i].astype(float)
+        q = y / d["nf"][i]
+        mu = np.maximum(X @ np.linalg.lstsq(X, q, rcond=None)[0] * d["nf"][i], 0.5)
+        dg, df = r["dispGeneEst"][i], r["dispFit"][i]
+        start = dg if dg > 0.1 * df else df
+        prior = (np.log(df), r["dispPriorVar"])
+        a, it, first, last = np_twin.fit_disp(y, mu, X, np.log(start), prior, np.log(1e-8 / 10))
+        est = min(np.exp(a), 10.0)
+        if not (it < 100):
+            est = np_twin.fit_disp_grid(y, mu, X, S, prior)
+        est = min(max(est, 1e-8), 10.0)
+        same += it == r["dispIter"][i]
+        assert np.isclose(np.log(est), np.log(r["dispMAP"][i]), atol=1e-6 if it == r["dispIter"][i] else 5e-2), i
+    assert same >= len(pick) - 2
