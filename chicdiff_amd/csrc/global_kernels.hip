@@ -949,107 +949,168 @@ void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfra
     window_sums_kernel<<<dim3((unsigned)blocks, S), 256, 0, st>>>(fragN, fragFM, nfrag, S, rptr, n, N, FM);
 }
 
-// a1: count join.  RU is keyed by baitID (chicdiff.R:425), so the 1024 queries of a block fall in a
-// narrow key range: the block (2048 queries) finds that range with two binary searches on its min/max query,
-// streams the keys/values of the range into LDS (coalesced, read once) and resolves every query
-// there; a block whose range does not fit (unsorted callers) searches global memory, restricted
-// to the range.  Results do not depend on the path taken.
-constexpr int kJoinQ = 2048, kJoinCap = 4096;
-__device__ __forceinline__ int64_t lower_bound_g(const int64_t *keys, int64_t lo, int64_t hi, int64_t key) {
-    while (lo < hi) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        if (keys[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-// lower_bound over keys[lo, hi) by all 256 threads of the block: 256-ary search, 3 rounds for 10^7 keys
-// instead of 23 dependent loads by one thread.  Every thread returns the same value.
-__device__ __forceinline__ int64_t block_lower_bound(const int64_t *__restrict__ keys, int64_t lo, int64_t hi, int64_t target) {
-    while (hi - lo > 256) {
-        const int64_t step = (hi - lo + 255) / 256;
-        const int64_t pos = lo + (int64_t)threadIdx.x * step;
-        const int c = __syncthreads_count(pos < hi && keys[pos] < target);  // monotone in threadIdx.x
+// a1: count join.  RU is keyed by baitID (chicdiff.R:425) and a region's fragments are consecutive IDs, so the 512
+// queries of a wave's tile fall in a narrow key range and a lane's eight CONSECUTIVE queries land within a few keys
+// of each other.  Each wave works alone (no LDS, no block barrier), and what it is bound by is the chain of
+// DEPENDENT loads per tile (measured: one binary search per query 0.24 ms, a per-lane search of the first query
+// 0.18 ms at 22 M queries x 10 M keys), so the chain is kept to eight steps:
+//   1. lo = lower bound of the tile's smallest query, a 64-ary search by the whole wave (4 loads for 10^7 keys);
+//   2. one load of every 64th key after lo bounds the tile's largest query: hi, a multiple of 64 keys after lo
+//      (a tile that spans more than 4096 keys — an unsorted caller — gets a proper search instead);
+//   3. one load of 64 evenly spaced keys of [lo, hi): every lane ranks its first query among them (register
+//      compares against the 64 lanes' values) and so knows where its queries begin to within (hi-lo)/64 keys;
+//   4. one load of the 16 keys from there into registers: all eight queries are ranked by counting;
+//   5. one gather of key and value at the lower bound decides match / no match (N <- 0, chicdiff.R:851-853).
+// A query the 16 keys do not cover (a gap between regions, a far denser table, an unsorted caller) finishes by a
+// branch-free binary search over what is left of [lo, hi).  Results do not depend on the tiling.
+constexpr int kJoinPerLane = 8, kJoinTile = 64 * kJoinPerLane, kJoinGallop = 4096, kJoinRun = 16;
+// lower_bound over keys[lo, hi) by the 64 lanes of a wave; every lane returns the same value
+__device__ __forceinline__ int64_t wave_lower_bound(const int64_t *__restrict__ keys, int64_t lo, int64_t hi, int64_t target, int lane) {
+    while (hi - lo > 64) {
+        const int64_t step = (hi - lo + 63) / 64;
+        const int64_t pos = lo + (int64_t)lane * step;
+        const int c = __popcll(__ballot(pos < hi && keys[pos] < target));  // monotone in the lane
         const int64_t nlo = c > 0 ? lo + (int64_t)(c - 1) * step + 1 : lo;
         const int64_t pc = lo + (int64_t)c * step;
         hi = pc < hi ? pc : hi;  // the answer is in [nlo, hi] (it may be `hi` itself)
         lo = nlo;
     }
-    const int64_t pos = lo + threadIdx.x;
-    const int c = __syncthreads_count(pos < hi && keys[pos] < target);
-    return lo + c;
+    const int64_t pos = lo + lane;
+    return lo + __popcll(__ballot(pos < hi && keys[pos] < target));
 }
 
+template <bool VEC>  // VEC: bait / oe / out are 16-byte aligned, full tiles move as 4 x int32
 __global__ __launch_bounds__(256) void count_join_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
                                                          int64_t nru, const int64_t *__restrict__ keys,
                                                          const int32_t *__restrict__ vals, int64_t nkeys,
                                                          int32_t *__restrict__ out) {
-    __shared__ int64_t s_keys[kJoinCap];
-    __shared__ int32_t s_vals[kJoinCap];
-    __shared__ int64_t s_red[2][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t nblk = (nru + kJoinQ - 1) / kJoinQ;
-    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int64_t q0 = blk * kJoinQ;
-        int64_t q[8];
+    const int lane = threadIdx.x & 63;
+    const int64_t ntile = (nru + kJoinTile - 1) / kJoinTile;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
+    for (int64_t tile = wave0; tile < ntile; tile += nwave) {
+        const int64_t r0 = tile * kJoinTile + (int64_t)lane * kJoinPerLane;
+        const bool full = VEC && (tile + 1) * kJoinTile <= nru;
+        int32_t qb[kJoinPerLane], qo[kJoinPerLane];
+        if (full) {
+            const int4 b0 = *(const int4 *)(bait + r0), b1 = *(const int4 *)(bait + r0 + 4);
+            const int4 o0 = *(const int4 *)(oe + r0), o1 = *(const int4 *)(oe + r0 + 4);
+            qb[0] = b0.x; qb[1] = b0.y; qb[2] = b0.z; qb[3] = b0.w; qb[4] = b1.x; qb[5] = b1.y; qb[6] = b1.z; qb[7] = b1.w;
+            qo[0] = o0.x; qo[1] = o0.y; qo[2] = o0.z; qo[3] = o0.w; qo[4] = o1.x; qo[5] = o1.y; qo[6] = o1.z; qo[7] = o1.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) {
+                const bool v = r0 + k < nru;
+                qb[k] = v ? bait[r0 + k] : 0;
+                qo[k] = v ? oe[r0 + k] : 0;
+            }
+        }
+        int64_t q[kJoinPerLane];
         int64_t kmin = INT64_MAX, kmax = INT64_MIN;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int64_t r = q0 + threadIdx.x + k * 256;
-            q[k] = INT64_MIN;
-            if (r < nru) {
-                q[k] = ((int64_t)bait[r] << 32) | (uint32_t)oe[r];
+        for (int k = 0; k < kJoinPerLane; k++) {
+            q[k] = ((int64_t)qb[k] << 32) | (uint32_t)qo[k];
+            if (r0 + k < nru) {
                 kmin = q[k] < kmin ? q[k] : kmin;
                 kmax = q[k] > kmax ? q[k] : kmax;
             }
         }
         for (int off = 32; off > 0; off >>= 1) {
-            const int64_t a = __shfl_down(kmin, off), c = __shfl_down(kmax, off);
+            const int64_t a = __shfl_xor(kmin, off), c = __shfl_xor(kmax, off);
             kmin = a < kmin ? a : kmin;
             kmax = c > kmax ? c : kmax;
         }
-        __syncthreads();  // previous iteration done with the shared buffers
-        if (lane == 0) { s_red[0][wave] = kmin; s_red[1][wave] = kmax; }
-        __syncthreads();
-        int64_t mn = s_red[0][0], mx = s_red[1][0];
-        for (int w = 1; w < 4; w++) { mn = s_red[0][w] < mn ? s_red[0][w] : mn; mx = s_red[1][w] > mx ? s_red[1][w] : mx; }
-        const int64_t lo = block_lower_bound(keys, 0, nkeys, mn);
-        int64_t hi = block_lower_bound(keys, lo, nkeys, mx);
-        if (hi < nkeys && keys[hi] == mx) hi++;
-        const int w = (int)(hi - lo);
-        if (hi - lo <= kJoinCap) {
-            for (int e = threadIdx.x; e < w; e += 256) {
-                s_keys[e] = keys[lo + e];
-                s_vals[e] = vals[lo + e];
-            }
-            __syncthreads();
+        const int64_t lo = wave_lower_bound(keys, 0, nkeys, kmin, lane);
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int64_t r = q0 + threadIdx.x + k * 256;
-                if (r >= nru) continue;
-                int a = 0, c = w;
-                while (a < c) {
-                    const int mid = (a + c) >> 1;
-                    if (s_keys[mid] < q[k]) a = mid + 1; else c = mid;
-                }
-                out[r] = (a < w && s_keys[a] == q[k]) ? s_vals[a] : 0;
+        for (int k = 0; k < kJoinPerLane; k++)
+            if (r0 + k >= nru) q[k] = kmax;  // the ragged end of the last tile: searched like its neighbours, never stored
+        int64_t hi;
+        {
+            const int64_t pos = lo + (int64_t)(lane + 1) * 64 - 1;
+            const int c = __popcll(__ballot(pos < nkeys && keys[pos] < kmax));
+            if (c < 64) {
+                hi = lo + (int64_t)(c + 1) * 64;  // keys[hi - 1] >= kmax, or hi runs past the table
+                hi = hi < nkeys ? hi : nkeys;
+            } else {
+                hi = wave_lower_bound(keys, lo + kJoinGallop, nkeys, kmax, lane);
+                if (hi < nkeys && keys[hi] == kmax) hi++;
             }
+        }
+        // where the lane's first query sits among 64 evenly spaced keys of [lo, hi)
+        const int64_t stride = (hi - lo + 63) / 64;
+        int64_t from = lo;
+        {
+            const int64_t pos = lo + (int64_t)lane * stride;
+            const int64_t sample = pos < hi ? keys[pos] : INT64_MAX;
+            const int s_lo = (int)(uint32_t)sample, s_hi = (int)(sample >> 32);
+            int m = 0;
+#pragma unroll 16
+            for (int l = 0; l < 64; l++) {  // v_readlane: the other lanes' samples as scalar operands
+                const int64_t other = ((int64_t)__builtin_amdgcn_readlane(s_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(s_lo, l);
+                m += other < q[0] ? 1 : 0;
+            }
+            if (m > 0) from = lo + (int64_t)(m - 1) * stride + 1;  // keys[from - 1] < q[0]
+        }
+        // all eight queries against the kJoinRun keys from there
+        int64_t b[kJoinPerLane], rest[kJoinPerLane];  // answer of query k in [b[k], b[k] + rest[k]]
+        {
+            int64_t R[kJoinRun];
+#pragma unroll
+            for (int t = 0; t < kJoinRun; t++) R[t] = from + t < hi ? keys[from + t] : INT64_MAX;
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) {
+                int cnt = 0;
+#pragma unroll
+                for (int t = 0; t < kJoinRun; t++) cnt += R[t] < q[k] ? 1 : 0;
+                const bool before = q[k] < q[0];                               // unsorted caller: anywhere in [lo, hi]
+                const bool beyond = cnt == kJoinRun && from + kJoinRun < hi;   // the run does not reach the query
+                b[k] = before ? lo : from + cnt;
+                rest[k] = before ? hi - lo : (beyond ? hi - (from + kJoinRun) : 0);
+            }
+        }
+        for (;;) {
+            bool more = false;
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) more |= rest[k] > 0;
+            if (!__ballot(more)) break;
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) {
+                if (rest[k] > 1) {
+                    const int64_t half = rest[k] >> 1;
+                    b[k] += keys[b[k] + half - 1] < q[k] ? half : 0;
+                    rest[k] -= half;
+                } else if (rest[k] == 1) {
+                    b[k] += keys[b[k]] < q[k] ? 1 : 0;
+                    rest[k] = 0;
+                }
+            }
+        }
+        int32_t res[kJoinPerLane];
+#pragma unroll
+        for (int k = 0; k < kJoinPerLane; k++) {
+            const bool in = b[k] < hi && r0 + k < nru;
+            const int64_t at = in ? b[k] : 0;
+            const int64_t kk = in ? keys[at] : 0;
+            const int32_t vv = in ? vals[at] : 0;
+            res[k] = (in && kk == q[k]) ? vv : 0;
+        }
+        if (full) {
+            *(int4 *)(out + r0) = make_int4(res[0], res[1], res[2], res[3]);
+            *(int4 *)(out + r0 + 4) = make_int4(res[4], res[5], res[6], res[7]);
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int64_t r = q0 + threadIdx.x + k * 256;
-                if (r >= nru) continue;
-                const int64_t a = lower_bound_g(keys, lo, hi, q[k]);
-                out[r] = (a < hi && keys[a] == q[k]) ? vals[a] : 0;
-            }
+            for (int k = 0; k < kJoinPerLane; k++)
+                if (r0 + k < nru) out[r0 + k] = res[k];
         }
     }
 }
 void launch_count_join(const int32_t *bait, const int32_t *oe, int64_t nru, const int64_t *keys, const int32_t *vals,
                        int64_t nkeys, int32_t *out, hipStream_t st) {
-    int64_t blocks = (nru + kJoinQ - 1) / kJoinQ;
-    if (blocks > 4096) blocks = 4096;
+    int64_t blocks = ((nru + kJoinTile - 1) / kJoinTile + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    count_join_kernel<<<(unsigned)blocks, 256, 0, st>>>(bait, oe, nru, keys, vals, nkeys, out);
+    const bool vec = (((uintptr_t)bait | (uintptr_t)oe | (uintptr_t)out) & 15) == 0;
+    if (vec) count_join_kernel<true><<<(unsigned)blocks, 256, 0, st>>>(bait, oe, nru, keys, vals, nkeys, out);
+    else count_join_kernel<false><<<(unsigned)blocks, 256, 0, st>>>(bait, oe, nru, keys, vals, nkeys, out);
 }
 
 __global__ __launch_bounds__(256) void pvalue_kernel(const double *__restrict__ stat, int64_t n, double *__restrict__ p) {

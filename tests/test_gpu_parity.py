@@ -214,10 +214,35 @@ def test_count_join(ctx, oracle):
     assert np.array_equal(got, ref)                      # unsorted queries: global-memory search path
     order = np.argsort((bait.astype(np.int64) << 32) | oe, kind="stable")
     got2 = ctx.count_join(t(bait[order]), t(oe[order]), t(keys), t(vals)).cpu().numpy()
-    assert np.array_equal(got2, ref[order])              # RU keyed by baitID: LDS key-window path
+    assert np.array_equal(got2, ref[order])              # RU keyed by baitID: narrow key range per tile
     assert (got2 == 0).any() and (got2 > 0).any()
     e = ctx.count_join(t(bait[:5]), t(oe[:5]), t(keys[:0]), t(vals[:0])).cpu().numpy()
     assert np.array_equal(e, np.zeros(5, dtype=np.int32))  # empty count table: every N is 0
+    sb, so = bait[order], oe[order]
+    for nq in (1, 7, 511, 512, 513, 1025):               # ragged last tile, single lanes
+        assert np.array_equal(ctx.count_join(t(sb[:nq]), t(so[:nq]), t(keys), t(vals)).cpu().numpy(), ref[order][:nq]), nq
+    # pointers that are not 16-byte aligned (a caller's slice): the scalar load / store variant
+    db, do = t(sb), t(so)
+    for off in (1, 2, 3):
+        assert np.array_equal(ctx.count_join(db[off:], do[off:], t(keys), t(vals)).cpu().numpy(), ref[order][off:]), off
+    # a count table far denser than the queries (chinput holds every observed pair of the RU baits): the 16 keys a
+    # lane holds in registers do not reach its next query, the search continues in what is left of the range;
+    # and one far sparser; and regions as Chicdiff builds them (runs of consecutive IDs, gaps between them)
+    allk = np.unique((rng.integers(1000, 1400, 3000000).astype(np.int64) << 32) | rng.integers(0, 30000, 3000000))
+    for kk in (allk, allk[::97]):
+        vv = rng.integers(1, 500, len(kk)).astype(np.int32)
+        assert np.array_equal(ctx.count_join(db, do, t(kk), t(vv)).cpu().numpy(), oracle.count_join(sb, so, kk, vv))
+    rb = np.repeat(rng.integers(1000, 1400, 20000), 11).astype(np.int32)
+    ro = (np.repeat(rng.integers(20, 29000, 20000), 11) + np.tile(np.arange(11), 20000)).astype(np.int32)
+    o2 = np.argsort(rb, kind="stable")                   # setkey(RU, baitID): sorted by bait only
+    rb, ro = rb[o2], ro[o2]
+    vv = rng.integers(1, 500, len(allk)).astype(np.int32)
+    got3 = ctx.count_join(t(rb), t(ro), t(allk), t(vv)).cpu().numpy()
+    assert np.array_equal(got3, oracle.count_join(rb, ro, allk, vv)) and (got3 > 0).sum() > 1000
+    # extreme keys: INT32_MAX / negative IDs never match a table of valid IDs and must not disturb their neighbours
+    xb = np.array([2**31 - 1, 1000, -5, 1200, 1200], dtype=np.int32)
+    xo = np.array([-1, 5, 7, 2**31 - 1, 17], dtype=np.int32)
+    assert np.array_equal(ctx.count_join(t(xb), t(xo), t(keys), t(vals)).cpu().numpy(), oracle.count_join(xb, xo, keys, vals))
 
 
 def test_theta_grid(ctx, oracle):
