@@ -956,8 +956,9 @@ int chicdiff_hip_count_join_dev(chicdiff_hip_ctx *c, const int32_t *d_ru_bait, c
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
     if (nru > 0) {
+        if (int rc = ensure_aux(c, count_join_scratch_bytes(nkeys))) return rc;
         Scope t(c, "count_join");
-        launch_count_join(d_ru_bait, d_ru_oe, nru, d_keys, d_vals, nkeys, d_out, c->stream);
+        launch_count_join(d_ru_bait, d_ru_oe, nru, d_keys, d_vals, nkeys, d_out, c->aux, c->stream);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_collect(c);

@@ -94,8 +94,9 @@ void launch_offsets(const double *fullMean, const double *sf_dev, int64_t n, int
                     double *out, hipStream_t st);
 void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfrag, int S, const int64_t *rptr,
                         int64_t n, int32_t *N, double *FM, hipStream_t st);
+size_t count_join_scratch_bytes(int64_t nkeys);
 void launch_count_join(const int32_t *bait, const int32_t *oe, int64_t nru, const int64_t *keys,
-                       const int32_t *vals, int64_t nkeys, int32_t *out, hipStream_t st);
+                       const int32_t *vals, int64_t nkeys, int32_t *out, void *scratch, hipStream_t st);
 void launch_fragment_background(const int32_t *bait, const int32_t *oe, int64_t nru, int32_t id_min, int32_t nid,
                                 const int64_t *midsum, int32_t S, const double *sj, const double *si, const int32_t *tblb,
                                 const int32_t *tlb, const double *T, int32_t ntblb, int32_t ntlb, const double *distfun_dev,

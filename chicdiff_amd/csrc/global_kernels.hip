@@ -950,20 +950,22 @@ void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfra
 }
 
 // a1: count join.  RU is keyed by baitID (chicdiff.R:425) and a region's fragments are consecutive IDs, so the 512
-// queries of a wave's tile fall in a narrow key range and a lane's eight CONSECUTIVE queries land within a few keys
-// of each other.  Each wave works alone (no LDS, no block barrier), and what it is bound by is the chain of
-// DEPENDENT loads per tile (measured: one binary search per query 0.24 ms, a per-lane search of the first query
-// 0.18 ms at 22 M queries x 10 M keys), so the chain is kept to eight steps:
-//   1. lo = lower bound of the tile's smallest query, a 64-ary search by the whole wave (4 loads for 10^7 keys);
-//   2. one load of every 64th key after lo bounds the tile's largest query: hi, a multiple of 64 keys after lo
-//      (a tile that spans more than 4096 keys — an unsorted caller — gets a proper search instead);
-//   3. one load of 64 evenly spaced keys of [lo, hi): every lane ranks its first query among them (register
-//      compares against the 64 lanes' values) and so knows where its queries begin to within (hi-lo)/64 keys;
-//   4. one load of the 16 keys from there into registers: all eight queries are ranked by counting;
-//   5. one gather of key and value at the lower bound decides match / no match (N <- 0, chicdiff.R:851-853).
-// A query the 16 keys do not cover (a gap between regions, a far denser table, an unsorted caller) finishes by a
-// branch-free binary search over what is left of [lo, hi).  Results do not depend on the tiling.
-constexpr int kJoinPerLane = 8, kJoinTile = 64 * kJoinPerLane, kJoinGallop = 4096, kJoinRun = 16;
+// queries of a wave's tile (eight consecutive rows per lane, moved as 4 x int32) fall in a narrow key range.  Each
+// wave works alone — no block barrier — and keeps the chain of DEPENDENT global loads per tile short, which is what
+// bounds the kernel (measured at 22 M queries x 10 M keys: a block-wide LDS window 0.31 ms, one global binary search
+// per query 0.24 ms, a per-lane register run of 16 keys 0.17 ms):
+//   1. lo = lower bound of the tile's smallest query: a 64-ary search by the whole wave over the table's coarse
+//      level (every 64th key, copied out once per call: 1/64 of the table, L2-resident), then one dense load of
+//      the 64 keys it points at — probing the table itself every 64th key costs a 128-byte line per 8 bytes used
+//      and two to three HBM round trips per tile;
+//   2. one dense load of the next 64 coarse entries bounds the tile's largest query: hi
+//      (a tile that spans more than 4096 keys gets a proper search instead);
+//   3. a range of at most kJoinCap keys goes to the wave's LDS slice with its values (coalesced, read once) and
+//      every lane resolves its eight queries there by a branch-free binary search, eight independent LDS reads per
+//      step; a wider range (a far denser table, an unsorted caller) is searched in global memory the same way;
+//   4. key and value at the lower bound decide match / no match (N <- 0, chicdiff.R:851-853).
+// Results do not depend on the tiling or on the path taken.
+constexpr int kJoinPerLane = 8, kJoinTile = 64 * kJoinPerLane, kJoinCap = 512;
 // lower_bound over keys[lo, hi) by the 64 lanes of a wave; every lane returns the same value
 __device__ __forceinline__ int64_t wave_lower_bound(const int64_t *__restrict__ keys, int64_t lo, int64_t hi, int64_t target, int lane) {
     while (hi - lo > 64) {
@@ -980,18 +982,28 @@ __device__ __forceinline__ int64_t wave_lower_bound(const int64_t *__restrict__ 
 }
 
 template <bool VEC>  // VEC: bait / oe / out are 16-byte aligned, full tiles move as 4 x int32
-__global__ __launch_bounds__(256) void count_join_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
+__global__ __launch_bounds__(256, 6) void count_join_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
                                                          int64_t nru, const int64_t *__restrict__ keys,
                                                          const int32_t *__restrict__ vals, int64_t nkeys,
+                                                         const int64_t *__restrict__ index, int64_t nidx,
                                                          int32_t *__restrict__ out) {
+    __shared__ int64_t s_keys[4][kJoinCap];
+    __shared__ int32_t s_vals[4][kJoinCap];
     const int lane = threadIdx.x & 63;
-    const int64_t ntile = (nru + kJoinTile - 1) / kJoinTile;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
-    for (int64_t tile = wave0; tile < ntile; tile += nwave) {
+    int64_t *const sk = s_keys[threadIdx.x >> 6];
+    int32_t *const sv = s_vals[threadIdx.x >> 6];
+    // VEC launches cover the full tiles only; the ragged end (and unaligned callers) go through the scalar variant
+    const int64_t ntile = VEC ? nru / kJoinTile : (nru + kJoinTile - 1) / kJoinTile;
+    // blocks b and b + 8 share an XCD (round-robin dispatch; speed only): each of the eight L2s serves one contiguous
+    // eighth of the tiles, so the sparse probes of neighbouring tiles (every 64th key: 128-byte lines of which 8
+    // bytes are used) hit lines a neighbour has just brought in instead of going to HBM again
+    const int64_t per_xcd = (ntile + 7) / 8, t_begin = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t t_end = t_begin + per_xcd < ntile ? t_begin + per_xcd : ntile;
+    const int64_t wave0 = (int64_t)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), nwave = (int64_t)(gridDim.x >> 3) * 4;
+    for (int64_t tile = t_begin + wave0; tile < t_end; tile += nwave) {
         const int64_t r0 = tile * kJoinTile + (int64_t)lane * kJoinPerLane;
-        const bool full = VEC && (tile + 1) * kJoinTile <= nru;
         int32_t qb[kJoinPerLane], qo[kJoinPerLane];
-        if (full) {
+        if (VEC) {
             const int4 b0 = *(const int4 *)(bait + r0), b1 = *(const int4 *)(bait + r0 + 4);
             const int4 o0 = *(const int4 *)(oe + r0), o1 = *(const int4 *)(oe + r0 + 4);
             qb[0] = b0.x; qb[1] = b0.y; qb[2] = b0.z; qb[3] = b0.w; qb[4] = b1.x; qb[5] = b1.y; qb[6] = b1.z; qb[7] = b1.w;
@@ -1009,7 +1021,7 @@ __global__ __launch_bounds__(256) void count_join_kernel(const int32_t *__restri
 #pragma unroll
         for (int k = 0; k < kJoinPerLane; k++) {
             q[k] = ((int64_t)qb[k] << 32) | (uint32_t)qo[k];
-            if (r0 + k < nru) {
+            if (VEC || r0 + k < nru) {
                 kmin = q[k] < kmin ? q[k] : kmin;
                 kmax = q[k] > kmax ? q[k] : kmax;
             }
@@ -1019,81 +1031,86 @@ __global__ __launch_bounds__(256) void count_join_kernel(const int32_t *__restri
             kmin = a < kmin ? a : kmin;
             kmax = c > kmax ? c : kmax;
         }
-        const int64_t lo = wave_lower_bound(keys, 0, nkeys, kmin, lane);
-#pragma unroll
-        for (int k = 0; k < kJoinPerLane; k++)
-            if (r0 + k >= nru) q[k] = kmax;  // the ragged end of the last tile: searched like its neighbours, never stored
+        // lo: the coarse level (every 64th key, L2-resident) says which 64 keys hold the lower bound of the tile's
+        // smallest query, one dense load of those finishes; hi: the first coarse entry >= the largest query, from the
+        // 64 entries after lo (one dense load), or a proper search for a tile that spans more than 4096 keys
+        const int64_t jlo = wave_lower_bound(index, 0, nidx, kmin, lane);  // first j with keys[64 j] >= kmin
+        int64_t lo = 0;
+        if (jlo > 0) {
+            const int64_t e = 64 * jlo < nkeys ? 64 * jlo : nkeys;
+            lo = wave_lower_bound(keys, 64 * (jlo - 1) + 1, e, kmin, lane);
+        }
         int64_t hi;
         {
-            const int64_t pos = lo + (int64_t)(lane + 1) * 64 - 1;
-            const int c = __popcll(__ballot(pos < nkeys && keys[pos] < kmax));
-            if (c < 64) {
-                hi = lo + (int64_t)(c + 1) * 64;  // keys[hi - 1] >= kmax, or hi runs past the table
-                hi = hi < nkeys ? hi : nkeys;
-            } else {
-                hi = wave_lower_bound(keys, lo + kJoinGallop, nkeys, kmax, lane);
-                if (hi < nkeys && keys[hi] == kmax) hi++;
-            }
-        }
-        // where the lane's first query sits among 64 evenly spaced keys of [lo, hi)
-        const int64_t stride = (hi - lo + 63) / 64;
-        int64_t from = lo;
-        {
-            const int64_t pos = lo + (int64_t)lane * stride;
-            const int64_t sample = pos < hi ? keys[pos] : INT64_MAX;
-            const int s_lo = (int)(uint32_t)sample, s_hi = (int)(sample >> 32);
-            int m = 0;
-#pragma unroll 16
-            for (int l = 0; l < 64; l++) {  // v_readlane: the other lanes' samples as scalar operands
-                const int64_t other = ((int64_t)__builtin_amdgcn_readlane(s_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(s_lo, l);
-                m += other < q[0] ? 1 : 0;
-            }
-            if (m > 0) from = lo + (int64_t)(m - 1) * stride + 1;  // keys[from - 1] < q[0]
-        }
-        // all eight queries against the kJoinRun keys from there
-        int64_t b[kJoinPerLane], rest[kJoinPerLane];  // answer of query k in [b[k], b[k] + rest[k]]
-        {
-            int64_t R[kJoinRun];
-#pragma unroll
-            for (int t = 0; t < kJoinRun; t++) R[t] = from + t < hi ? keys[from + t] : INT64_MAX;
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++) {
-                int cnt = 0;
-#pragma unroll
-                for (int t = 0; t < kJoinRun; t++) cnt += R[t] < q[k] ? 1 : 0;
-                const bool before = q[k] < q[0];                               // unsorted caller: anywhere in [lo, hi]
-                const bool beyond = cnt == kJoinRun && from + kJoinRun < hi;   // the run does not reach the query
-                b[k] = before ? lo : from + cnt;
-                rest[k] = before ? hi - lo : (beyond ? hi - (from + kJoinRun) : 0);
-            }
-        }
-        for (;;) {
-            bool more = false;
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++) more |= rest[k] > 0;
-            if (!__ballot(more)) break;
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++) {
-                if (rest[k] > 1) {
-                    const int64_t half = rest[k] >> 1;
-                    b[k] += keys[b[k] + half - 1] < q[k] ? half : 0;
-                    rest[k] -= half;
-                } else if (rest[k] == 1) {
-                    b[k] += keys[b[k]] < q[k] ? 1 : 0;
-                    rest[k] = 0;
-                }
-            }
+            const int64_t j0 = lo / 64 + 1, pos = j0 + lane;
+            const int c = __popcll(__ballot(pos < nidx && index[pos] < kmax));
+            int64_t jhi = j0 + c;  // keys[64 jhi] >= kmax, or jhi >= nidx
+            if (c == 64) jhi = wave_lower_bound(index, j0 + 64, nidx, kmax, lane);
+            hi = jhi < nidx ? 64 * jhi + 1 : nkeys;
         }
         int32_t res[kJoinPerLane];
+        if (hi - lo <= kJoinCap) {
+            const int w = (int)(hi - lo);
+            {
+                int64_t tk[kJoinCap / 64];
+                int32_t tv[kJoinCap / 64];
 #pragma unroll
-        for (int k = 0; k < kJoinPerLane; k++) {
-            const bool in = b[k] < hi && r0 + k < nru;
-            const int64_t at = in ? b[k] : 0;
-            const int64_t kk = in ? keys[at] : 0;
-            const int32_t vv = in ? vals[at] : 0;
-            res[k] = (in && kk == q[k]) ? vv : 0;
+                for (int e = 0; e < kJoinCap / 64; e++) {
+                    const int at = e * 64 + lane;
+                    tk[e] = at < w ? keys[lo + at] : 0;
+                    tv[e] = at < w ? vals[lo + at] : 0;
+                }
+#pragma unroll
+                for (int e = 0; e < kJoinCap / 64; e++) {
+                    sk[e * 64 + lane] = tk[e];
+                    sv[e * 64 + lane] = tv[e];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int b[kJoinPerLane];  // the answer of query k stays in [b[k], b[k] + len]
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) b[k] = 0;
+            int len = w;
+            while (len > 1) {
+                const int half = len >> 1;
+#pragma unroll
+                for (int k = 0; k < kJoinPerLane; k++) b[k] += sk[b[k] + half - 1] < q[k] ? half : 0;
+                len -= half;
+            }
+            if (len == 1) {
+#pragma unroll
+                for (int k = 0; k < kJoinPerLane; k++) b[k] += sk[b[k]] < q[k] ? 1 : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) {
+                const bool in = b[k] < w;
+                const int at = in ? b[k] : 0;
+                res[k] = (in && sk[at] == q[k]) ? sv[at] : 0;
+            }
+            __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next tile
+        } else {
+            int64_t b[kJoinPerLane];
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) b[k] = lo;
+            int64_t len = hi - lo;
+            while (len > 1) {
+                const int64_t half = len >> 1;
+#pragma unroll
+                for (int k = 0; k < kJoinPerLane; k++) b[k] += keys[b[k] + half - 1] < q[k] ? half : 0;
+                len -= half;
+            }
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) b[k] += keys[b[k]] < q[k] ? 1 : 0;  // len == 1: the range has > kJoinCap keys
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) {
+                const bool in = b[k] < hi;
+                const int64_t at = in ? b[k] : lo;
+                res[k] = (in && keys[at] == q[k]) ? vals[at] : 0;
+            }
         }
-        if (full) {
+        if (VEC) {
             *(int4 *)(out + r0) = make_int4(res[0], res[1], res[2], res[3]);
             *(int4 *)(out + r0 + 4) = make_int4(res[4], res[5], res[6], res[7]);
         } else {
@@ -1103,14 +1120,26 @@ __global__ __launch_bounds__(256) void count_join_kernel(const int32_t *__restri
         }
     }
 }
+__global__ __launch_bounds__(256) void join_index_kernel(const int64_t *__restrict__ keys, int64_t nidx, int64_t *__restrict__ index) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < nidx) index[j] = keys[64 * j];
+}
+size_t count_join_scratch_bytes(int64_t nkeys) { return sizeof(int64_t) * (size_t)((nkeys + 63) / 64 + 1); }
+// scratch: count_join_scratch_bytes(nkeys) bytes
 void launch_count_join(const int32_t *bait, const int32_t *oe, int64_t nru, const int64_t *keys, const int32_t *vals,
-                       int64_t nkeys, int32_t *out, hipStream_t st) {
-    int64_t blocks = ((nru + kJoinTile - 1) / kJoinTile + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
+                       int64_t nkeys, int32_t *out, void *scratch, hipStream_t st) {
+    auto grid = [](int64_t rows) {  // a multiple of 8: one share of the tiles per XCD
+        int64_t blocks = (((rows + kJoinTile - 1) / kJoinTile + 3) / 4 + 7) / 8 * 8;
+        return (unsigned)(blocks > 8192 ? 8192 : (blocks < 8 ? 8 : blocks));
+    };
+    int64_t *index = (int64_t *)scratch;
+    const int64_t nidx = (nkeys + 63) / 64;
+    if (nidx > 0) join_index_kernel<<<(unsigned)((nidx + 255) / 256), 256, 0, st>>>(keys, nidx, index);
     const bool vec = (((uintptr_t)bait | (uintptr_t)oe | (uintptr_t)out) & 15) == 0;
-    if (vec) count_join_kernel<true><<<(unsigned)blocks, 256, 0, st>>>(bait, oe, nru, keys, vals, nkeys, out);
-    else count_join_kernel<false><<<(unsigned)blocks, 256, 0, st>>>(bait, oe, nru, keys, vals, nkeys, out);
+    const int64_t body = vec ? nru / kJoinTile * kJoinTile : 0;
+    if (body > 0) count_join_kernel<true><<<grid(body), 256, 0, st>>>(bait, oe, body, keys, vals, nkeys, index, nidx, out);
+    if (nru > body)
+        count_join_kernel<false><<<grid(nru - body), 256, 0, st>>>(bait + body, oe + body, nru - body, keys, vals, nkeys, index, nidx, out + body);
 }
 
 __global__ __launch_bounds__(256) void pvalue_kernel(const double *__restrict__ stat, int64_t n, double *__restrict__ p) {
