@@ -141,7 +141,8 @@ DESeq2Wrap <- function(chicdiff.settings, RU, FullRegionData, suffix = "", theta
   }
 
   ctx <- .hipContext(device)
-  fr <- .hipDenseFragments(FullRegionData)
+  ## either the reference's long "recast" table, or the device-resident fragment block of getFullRegionDataHip()
+  fr <- if (inherits(FullRegionData, "chicdiffHipRegionData")) FullRegionData else .hipDenseFragments(FullRegionData)
   n <- fr$n; S <- fr$S
   group <- .hipGroup(fr$condition)
 

@@ -8,7 +8,7 @@
  *
  * One routine per step of DESeq2Wrap() (chicdiff.R:1494-1777) that moved to the GPU; r/R/DESeq2Wrap_hip.R calls them:
  *   chicdiff_hip_open          —                                   one context per R process and device
- *   chicdiff_hip_upload / _download / _release                      device-resident vectors (external pointers)
+ *   chicdiff_hip_upload / _alloc / _download / _release             device-resident vectors (external pointers)
  *   chicdiff_hip_window_sums   chicdiff.R:1540-1556                 N / FullMean window sums -> n x S matrices
  *   chicdiff_hip_size_factors  chicdiff.R:1561-1562                 estimateSizeFactors
  *   chicdiff_hip_offsets       chicdiff.R:1583-1589, 1635-1638      normFactorsM3 / sc(theta) / size factors
@@ -19,6 +19,9 @@
  *   chicdiff_hip_padj          DESeq2 results(): independent filtering + BH
  *   chicdiff_hip_ihw_apply     chicdiff.R:2038-2049
  *   chicdiff_hip_region_universe chicdiff.R:376-401
+ *   chicdiff_hip_chinput_table chicdiff.R:828-831, 849              fread(chinput), RU baits only, keyed (baitID, otherEndID)
+ *   chicdiff_hip_count_join    chicdiff.R:843-858                   N per RU row and replicate, 0 where unobserved
+ *   chicdiff_hip_fragment_background chicdiff.R:628-703, 894-896    Bmean, Tmean, FullMean per RU row and replicate
  *
  * Conventions: R matrices are column-major = the library's sample-major layout, so INTEGER()/REAL() pass through
  * untransposed.  Every device allocation is owned by an external pointer with a finalizer from the moment it
@@ -131,6 +134,16 @@ static SEXP to_host(SEXP ctx, const void *d, int type, R_xlen_t len) {
 SEXP chicdiff_hip_upload(SEXP ctx, SEXP x) {
     if (TYPEOF(x) != INTSXP && TYPEOF(x) != REALSXP) Rf_error("chicdiff_hip_upload: integer or double vector expected");
     SEXP p = as_device(ctx, x, TYPEOF(x), -1, "x");
+    UNPROTECT(1);
+    return p;
+}
+/* .Call(chicdiff_hip_alloc, ctx, "integer" | "double", length) -> uninitialised device vector (a matrix another routine fills column by column) */
+SEXP chicdiff_hip_alloc(SEXP ctx, SEXP type, SEXP length) {
+    if (!Rf_isString(type) || LENGTH(type) != 1) Rf_error("chicdiff_hip_alloc: type must be \"integer\" or \"double\"");
+    const char *t = CHAR(STRING_ELT(type, 0));
+    const double len = Rf_asReal(length);
+    if (!(len >= 0) || (strcmp(t, "integer") && strcmp(t, "double"))) Rf_error("chicdiff_hip_alloc: bad arguments");
+    SEXP p = devbuf_new(ctx, strcmp(t, "integer") ? REALSXP : INTSXP, (R_xlen_t)len);
     UNPROTECT(1);
     return p;
 }
@@ -475,9 +488,155 @@ SEXP chicdiff_hip_region_universe(SEXP ctx, SEXP baitID, SEXP oeID, SEXP RUexpan
     return out;
 }
 
+/* ---- f2 + a1: chinput -> count table -> per-replicate fragment counts, chicdiff.R:811-858 ------------------------------ */
+/* .Call(chicdiff_hip_chinput_table, ctx, path, baits (integer: sort(unique(RU$baitID)), or NULL = keep every row))
+ * -> list(keys = device (baitID << 32 | otherEndID, ascending; carried in an 8-byte vector), vals = device integer N,
+ *         nkeys, nrows): `x <- fread(chinput); setkey(x, baitID); x <- x[J(baits), ]` (:828-831) and the
+ * `setkey(temp, baitID, otherEndID)` of :849, as one table per replicate */
+SEXP chicdiff_hip_chinput_table(SEXP ctx, SEXP path, SEXP baits) {
+    if (!Rf_isString(path) || LENGTH(path) != 1) Rf_error("chicdiff_hip_chinput_table: one file name expected");
+    chicdiff_hip_ctx *c = ctx_of(ctx);
+    int np = 0;
+    int32_t max_id = -1;
+    SEXP dMap = R_NilValue;
+    if (!Rf_isNull(baits)) {
+        if (!Rf_isInteger(baits)) Rf_error("chicdiff_hip_chinput_table: baits must be integer IDs");
+        for (R_xlen_t i = 0; i < XLENGTH(baits); i++) {
+            const int b = INTEGER(baits)[i];
+            if (b == NA_INTEGER || b < 0) Rf_error("chicdiff_hip_chinput_table: NA or negative bait ID");
+            if (b > max_id) max_id = b;
+        }
+        /* one byte per ID 0..max_id, staged in R-managed memory and kept in a 4-byte device vector */
+        const R_xlen_t words = ((R_xlen_t)max_id + 1 + 3) / 4 + 1;
+        unsigned char *map = (unsigned char *)R_alloc((size_t)words, 4);
+        memset(map, 0, (size_t)words * 4);
+        for (R_xlen_t i = 0; i < XLENGTH(baits); i++) map[INTEGER(baits)[i]] = 1;
+        dMap = devbuf_new(ctx, INTSXP, words); np++;
+        check_rc(ctx, chicdiff_hip_memcpy_h2d(c, dptr(dMap), map, (uint64_t)words * 4), "chicdiff_hip_chinput_table");
+    }
+    int64_t nrows = 0, nkeys = 0;
+    check_rc(ctx, chicdiff_hip_chinput_read(c, CHAR(STRING_ELT(path, 0)), 0, &nrows), "chicdiff_hip_chinput_table");
+    static const char *names[] = {"keys", "vals", "nkeys", "nrows"};
+    SEXP out = PROTECT(named_list(4, names)); np++;
+    SEXP dK = devbuf_new(ctx, REALSXP, (R_xlen_t)nrows); np++;
+    SET_VECTOR_ELT(out, 0, dK);
+    SEXP dV = devbuf_new(ctx, INTSXP, (R_xlen_t)nrows); np++;
+    SET_VECTOR_ELT(out, 1, dV);
+    if (nrows > 0)
+        check_rc(ctx, chicdiff_hip_chinput_table_dev(c, Rf_isNull(baits) ? NULL : (const uint8_t *)dptr(dMap), max_id, (int64_t *)dptr(dK),
+                                                     (int32_t *)dptr(dV), &nkeys),
+                 "chicdiff_hip_chinput_table");
+    SET_VECTOR_ELT(out, 2, Rf_ScalarReal((double)nkeys));
+    SET_VECTOR_ELT(out, 3, Rf_ScalarReal((double)nrows));
+    if (!Rf_isNull(baits)) devbuf_finalizer(dMap);
+    UNPROTECT(np);
+    return out;
+}
+
+/* .Call(chicdiff_hip_count_join, ctx, ru_bait, ru_oe (integer nru, host or device), table (chicdiff_hip_chinput_table),
+ *       out (device integer nru x S or NULL), column (0-based)) -> device integer: N of every RU row in that
+ * replicate, 0 where the pair was not observed: `merge(x, temp, all.x = TRUE); x[is.na(N), N := 0]` (:850-853).
+ * With `out` the column is written in place (one n x S fragment matrix for chicdiff_hip_window_sums). */
+SEXP chicdiff_hip_count_join(SEXP ctx, SEXP ru_bait, SEXP ru_oe, SEXP table, SEXP out, SEXP column) {
+    if (TYPEOF(table) != VECSXP || LENGTH(table) < 3) Rf_error("chicdiff_hip_count_join: table must come from chicdiff_hip_chinput_table");
+    const R_xlen_t nru = TYPEOF(ru_bait) == EXTPTRSXP ? devbuf_of(ru_bait, INTSXP, -1, "ru_bait")->len : XLENGTH(ru_bait);
+    const R_xlen_t nkeys = (R_xlen_t)Rf_asReal(VECTOR_ELT(table, 2));
+    devbuf *k = devbuf_of(VECTOR_ELT(table, 0), REALSXP, -1, "table$keys"), *v = devbuf_of(VECTOR_ELT(table, 1), INTSXP, -1, "table$vals");
+    if (nkeys < 0 || nkeys > k->len || nkeys > v->len) Rf_error("chicdiff_hip_count_join: table$nkeys does not fit the table");
+    SEXP dB = as_device(ctx, ru_bait, INTSXP, nru, "ru_bait"), dO = as_device(ctx, ru_oe, INTSXP, nru, "ru_oe");
+    SEXP res;
+    int32_t *dst;
+    if (Rf_isNull(out)) {
+        res = devbuf_new(ctx, INTSXP, nru);
+        dst = (int32_t *)dptr(res);
+    } else {
+        const R_xlen_t col = (R_xlen_t)Rf_asReal(column);
+        devbuf *o = devbuf_of(out, INTSXP, -1, "out");
+        if (col < 0 || (col + 1) * nru > o->len) Rf_error("chicdiff_hip_count_join: column outside `out`");
+        res = PROTECT(out);
+        dst = (int32_t *)o->d + col * nru;
+    }
+    check_rc(ctx, chicdiff_hip_count_join_dev(ctx_of(ctx), (const int32_t *)dptr(dB), (const int32_t *)dptr(dO), (int64_t)nru, (const int64_t *)k->d,
+                                              (const int32_t *)v->d, (int64_t)nkeys, dst),
+             "chicdiff_hip_count_join");
+    release_if_temp(dB, ru_bait);
+    release_if_temp(dO, ru_oe);
+    UNPROTECT(3);
+    return res;
+}
+
+/* ---- a3: Bmean / Tmean / FullMean of every RU row and replicate, chicdiff.R:628-703, 894-896 ------------------------------ */
+/* .Call(chicdiff_hip_fragment_background, ctx, ru_bait, ru_oe, id_min, midsum (double nid: start + end of fragment
+ *       id_min + k), s_j, s_i (double nid x S, NA = absent), tblb, tlb (integer nid x S, NA = absent), Tmean (double
+ *       ntlb x ntblb x S, NA = combination absent), distfun (double 10 x S: cubicFit[1:4], head.coef, tail.coef,
+ *       obs.min, obs.max of .chicEstimateDistFun), S)
+ * -> list(Bmean, Tmean, FullMean): device double nru x S.  Reading the Chicago objects, the by-bait / by-other-end
+ * first values and the lm() refit of the distance function stay R (r/R/DESeq2Wrap_hip.R: .hipBackgroundTables). */
+SEXP chicdiff_hip_fragment_background(SEXP ctx, SEXP ru_bait, SEXP ru_oe, SEXP id_min, SEXP midsum, SEXP sj, SEXP si, SEXP tblb, SEXP tlb,
+                                      SEXP Tmean, SEXP distfun, SEXP nsamples) {
+    const int S = Rf_asInteger(nsamples);
+    if (S < 1 || !Rf_isReal(midsum) || !Rf_isReal(sj) || !Rf_isReal(si) || !Rf_isInteger(tblb) || !Rf_isInteger(tlb) || !Rf_isReal(Tmean) ||
+        !Rf_isReal(distfun) || LENGTH(distfun) != 10 * S)
+        Rf_error("chicdiff_hip_fragment_background: bad arguments");
+    const R_xlen_t nid = XLENGTH(midsum);
+    if (XLENGTH(sj) != nid * S || XLENGTH(si) != nid * S || XLENGTH(tblb) != nid * S || XLENGTH(tlb) != nid * S)
+        Rf_error("chicdiff_hip_fragment_background: the per-fragment tables must be nid x S");
+    SEXP dims = Rf_getAttrib(Tmean, R_DimSymbol);
+    if (Rf_isNull(dims) || LENGTH(dims) != 3 || INTEGER(dims)[2] != S) Rf_error("chicdiff_hip_fragment_background: Tmean must be ntlb x ntblb x S");
+    const int ntlb = INTEGER(dims)[0], ntblb = INTEGER(dims)[1];
+    const R_xlen_t nru = TYPEOF(ru_bait) == EXTPTRSXP ? devbuf_of(ru_bait, INTSXP, -1, "ru_bait")->len : XLENGTH(ru_bait);
+    chicdiff_hip_ctx *c = ctx_of(ctx);
+    int np = 0;
+    /* R's NA_integer_ bin codes become -1, the 1-based codes 0-based; start + end goes over as int64 */
+    int32_t *hb = (int32_t *)R_alloc((size_t)(nid * S), 4), *hl = (int32_t *)R_alloc((size_t)(nid * S), 4);
+    for (R_xlen_t i = 0; i < nid * S; i++) {
+        const int b = INTEGER(tblb)[i], l = INTEGER(tlb)[i];
+        if ((b != NA_INTEGER && (b < 1 || b > ntblb)) || (l != NA_INTEGER && (l < 1 || l > ntlb)))
+            Rf_error("chicdiff_hip_fragment_background: bin code outside the Tmean table");
+        hb[i] = b == NA_INTEGER ? -1 : b - 1;
+        hl[i] = l == NA_INTEGER ? -1 : l - 1;
+    }
+    int64_t *hm = (int64_t *)R_alloc((size_t)nid, 8);
+    for (R_xlen_t i = 0; i < nid; i++) hm[i] = ISNAN(REAL(midsum)[i]) ? 0 : (int64_t)REAL(midsum)[i];
+    SEXP dB = as_device(ctx, ru_bait, INTSXP, nru, "ru_bait"); np++;
+    SEXP dO = as_device(ctx, ru_oe, INTSXP, nru, "ru_oe"); np++;
+    SEXP dM = devbuf_new(ctx, REALSXP, nid); np++;
+    SEXP dTb = devbuf_new(ctx, INTSXP, nid * S); np++;
+    SEXP dTl = devbuf_new(ctx, INTSXP, nid * S); np++;
+    check_rc(ctx, chicdiff_hip_memcpy_h2d(c, dptr(dM), hm, 8 * (uint64_t)nid), "chicdiff_hip_fragment_background");
+    check_rc(ctx, chicdiff_hip_memcpy_h2d(c, dptr(dTb), hb, 4 * (uint64_t)(nid * S)), "chicdiff_hip_fragment_background");
+    check_rc(ctx, chicdiff_hip_memcpy_h2d(c, dptr(dTl), hl, 4 * (uint64_t)(nid * S)), "chicdiff_hip_fragment_background");
+    SEXP dSj = as_device(ctx, sj, REALSXP, nid * S, "s_j"); np++;
+    SEXP dSi = as_device(ctx, si, REALSXP, nid * S, "s_i"); np++;
+    /* the library's table is [S][ntblb][ntlb] with tlb fastest: R's ntlb x ntblb x S array has exactly that layout */
+    SEXP dT = as_device(ctx, Tmean, REALSXP, (R_xlen_t)ntlb * ntblb * S, "Tmean"); np++;
+    static const char *names[] = {"Bmean", "Tmean", "FullMean"};
+    SEXP out = PROTECT(named_list(3, names)); np++;
+    SEXP res[3];
+    for (int k = 0; k < 3; k++) {
+        res[k] = devbuf_new(ctx, REALSXP, nru * S); np++;
+        SET_VECTOR_ELT(out, k, res[k]);
+    }
+    /* distfun arrives 10 x S column-major = [S][10] row-major, the layout the library reads */
+    check_rc(ctx, chicdiff_hip_fragment_background_dev(c, (const int32_t *)dptr(dB), (const int32_t *)dptr(dO), (int64_t)nru, Rf_asInteger(id_min),
+                                                       (int32_t)nid, (const int64_t *)dptr(dM), S, (const double *)dptr(dSj), (const double *)dptr(dSi),
+                                                       (const int32_t *)dptr(dTb), (const int32_t *)dptr(dTl), (const double *)dptr(dT), ntblb, ntlb,
+                                                       REAL(distfun), (double *)dptr(res[0]), (double *)dptr(res[1]), (double *)dptr(res[2])),
+                 "chicdiff_hip_fragment_background");
+    release_if_temp(dB, ru_bait);
+    release_if_temp(dO, ru_oe);
+    devbuf_finalizer(dM); devbuf_finalizer(dTb); devbuf_finalizer(dTl);
+    release_if_temp(dSj, sj);
+    release_if_temp(dSi, si);
+    release_if_temp(dT, Tmean);
+    UNPROTECT(np);
+    return out;
+}
+
 static const R_CallMethodDef call_methods[] = {{"chicdiff_hip_open", (DL_FUNC)&chicdiff_hip_open, 1},
                                                {"chicdiff_hip_close", (DL_FUNC)&chicdiff_hip_close, 1},
                                                {"chicdiff_hip_upload", (DL_FUNC)&chicdiff_hip_upload, 2},
+                                               {"chicdiff_hip_alloc", (DL_FUNC)&chicdiff_hip_alloc, 3},
                                                {"chicdiff_hip_download", (DL_FUNC)&chicdiff_hip_download, 1},
                                                {"chicdiff_hip_release", (DL_FUNC)&chicdiff_hip_release, 1},
                                                {"chicdiff_hip_window_sums", (DL_FUNC)&chicdiff_hip_window_sums, 5},
@@ -489,6 +648,9 @@ static const R_CallMethodDef call_methods[] = {{"chicdiff_hip_open", (DL_FUNC)&c
                                                {"chicdiff_hip_padj", (DL_FUNC)&chicdiff_hip_padj, 4},
                                                {"chicdiff_hip_ihw_apply", (DL_FUNC)&chicdiff_hip_ihw_apply, 5},
                                                {"chicdiff_hip_region_universe", (DL_FUNC)&chicdiff_hip_region_universe, 5},
+                                               {"chicdiff_hip_chinput_table", (DL_FUNC)&chicdiff_hip_chinput_table, 3},
+                                               {"chicdiff_hip_count_join", (DL_FUNC)&chicdiff_hip_count_join, 6},
+                                               {"chicdiff_hip_fragment_background", (DL_FUNC)&chicdiff_hip_fragment_background, 12},
                                                {NULL, NULL, 0}};
 
 void R_init_chicdiffhip(DllInfo *dll) {

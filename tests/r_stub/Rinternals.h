@@ -16,7 +16,9 @@ typedef int Rboolean;
 #define EXTPTRSXP 22
 extern SEXP R_NilValue, R_NamesSymbol, R_DimSymbol;
 extern double R_NaReal;
+extern int R_NaInt;
 #define NA_REAL R_NaReal
+#define NA_INTEGER R_NaInt
 int TYPEOF(SEXP x);
 int LENGTH(SEXP x);
 R_xlen_t XLENGTH(SEXP x);
@@ -40,6 +42,9 @@ int Rf_length(SEXP x);
 Rboolean Rf_isInteger(SEXP x);
 Rboolean Rf_isReal(SEXP x);
 Rboolean Rf_isNull(SEXP x);
+Rboolean Rf_isString(SEXP x);
+SEXP STRING_ELT(SEXP x, R_xlen_t i);
+const char *CHAR(SEXP x);
 SEXP Rf_ScalarReal(double x);
 SEXP Rf_ScalarInteger(int x);
 SEXP R_MakeExternalPtr(void *p, SEXP tag, SEXP prot);

@@ -9,7 +9,8 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "r", "src", "chicdiff_hip_shim.c")
-RSRC = [os.path.join(ROOT, "r", "R", "DESeq2Wrap_hip.R"), os.path.join(ROOT, "tools", "make_golden.R")]
+RSRC = [os.path.join(ROOT, "r", "R", "DESeq2Wrap_hip.R"), os.path.join(ROOT, "tools", "make_golden.R"),
+        os.path.join(ROOT, "r", "R", "getFullRegionData_hip.R")]
 
 
 def test_shim_compiles_against_declaration_only_r_headers():
@@ -31,9 +32,10 @@ def _registered():
 
 
 def _calls(text):
-    """(.Call name, number of arguments after the name, PACKAGE excluded) for every .Call in an R source."""
+    """(.Call name, number of arguments after the name, PACKAGE excluded) for every .Call in an R source; .hipCall(name, ...)
+    is the wrapper that appends PACKAGE itself."""
     out = []
-    for m in re.finditer(r'\.Call\("(\w+)"', text):
+    for m in re.finditer(r'\.(?:hip)?Call\("(\w+)"', text):
         i, depth, nargs, in_str = m.end(), 1, 0, None
         while depth:
             ch = text[i]
@@ -51,6 +53,9 @@ def _calls(text):
             elif ch == "," and depth == 1:
                 nargs += 1
             i += 1
+        if text[m.start():].startswith(".hipCall"):
+            out.append((m.group(1), nargs))
+            continue
         assert "PACKAGE" in text[m.start():i]
         out.append((m.group(1), nargs - 1))  # the trailing PACKAGE = argument
     return out
@@ -58,7 +63,7 @@ def _calls(text):
 
 def test_every_dot_call_is_registered_with_matching_arity():
     reg = _registered()
-    assert len(reg) >= 14
+    assert len(reg) >= 18
     seen = set()
     for path in RSRC:
         if not os.path.exists(path):
@@ -68,7 +73,8 @@ def test_every_dot_call_is_registered_with_matching_arity():
             assert reg[name] == nargs, (path, name, nargs, reg[name])
             seen.add(name)
     for must in ("chicdiff_hip_open", "chicdiff_hip_window_sums", "chicdiff_hip_size_factors", "chicdiff_hip_theta_grid",
-                 "chicdiff_hip_wald_test", "chicdiff_hip_fit", "chicdiff_hip_release"):
+                 "chicdiff_hip_wald_test", "chicdiff_hip_fit", "chicdiff_hip_release", "chicdiff_hip_chinput_table",
+                 "chicdiff_hip_count_join", "chicdiff_hip_fragment_background", "chicdiff_hip_alloc"):
         assert must in seen, must
 
 
@@ -81,7 +87,8 @@ def test_shim_uses_only_declared_library_entry_points():
     assert used and used <= declared, used - declared
     for must in ("chicdiff_hip_window_sums_dev", "chicdiff_hip_size_factors_dev", "chicdiff_hip_offsets_dev", "chicdiff_hip_theta_grid_dev",
                  "chicdiff_hip_wald_test_dev", "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_cooks_filter_dev",
-                 "chicdiff_hip_independent_filtering_dev"):
+                 "chicdiff_hip_independent_filtering_dev", "chicdiff_hip_chinput_read", "chicdiff_hip_chinput_table_dev",
+                 "chicdiff_hip_count_join_dev", "chicdiff_hip_fragment_background_dev"):
         assert must in used, must
 
 
