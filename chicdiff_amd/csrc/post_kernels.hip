@@ -356,40 +356,58 @@ void launch_cooks_filter(const int32_t *counts, int64_t n, int S, int p, const d
 constexpr int kIfN = 50;      // quantile cutoffs (DESeq2: theta <- seq(lower, upper, length = 50))
 constexpr int kIfBlock = 1024;
 
-__global__ __launch_bounds__(256) void if_keys_kernel(const double *__restrict__ bm, int64_t n, uint64_t *keys, unsigned long long *nzero) {
+// Independent filtering (DESeq2 pvalueAdjustment): what the kernels hand to each other.  One sort of baseMean (the
+// 50 quantile cutoffs), one sort of the p-values; the 50 filtered BH rejection counts and the final adjustment are
+// ranks inside that one p-order.  The host looks once in between, for the 50-point lowess that picks the filter.
+struct IfState {
+    unsigned long long nzero, count;  // rows with baseMean == 0; rows with a p-value
+    unsigned int total[kIfN];         // rows passing filter f (and holding a p-value)
+    unsigned int numRej[kIfN];        // BH rejections at level alpha among them
+    double cut[kIfN];                 // quantile(baseMean, theta[f])
+    chicdiff_results_info info;       // theta[] only (the rest is filled in on the host)
+};
+
+__global__ __launch_bounds__(256) void if_keys_kernel(const double *__restrict__ bm, int64_t n, uint64_t *keys, IfState *st) {
     unsigned int mine = 0;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const double x = bm[i];
         keys[i] = x != x ? ~0ull : key_of(x);
         mine += x == 0.0 ? 1u : 0u;
     }
-    if (mine) atomicAdd(nzero, (unsigned long long)mine);
+    if (mine) atomicAdd(&st->nzero, (unsigned long long)mine);
 }
-// order statistics lo/hi of the 50 quantiles (R quantile type 7 interpolates between them on the host)
-__global__ void if_gather_kernel(const uint64_t *__restrict__ sorted, const int64_t *__restrict__ idx, int m, double *out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < m) out[k] = value_of(sorted[idx[k]]);
+// lower = mean(baseMean == 0); theta = seq(lower, upper, length = 50); cutoffs = quantile(baseMean, theta), type 7
+__global__ void if_cuts_kernel(const uint64_t *__restrict__ sorted, int64_t n, double alpha, IfState *st) {
+    const int k = threadIdx.x;
+    if (k >= kIfN) return;
+    const double lower = (double)st->nzero / (double)n, upper = lower < 0.95 ? 0.95 : 1.0;
+    const double theta = lower + (double)k * ((upper - lower) / (double)(kIfN - 1));
+    const double h = (double)(n - 1) * theta;
+    const int64_t lo = (int64_t)floor(h), hi = lo + 1 < n ? lo + 1 : n - 1;
+    const double frac = h - (double)lo, xlo = value_of(sorted[lo]), xhi = value_of(sorted[hi]);
+    st->cut[k] = xlo + frac * (xhi - xlo);
+    st->info.theta[k] = k == kIfN - 1 ? upper : theta;
 }
-struct IfCuts { double c[kIfN]; };
 // T = number of cutoffs <= baseMean (cutoffs ascending): the row passes the filters 0 .. T-1
-__device__ __forceinline__ int if_T(double bm, const IfCuts &cu) {
+__device__ __forceinline__ int if_T(double bm, const double *cut) {
     int lo = 0, hi = kIfN;  // first cutoff > bm
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (cu.c[mid] <= bm) lo = mid + 1; else hi = mid;
+        if (cut[mid] <= bm) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
 // pass 1 over the p-sorted rows: per block and filter, how many rows pass (and have a p-value)
 __global__ __launch_bounds__(kIfBlock) void if_count_kernel(const uint32_t *__restrict__ idx, const double *__restrict__ bm, int64_t n,
-                                                             const unsigned long long *nvalid, IfCuts cu, uint8_t *T, uint32_t *blockcnt,
-                                                             int nblocks) {
+                                                             const IfState *st, uint8_t *T, uint32_t *blockcnt, int nblocks) {
     __shared__ unsigned int h[kIfN + 1];
+    __shared__ double s_cut[kIfN];
     if (threadIdx.x <= kIfN) h[threadIdx.x] = 0;
+    if (threadIdx.x < kIfN) s_cut[threadIdx.x] = st->cut[threadIdx.x];
     __syncthreads();
     const int64_t k = (int64_t)blockIdx.x * kIfBlock + threadIdx.x;
     int t = 0;
-    if (k < n && (unsigned long long)k < *nvalid) t = if_T(bm[idx[k]], cu);
+    if (k < n && (unsigned long long)k < st->count) t = if_T(bm[idx[k]], s_cut);
     if (k < n) T[k] = (uint8_t)t;
     atomicAdd(&h[t], 1u);
     __syncthreads();
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(kIfBlock) void if_count_kernel(const uint32_t *__re
     }
 }
 // exclusive scan over the blocks, one workgroup per filter; total[f] = rows passing filter f
-__global__ __launch_bounds__(1024) void if_scan_kernel(uint32_t *blockcnt, int nblocks, uint32_t *total) {
+__global__ __launch_bounds__(1024) void if_scan_kernel(uint32_t *blockcnt, int nblocks, IfState *st) {
     __shared__ unsigned int part[1024];
     uint32_t *c = blockcnt + (size_t)blockIdx.x * nblocks;
     const int per = (nblocks + 1023) / 1024, b0 = threadIdx.x * per;
@@ -420,39 +438,41 @@ __global__ __launch_bounds__(1024) void if_scan_kernel(uint32_t *blockcnt, int n
         c[b] = run;
         run += v;
     }
-    if (threadIdx.x == 1023) total[blockIdx.x] = part[1023];
+    if (threadIdx.x == 1023) st->total[blockIdx.x] = part[1023];
 }
-// pass 2: BH at level alpha rejects the hypotheses up to the largest filtered rank j with m/j * p_(j) < alpha
-// (DESeq2 counts padj < alpha): numRej[f] = that j
+// pass 2: BH at level alpha rejects the hypotheses up to the largest filtered rank r with m/r * p_(r) < alpha
+// (DESeq2 counts padj < alpha): numRej[f] = that r.  m/r >= 1, so only the rows with p < alpha can qualify: the
+// workgroups behind them in the p-order leave at once; the others first tabulate, per wave and filter, how many of
+// their rows pass, then every wave ranks its own rows (ballot + the waves before it) and reports its last qualifying
+// rank — no workgroup barrier inside the loop over the 50 filters.
 __global__ __launch_bounds__(kIfBlock) void if_rej_kernel(const uint64_t *__restrict__ pkeys, const uint8_t *__restrict__ T, int64_t n,
-                                                           const uint32_t *__restrict__ blockoff, const uint32_t *__restrict__ total,
-                                                           int nblocks, double alpha, unsigned int *numRej) {
-    __shared__ unsigned int wsum[kIfBlock / 64];
+                                                           const uint32_t *__restrict__ blockoff, int nblocks, double alpha, IfState *st) {
+    __shared__ unsigned int wcnt[kIfBlock / 64][kIfN];
     __shared__ unsigned int best[kIfN];
-    const int64_t k = (int64_t)blockIdx.x * kIfBlock + threadIdx.x;
+    const int64_t k0 = (int64_t)blockIdx.x * kIfBlock;
+    if (pkeys[k0] >= key_of(alpha)) return;  // also true for the NA keys (all ones) at the end
+    if (threadIdx.x < kIfN) best[threadIdx.x] = 0;
+    const int64_t k = k0 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = k < n ? T[k] : 0;
     const double p = t > 0 ? value_of(pkeys[k]) : 0.0;
-    if (threadIdx.x < kIfN) best[threadIdx.x] = 0;
+    for (int f = 0; f < kIfN; f++) {
+        const unsigned long long bal = __ballot(t > f);
+        if (lane == 0) wcnt[wave][f] = (unsigned int)__popcll(bal);
+    }
     __syncthreads();
     for (int f = 0; f < kIfN; f++) {
-        const bool pass = t > f;
-        const unsigned long long bal = __ballot(pass);
-        if (lane == 0) wsum[wave] = (unsigned int)__popcll(bal);
-        __syncthreads();
-        unsigned int before = 0;
-        for (int w2 = 0; w2 < wave; w2++) before += wsum[w2];
-        if (pass) {
-            const unsigned int rank = blockoff[(size_t)f * nblocks + blockIdx.x] + before + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull)) + 1u;
-            if ((double)total[f] / (double)rank * p < alpha) atomicMax(&best[f], rank);
-        }
-        __syncthreads();
+        const unsigned long long bal = __ballot(t > f);
+        if (!bal) continue;
+        unsigned int before = blockoff[(size_t)f * nblocks + blockIdx.x];
+        for (int w2 = 0; w2 < wave; w2++) before += wcnt[w2][f];
+        const unsigned int rank = before + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull)) + 1u;
+        const bool ok = t > f && (double)st->total[f] / (double)rank * p < alpha;
+        const unsigned long long okb = __ballot(ok);
+        if (okb && lane == 63 - __clzll((long long)okb)) atomicMax(&best[f], rank);  // ranks ascend with the lane
     }
-    if (threadIdx.x < kIfN && best[threadIdx.x]) atomicMax(&numRej[threadIdx.x], best[threadIdx.x]);
-}
-__global__ __launch_bounds__(256) void if_mask_kernel(const double *__restrict__ bm, const double *__restrict__ p, int64_t n, double cutoff,
-                                                      double *out) {
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = bm[i] >= cutoff ? p[i] : NAN;
+    __syncthreads();
+    if (threadIdx.x < kIfN && best[threadIdx.x]) atomicMax(&st->numRej[threadIdx.x], best[threadIdx.x]);
 }
 
 // Cleveland's LOWESS as in R stats::lowess / clowess.c (x ascending), host side: 50 points
@@ -543,13 +563,36 @@ static void lowess_host(const double *x, const double *y, int n, double f, int n
     }
 }
 
+
+// padj = BH over the rows that pass the chosen filter, in the p-order already at hand: q = m / rank * p for a passing
+// row (rank among the passing rows), +Inf otherwise; a suffix minimum; scatter back (NaN for the filtered rows)
+__global__ __launch_bounds__(kIfBlock) void if_final_q_kernel(const uint64_t *__restrict__ pkeys, const uint8_t *__restrict__ T, int64_t n,
+                                                               const uint32_t *__restrict__ blockoff, int nblocks, const IfState *st, int j,
+                                                               double *q) {
+    __shared__ unsigned int wcnt[kIfBlock / 64];
+    const int64_t k = (int64_t)blockIdx.x * kIfBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool pass = k < n && T[k] > j;
+    const unsigned long long bal = __ballot(pass);
+    if (lane == 0) wcnt[wave] = (unsigned int)__popcll(bal);
+    __syncthreads();
+    unsigned int before = blockoff[(size_t)j * nblocks + blockIdx.x];
+    for (int w2 = 0; w2 < wave; w2++) before += wcnt[w2];
+    const unsigned int rank = before + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull)) + 1u;
+    if (k < n) q[k] = pass ? (double)st->total[j] / (double)rank * value_of(pkeys[k]) : INFINITY;
+}
+__global__ __launch_bounds__(256) void if_final_scatter_kernel(const double *__restrict__ smin, const uint32_t *__restrict__ idx,
+                                                               const uint8_t *__restrict__ T, int64_t n, int j, double *padj) {
+    for (int64_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) padj[idx[k]] = T[k] > j ? fmin(1.0, smin[k]) : NAN;
+}
+
 size_t if_workspace_bytes(int64_t n) {
     const int nblocks = (int)((n + kIfBlock - 1) / kIfBlock);
     size_t sort_tmp = 0;
     uint64_t *k = nullptr;
     (void)rocprim::radix_sort_keys(nullptr, sort_tmp, k, k, (size_t)n, 0, 64, (hipStream_t)0);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    return bh_workspace_bytes(n) + 2 * al(8 * (size_t)n) + al((size_t)n) + al(4 * (size_t)kIfN * nblocks) + al(sort_tmp) + 16 * 256 + al(8 * (size_t)n) + 256;
+    return bh_workspace_bytes(n) + 2 * al(8 * (size_t)n) + al((size_t)n) + al(4 * (size_t)kIfN * nblocks) + al(sort_tmp) + al(sizeof(IfState)) + 256;
 }
 
 // returns 0 ok.  info: filterThreshold, filterTheta, index (1-based), theta[50], numRej[50], lowess[50]
@@ -563,64 +606,41 @@ int run_independent_filtering(const double *d_bm, const double *d_p, int64_t n, 
     uint64_t *k1 = (uint64_t *)p; p += al(8 * (size_t)n);
     uint8_t *T = (uint8_t *)p; p += al((size_t)n);
     uint32_t *blockcnt = (uint32_t *)p; p += al(4 * (size_t)kIfN * nblocks);
-    unsigned long long *nzero = (unsigned long long *)p; p += 256;
-    int64_t *qidx = (int64_t *)p; p += 4 * 256;
-    double *qval = (double *)p; p += 4 * 256;
-    uint32_t *total = (uint32_t *)p; p += 256;
-    unsigned int *numRej = (unsigned int *)p; p += 256;
-    double *pmask = (double *)p; p += al(8 * (size_t)n);
+    IfState *state = (IfState *)p; p += al(sizeof(IfState));
     void *sort_tmp = p;
     size_t sort_bytes = 0;
     (void)rocprim::radix_sort_keys(nullptr, sort_bytes, k0, k1, (size_t)n, 0, 64, st);
     int g = (int)((n + 2047) / 2048);
     if (g < 1) g = 1;
     if (g > 2048) g = 2048;
+    if (hipMemsetAsync(state, 0, sizeof(IfState), st) != hipSuccess) return 1;
     // 1. lower = mean(baseMean == 0); cutoffs = quantile(baseMean, theta) (type 7)
-    if (hipMemsetAsync(nzero, 0, 8, st) != hipSuccess) return 1;
-    if_keys_kernel<<<g, 256, 0, st>>>(d_bm, n, k0, nzero);
+    if_keys_kernel<<<g, 256, 0, st>>>(d_bm, n, k0, state);
     if (rocprim::radix_sort_keys(sort_tmp, sort_bytes, k0, k1, (size_t)n, 0, 64, st) != hipSuccess) return 1;
-    unsigned long long h_nzero = 0;
-    if (hipMemcpyAsync(&h_nzero, nzero, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
-    const double lower = (double)h_nzero / (double)n, upper = lower < 0.95 ? 0.95 : 1.0;
-    int64_t h_qidx[2 * kIfN];
-    double frac[kIfN];
-    for (int k = 0; k < kIfN; k++) {
-        info->theta[k] = lower + (double)k * ((upper - lower) / (double)(kIfN - 1));  // seq(lower, upper, length = 50)
-        const double h = (double)(n - 1) * info->theta[k];
-        const int64_t lo = (int64_t)floor(h);
-        h_qidx[2 * k] = lo;
-        h_qidx[2 * k + 1] = lo + 1 < n ? lo + 1 : n - 1;
-        frac[k] = h - (double)lo;
-    }
-    info->theta[kIfN - 1] = upper;
-    double h_q[2 * kIfN];
-    if (hipMemcpyAsync(qidx, h_qidx, sizeof h_qidx, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
-    if_gather_kernel<<<1, 128, 0, st>>>(k1, qidx, 2 * kIfN, qval);
-    if (hipMemcpyAsync(h_q, qval, sizeof h_q, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
-    IfCuts cu;
-    for (int k = 0; k < kIfN; k++) cu.c[k] = h_q[2 * k] + frac[k] * (h_q[2 * k + 1] - h_q[2 * k]);
-    // 2. one sort by p-value (NA last) via the BH machinery's buffers, then the 50 filtered rejection counts
+    if_cuts_kernel<<<1, 64, 0, st>>>(k1, n, alpha, state);
+    // 2. one sort by p-value (NA last) in the BH machinery's buffers, then the 50 filtered rejection counts
     //    (bh_ws layout: count | k0 | k1 | i0 | i1 | q | s — see launch_bh_adjust)
-    unsigned long long *count = (unsigned long long *)bh_ws;
     uint64_t *pk0 = (uint64_t *)(bh_ws + 256), *pk1 = (uint64_t *)((char *)pk0 + al(8 * (size_t)n));
     uint32_t *pi0 = (uint32_t *)((char *)pk1 + al(8 * (size_t)n)), *pi1 = (uint32_t *)((char *)pi0 + al(4 * (size_t)n));
-    size_t psort = 0;
+    double *q = (double *)((char *)pi1 + al(4 * (size_t)n)), *s = (double *)((char *)q + al(8 * (size_t)n));
+    void *ptmp = (char *)s + al(8 * (size_t)n);
+    size_t psort = 0, pscan = 0;
     (void)rocprim::radix_sort_pairs(nullptr, psort, pk0, pk1, pi0, pi1, (size_t)n, 0, 64, st);
-    if (psort > bh_workspace_bytes(n)) return 1;
-    if (hipMemsetAsync(count, 0, 8, st) != hipSuccess) return 1;
-    bh_keys_kernel<<<g, 256, 0, st>>>(d_p, n, pk0, pi0, count);
-    void *ptmp = (char *)pi1 + al(4 * (size_t)n) + 2 * al(8 * (size_t)n);  // behind q and s
+    (void)rocprim::inclusive_scan(nullptr, pscan, rocprim::make_reverse_iterator(q + n), rocprim::make_reverse_iterator(s + n), (size_t)n,
+                                  rocprim::minimum<double>(), st);
+    bh_keys_kernel<<<g, 256, 0, st>>>(d_p, n, pk0, pi0, &state->count);
     if (rocprim::radix_sort_pairs(ptmp, psort, pk0, pk1, pi0, pi1, (size_t)n, 0, 64, st) != hipSuccess) return 1;
-    if (hipMemsetAsync(numRej, 0, sizeof(unsigned int) * kIfN, st) != hipSuccess) return 1;
-    if_count_kernel<<<nblocks, kIfBlock, 0, st>>>(pi1, d_bm, n, count, cu, T, blockcnt, nblocks);
-    if_scan_kernel<<<kIfN, 1024, 0, st>>>(blockcnt, nblocks, total);
-    if_rej_kernel<<<nblocks, kIfBlock, 0, st>>>(pk1, T, n, blockcnt, total, nblocks, alpha, numRej);
-    unsigned int h_rej[kIfN];
-    if (hipMemcpyAsync(h_rej, numRej, sizeof h_rej, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
-    // 3. lowess(numRej ~ theta, f = 1/5), threshold choice (DESeq2 pvalueAdjustment)
+    if_count_kernel<<<nblocks, kIfBlock, 0, st>>>(pi1, d_bm, n, state, T, blockcnt, nblocks);
+    if_scan_kernel<<<kIfN, 1024, 0, st>>>(blockcnt, nblocks, state);
+    if_rej_kernel<<<nblocks, kIfBlock, 0, st>>>(pk1, T, n, blockcnt, nblocks, alpha, state);
+    // 3. lowess(numRej ~ theta, f = 1/5), threshold choice (DESeq2 pvalueAdjustment): 50 points, on the host — the
+    //    one place the host looks at the device's numbers before the end
+    IfState h;
+    if (hipMemcpyAsync(&h, state, sizeof(IfState), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
     double maxRej = 0;
     for (int k = 0; k < kIfN; k++) {
-        info->numRej[k] = (double)h_rej[k];
+        info->theta[k] = h.info.theta[k];
+        info->numRej[k] = (double)h.numRej[k];
         maxRej = std::max(maxRej, info->numRej[k]);
     }
     lowess_host(info->theta, info->numRej, kIfN, 1.0 / 5.0, 3, 0.01 * (info->theta[kIfN - 1] - info->theta[0]), info->lowess);
@@ -641,12 +661,16 @@ int run_independent_filtering(const double *d_bm, const double *d_p, int64_t n, 
             if (info->numRej[k] > thresh) { j = k; break; }
     }
     info->index = j + 1;
-    info->filterThreshold = cu.c[j];
+    info->filterThreshold = h.cut[j];
     info->filterTheta = info->theta[j];
     info->alpha = alpha;
     // 4. padj = BH over the rows that pass the chosen filter
-    if_mask_kernel<<<g, 256, 0, st>>>(d_bm, d_p, n, cu.c[j], pmask);
-    return launch_bh_adjust(pmask, n, d_padj, bh_ws, st);
+    if_final_q_kernel<<<nblocks, kIfBlock, 0, st>>>(pk1, T, n, blockcnt, nblocks, state, j, q);
+    if (rocprim::inclusive_scan(ptmp, pscan, rocprim::make_reverse_iterator(q + n), rocprim::make_reverse_iterator(s + n), (size_t)n,
+                                rocprim::minimum<double>(), st) != hipSuccess)
+        return 1;
+    if_final_scatter_kernel<<<g, 256, 0, st>>>(s, pi1, T, n, j, d_padj);
+    return 0;
 }
 
 }  // namespace cd
