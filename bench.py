@@ -124,12 +124,15 @@ def theta_grid_time(ctx, torch, dk, dfm, S):
     sf = ctx.size_factors(dk)
     grid = [0.0, 0.25, 0.5, 0.75, 1.0]
     ctx.theta_grid(dk, dfm, sf, grid)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    dev = ctx.theta_grid(dk, dfm, sf, grid)
-    torch.cuda.synchronize()
-    del dev  # (all-zero rows of the synthetic matrix make every total deviance NA, as in the reference: sum() without na.rm)
-    return {"ms": round((time.perf_counter() - t0) * 1e3, 3), "thetas": len(grid)}
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dev = ctx.theta_grid(dk, dfm, sf, grid)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+        del dev  # (all-zero rows of the synthetic matrix make every total deviance NA, as in the reference: sum() without na.rm)
+    return {"ms": round(float(np.median(ts)), 3), "thetas": len(grid), "runs_ms": [round(t, 3) for t in ts]}
 
 
 def main():
