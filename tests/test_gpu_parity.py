@@ -1131,6 +1131,46 @@ def test_results_on_device(ctx, golden, oracle):
     assert nout == ref_n > 0 and np.array_equal(dpv.cpu().numpy(), ref_p, equal_nan=True)
 
 
+def test_independent_filtering_edge_cases(ctx):
+    """The one-sort pipeline of results() on inputs that stress its ranks: fewer rows than a workgroup, a single row,
+    no p-value at all, every p-value rejected (the p < alpha prefix is the whole table), none rejected, ties that
+    straddle wave and workgroup boundaries, rows without baseMean — against the numpy restatement the golden
+    table pins."""
+    import torch
+    import results_twin as results
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(ctx.device)
+    rng = np.random.default_rng(77)
+
+    def check(bm, p, what):
+        hp, hinfo = results.independent_filtering(bm, p)
+        dp, dinfo = ctx.independent_filtering(dev(bm), dev(p))
+        assert np.array_equal(dinfo["numRej"], hinfo["numRej"]), what
+        assert dinfo["index"] == hinfo["index"], what
+        assert np.allclose(dinfo["theta"], hinfo["theta"], rtol=1e-15, atol=1e-300), what
+        assert np.isclose(dinfo["filterThreshold"], hinfo["filterThreshold"], rtol=1e-15, equal_nan=True), what
+        assert np.allclose(dp.cpu().numpy(), hp, rtol=1e-13, equal_nan=True), what
+
+    for n in (1, 2, 7, 63, 64, 65, 1023, 1024, 1025, 4097):
+        bm = rng.lognormal(2.0, 1.0, n)
+        p = rng.uniform(size=n) ** 3
+        check(bm, p, f"n={n}")
+    n = 30000
+    bm = rng.lognormal(np.log(19), 1.4, n)
+    check(bm, np.full(n, np.nan), "no p-value")
+    check(bm, rng.uniform(0, 1e-9, n), "everything rejected")
+    check(bm, rng.uniform(0.5, 1.0, n), "nothing rejected")
+    check(bm, np.full(n, 1.0), "all p = 1")
+    p = rng.uniform(size=n) ** 4
+    p[:5000] = 1e-5                      # one tie group across many waves / workgroups of the p-order
+    p[5000:9000] = 0.03
+    check(bm, p, "long tie groups")
+    bm0 = bm.copy()
+    bm0[rng.uniform(size=n) < 0.4] = 0.0  # lower = mean(baseMean == 0) moves the theta grid
+    check(bm0, p, "many zero baseMeans")
+    bm1 = np.full(n, 7.0)                # every cutoff equal: every row passes every filter
+    check(bm1, p, "constant baseMean")
+
+
 def test_fit_fuzz_shapes_and_designs(ctx, oracle):
     """Random sample counts, group splits and row counts (both designs) against the oracle: every configuration must
     agree on the NA pattern and on >= 99 % of the rows to 1e-6 (small n makes single noise-decided rows visible)."""
