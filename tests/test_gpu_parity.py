@@ -1258,6 +1258,127 @@ def test_chinput_ingestion_on_device(ctx, oracle, tmp_path):
     assert np.array_equal(got, oracle.count_join(qb, qo, rk, rv)) and (got > 0).sum() > 1000 and (got == 0).sum() > 1000
 
 
+def test_pipeline_from_peaks_and_chinput_text_to_weighted_padj(ctx, oracle, golden, tmp_path):
+    """Every row of SURVEY.md §8 in one chain, nothing but file names and small tables crossing the host boundary:
+    peaks -> region universe (f4) -> per replicate: .chinput text -> key table (f2) -> count join (a1);
+    Chicago tables -> Bmean / Tmean / FullMean per fragment (a3) -> window sums (a2) -> size factors, sc(theta),
+    dispersions, Wald test (a4-a7, one call) -> Cook's cutoff, independent filtering, BH (a9) -> IHW application (f3);
+    against the oracle run link by link on the same inputs (integers bit-exact, the rest to 1e-6)."""
+    import torch
+    from scipy import stats
+    import results_twin as results
+    from post_inputs import ihw_tables_from_golden, region_universe_case
+    from test_chinput import write_chinput
+    rng = np.random.default_rng(2026)
+    S, RUexpand = 8, 5
+    group = synth.groups(S)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(ctx.device)
+    # f4: peaks on the reference's chr19 HindIII geometry -> RU rows in (regionID, otherEndID) order
+    pb, po, chr_of = region_universe_case(seed=11, n=6000)
+    ru = ctx.region_universe(t(pb), t(po), RUexpand, t(chr_of))
+    ptr_ref, rb_ref, rr_ref, ro_ref = oracle.region_universe(pb, po, RUexpand, chr_of)
+    ru_bait, ru_oe = ru["baitID"].cpu().numpy(), ru["otherEndID"].cpu().numpy()
+    assert np.array_equal(ru["region_ptr"].cpu().numpy(), ptr_ref) and np.array_equal(ru_bait, rb_ref) and np.array_equal(ru_oe, ro_ref)
+    n, nru = len(pb), len(ru_bait)
+    region_of = rr_ref.astype(np.int64) - 1
+    # the experiment: one mean / dispersion / fold change per region, shared out over its fragments; a fragment pair
+    # has ONE count per replicate however many windows hold it
+    pair = (ru_bait.astype(np.int64) << 32) | ru_oe
+    upair, first = np.unique(pair, return_index=True)
+    mu = rng.lognormal(np.log(6.0), 1.0, n)[region_of[first]]
+    alpha = (0.05 + 1.0 / mu) * rng.lognormal(0, 0.3, len(upair))
+    lfc = np.where(rng.uniform(size=n) < 0.15, rng.normal(0, 1.5, n), 0.0)[region_of[first]]
+    depth = rng.lognormal(0, 0.2, S)
+    files, flags = [], np.zeros(int(chr_of.shape[0]), np.uint8)
+    flags[np.unique(ru_bait)] = 1
+    N_ref = np.zeros((nru, S), dtype=np.int32)
+    fragN = torch.empty((S, nru), dtype=torch.int32, device=ctx.device)
+    for s in range(S):
+        m = mu * depth[s] * 2.0 ** (lfc * group[s])
+        k = rng.negative_binomial(1.0 / alpha, 1.0 / (1.0 + alpha * m)).astype(np.int32)
+        seen = k > 0                                              # chinput holds observed pairs only
+        ob, oo = rng.integers(1, len(chr_of), 20000).astype(np.int64), rng.integers(1, len(chr_of), 20000).astype(np.int64)
+        other = np.setdiff1d((ob << 32) | oo, upair)              # reads of pairs outside RU (incl. non-RU baits)
+        kb = np.concatenate([upair[seen] >> 32, other >> 32]).astype(np.int32)
+        ko = np.concatenate([upair[seen] & 0xFFFFFFFF, other & 0xFFFFFFFF]).astype(np.int32)
+        kn = np.concatenate([k[seen], rng.integers(1, 30, len(other)).astype(np.int32)])
+        shuffle = rng.permutation(len(kb))
+        path = tmp_path / f"rep{s}.chinput"
+        write_chinput(path, kb[shuffle], ko[shuffle], kn[shuffle])
+        keys, vals, nrows = ctx.read_chinput(path, t(flags))       # f2
+        fragN[s] = ctx.count_join(ru["baitID"], ru["otherEndID"], keys, vals)   # a1
+        rk, rv = oracle.count_table(kb[shuffle], ko[shuffle], kn[shuffle], flags)
+        assert np.array_equal(keys.cpu().numpy(), rk) and np.array_equal(vals.cpu().numpy(), rv)
+        N_ref[:, s] = oracle.count_join(ru_bait, ru_oe, rk, rv)
+        assert np.array_equal(N_ref[:, s], k[np.searchsorted(upair, pair)])
+    assert np.array_equal(fragN.cpu().numpy().T, N_ref)
+    # a3: Chicago tables (per replicate) on the same geometry
+    rmap = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chr19_HindIII_first3000.rmap"), dtype=str)
+    nid = len(chr_of) - 1
+    midsum = np.zeros(nid, dtype=np.int64)
+    midsum[: len(rmap)] = rmap[:, 1].astype(np.int64) + rmap[:, 2].astype(np.int64)   # IDs renumbered 1..3000 in file order
+    baits_all = np.unique(ru_bait)
+    sj = np.full((S, nid), np.nan)
+    sj[:, baits_all - 1] = np.exp(rng.normal(0, 0.3, (S, len(baits_all))))
+    sj[:, baits_all[::23] - 1] = np.nan                         # baits Chicago filtered out: FullMean NA -> size-factor rows
+    si = np.where(rng.random((S, nid)) < 0.8, np.exp(rng.normal(0, 0.3, (S, nid))), np.nan)
+    ntblb, ntlb = 5, 6
+    tblb = np.full((S, nid), -1, dtype=np.int32)
+    tblb[:, baits_all - 1] = rng.integers(0, ntblb, (S, len(baits_all)))
+    tlb = np.where(rng.random((S, nid)) < 0.85, rng.integers(0, ntlb, (S, nid)), -1).astype(np.int32)
+    T = np.exp(rng.normal(-3, 0.5, (S, ntblb, ntlb)))
+    distfun = np.zeros((S, 10))
+    for s in range(S):
+        fit = np.array([14.0 + 0.1 * s, -1.6, 0.05, -0.003])
+        x = np.array([np.log(10000.0), np.log(1.5e6)])
+        beta = fit[1] + 2 * fit[2] * x + 3 * fit[3] * x ** 2
+        al = fit[0] + (fit[1] - beta) * x + fit[2] * x ** 2 + fit[3] * x ** 3
+        distfun[s] = [*fit, al[0], beta[0], al[1], beta[1], x[0], x[1]]
+    a3 = dict(bait=ru_bait, oe=ru_oe, id_min=1, midsum=midsum, sj=sj, si=si, tblb=tblb, tlb=tlb, T=T, distfun=distfun)
+    _, _, fragFM = ctx.fragment_background(ru["baitID"], ru["otherEndID"], 1, t(midsum), t(sj), t(si), t(tblb), t(tlb), t(T), distfun)
+    _, _, FM_frag_ref = oracle.fragment_background(**a3)
+    assert np.allclose(fragFM.cpu().numpy(), FM_frag_ref, rtol=1e-13, equal_nan=True)
+    # a2: window sums
+    dN, dFM = ctx.window_sums(fragN, fragFM, ru["region_ptr"])
+    N_w, FM_w = oracle.window_sums(N_ref, FM_frag_ref.T, ptr_ref)
+    assert np.array_equal(dN.cpu().numpy().T, N_w)
+    assert np.allclose(dFM.cpu().numpy().T, FM_w, rtol=1e-13, equal_nan=True) and np.isnan(FM_w).any()
+    # a4-a7 in one call, then a9
+    theta = 0.5
+    want = ["baseMean", "log2FoldChange", "lfcSE", "stat", "pvalue", "maxCooks", "cooksArgmax"]
+    out, sc = ctx.wald_test(dN, dFM, group, theta=theta, want=want)
+    sf = oracle.size_factors(N_w)
+    ref = oracle.nbglm_fit(N_w, oracle.offsets(FM_w, sf, theta), group)
+    assert np.allclose(sc["sizeFactors"], sf, rtol=1e-12)
+    cutoff = stats.f.ppf(0.99, 2, S - 2)
+    ctx.cooks_filter(dN, group, out["maxCooks"], out["cooksArgmax"], out["pvalue"], cutoff)
+    p_ref, _ = results.cooks_filter(ref["pvalue"], ref["maxCooks"], ref["cooksArgmax"], lambda idx: N_w[idx], group, cutoff=cutoff)
+    d_padj, info = ctx.independent_filtering(out["baseMean"], out["pvalue"])
+    padj_ref, info_ref = results.independent_filtering(ref["baseMean"], p_ref)
+    got_p, got_padj = out["pvalue"].cpu().numpy(), d_padj.cpu().numpy()
+    assert np.array_equal(np.isnan(got_p), np.isnan(p_ref))
+    live = (ref["allZero"] == 0) & (ref["betaConv"] == 1)
+    check_close("pipeline log2FoldChange", out["log2FoldChange"].cpu().numpy(), ref["log2FoldChange"], live & (np.abs(ref["log2FoldChange"]) > 1e-2),
+                1e-6, frac=0.998, noise_rows=3)
+    check_close("pipeline pvalue", got_p, p_ref, live & ~np.isnan(p_ref), 1e-6, frac=0.998, noise_rows=3)
+    # the filter choice is a discrete decision on 50 rejection counts: when it agrees (it does unless a noise-decided
+    # row sits exactly on a rank boundary) padj follows p
+    assert abs(info["index"] - info_ref["index"]) <= 1
+    if info["index"] == info_ref["index"]:
+        assert np.array_equal(np.isnan(got_padj), np.isnan(padj_ref))
+        check_close("pipeline padj", got_padj, padj_ref, ~np.isnan(padj_ref), 1e-6, frac=0.998, noise_rows=3)
+    # f3: IHW application with the reference's trained weight table
+    breaks, avWeights = ihw_tables_from_golden(golden)
+    avDist = ((midsum[po.astype(np.int64).clip(1, nid) - 1] - midsum[pb.astype(np.int64) - 1]) / 2.0).astype(np.float64)
+    avDist[avDist == 0] = 1.0
+    w = ctx.ihw_apply(t(avDist), out["pvalue"], breaks, avWeights)
+    g_ref, w_ref, wp_ref, wpadj_ref = oracle.ihw_apply(avDist, got_p, breaks, avWeights)
+    assert np.array_equal(w["group"].cpu().numpy(), g_ref)
+    assert np.allclose(w["weighted_padj"].cpu().numpy(), wpadj_ref, rtol=1e-12, equal_nan=True)
+    print(f"pipeline: {n} peaks, {nru} RU rows, {S} chinput files; filter index {info['index']} (oracle {info_ref['index']}), "
+          f"padj < 0.05: {int(np.nansum(got_padj < 0.05))} (oracle {int(np.nansum(padj_ref < 0.05))})")
+
+
 def test_full_size_C5_20M_x16_pipeline_properties_and_slice_parity(ctx, oracle):
     """BASELINE.json configs[4] on one GPU: 20 M interactions x 16 samples (8 v 8) through the composed path — size factors
     -> sc(theta) -> dispersions -> Wald test (one call) -> results(): Cook's cutoff + independent filtering + BH -> the
