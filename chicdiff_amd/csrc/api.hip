@@ -385,7 +385,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     takeD(w.baseMean); takeD(w.baseVar); takeD(w.gm0); takeD(w.gm1); takeD(w.rough); takeD(w.binit0); takeD(w.binit1);
     takeD(w.crow); takeD(w.dispGene); takeD(w.dispFit); takeD(w.dispMAP); takeD(w.disp); takeD(w.beta0); takeD(w.beta1);
     takeD(w.resid);
-    takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter); takeI(w.optimConv); takeI(w.optimList);
+    takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter); takeI(w.optimConv);
     w.partials = (double *)p; p += partials;
     w.hist = (double *)p; p += hist;
     w.hist_local = (double *)p; p += hist;
@@ -656,10 +656,6 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         {
             Scope t(c, "wald_irls");
             launch_wald_irls(d_counts, d_nf, d, w, o, st);
-        }
-        {
-            Scope t(c, "wald_optim");
-            launch_wald_optim(d_counts, d_nf, d, w, o, st);
         }
         Scope t(c, "wald_final");
         launch_wald_final(d_counts, d_nf, d, w, o, out, st);

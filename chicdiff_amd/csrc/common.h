@@ -22,7 +22,6 @@ struct FitWork {
     double *baseMean, *baseVar, *gm0, *gm1, *rough, *binit0, *binit1, *crow;
     double *dispGene, *dispFit, *dispMAP, *disp, *beta0, *beta1, *resid;
     int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter, *optimConv;
-    int32_t *optimList;           // rows the IRLS left for the optim fallback (count in queue[16])
     double *partials;             // kRedBlocks x 72 doubles
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
     double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut
@@ -61,7 +60,6 @@ void launch_resid_hist(FitDims d, FitWork w, double *out40, hipStream_t st);  //
 void launch_prior_mc(FitDims d, FitWork w, const double *hist40, const void *table, hipStream_t st);  // simulation-matched prior variance
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
-void launch_wald_optim(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                        const chicdiff_nbglm_out &out, hipStream_t st);
 void launch_wald_intercept(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,

@@ -9,7 +9,7 @@
 //                                   NB log-likelihood (log y! from a table), so that an IRLS tick
 //                                   needs one log1p and one reciprocal per sample, no log(mu), no 1/mu;
 //   wald_irls   (row per lane + queue refill, as disp_fit_kernel) : IRLS ticks;
-//   wald_optim  (row per thread) : the few rows the IRLS left unconverged (DESeq2: optim fallback);
+//                 the few rows it leaves unconverged go through the optim fallback on the spot (optim_row);
 //   wald_final  (row per thread) : sandwich SE, stat, p (Cody), deviance, hat diagonals -> max
 //                                   Cook's distance (trimmed cell variances by rank counting in LDS).
 #include "common.h"
@@ -55,6 +55,65 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
 }
 
 
+// Fallback for rows whose IRLS diverged or ran out of iterations.  DESeq2 hands them to
+// optim(L-BFGS-B, bounds +-30) on the log2-scale negative log posterior (fitNbinomGLMsOptim); what is
+// reproduced here is that optimiser's target — the posterior mode inside the box — by damped Fisher
+// scoring with backtracking on the same objective, started from the least-squares start values.
+// A handful of rows per million (single extreme count outliers): the lane that holds the row in the IRLS kernel
+// does it on the spot (the row is in its LDS column; the wave's other lanes wait the few tens of microseconds).
+// counts / offsets of the row are read as y[j * stride], f[j * stride] (global memory, or the LDS copy below)
+__device__ __forceinline__ double optim_objective(const int32_t *y_, const double *f_, int64_t stride, int S, uint64_t gmask,
+                                                  double alpha, double size, double la, double crow, double lam, double b0,
+                                                  double b1) {
+    double f = 0.5 * lam * (b0 * b0 + b1 * b1) - crow;
+    const double E0 = exp(b0), E1 = exp(b0 + b1);
+    for (int j = 0; j < S; j++) {
+        const double y = (double)y_[j * stride];
+        const double mu = f_[j * stride] * (((gmask >> j) & 1) ? E1 : E0);
+        const double ma = alpha * mu, t = 1.0 + ma;
+        f += (size + y) * flog1p_from(ma, t, rcp(t));
+        if (y > 0) f -= y * (la + flog(mu));
+    }
+    return f;
+}
+// returns true when the mode was reached (DESeq2: optim's convergence code 0)
+__device__ __noinline__ bool optim_row(const int32_t *y_, const double *f_, int64_t stride, int S, uint64_t gmask, double alpha, double crow,
+                                       double &b0, double &b1) {
+    const double lam = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
+    const double bound = 30.0 * 0.69314718055994530942;
+    const double size = rcp(alpha), la = flog(alpha);
+    double f = optim_objective(y_, f_, stride, S, gmask, alpha, size, la, crow, lam, b0, b1);
+    bool converged = false;
+    for (int it = 0; it < 200 && !converged; it++) {
+        double g0 = lam * b0, g1 = lam * b1, wA = 0, wB = 0;
+        const double E0 = exp(b0), E1 = exp(b0 + b1);
+        for (int j = 0; j < S; j++) {
+            const bool g = (gmask >> j) & 1;
+            const double y = (double)y_[j * stride];
+            const double mu = f_[j * stride] * (g ? E1 : E0);
+            const double rt = rcp(fma(alpha, mu, 1.0));
+            const double sc = (y - mu) * rt, wj = mu * rt;
+            g0 -= sc;
+            if (g) { g1 -= sc; wB += wj; } else wA += wj;
+        }
+        const double m00 = wA + wB + lam, m01 = wB, m11 = wB + lam, det = m00 * m11 - m01 * m01;
+        const double d0 = -(m11 * g0 - m01 * g1) / det, d1 = -(m00 * g1 - m01 * g0) / det;
+        double t = 1.0;
+        bool moved = false;
+        for (int h = 0; h < 40; h++, t *= 0.5) {
+            const double n0 = fmin(fmax(b0 + t * d0, -bound), bound), n1 = fmin(fmax(b1 + t * d1, -bound), bound);
+            const double fn = optim_objective(y_, f_, stride, S, gmask, alpha, size, la, crow, lam, n0, n1);
+            if (fn < f) {
+                if (f - fn < 1e-13 * (fabs(f) + 1.0)) converged = true;
+                b0 = n0; b1 = n1; f = fn; moved = true;
+                break;
+            }
+        }
+        if (!moved) converged = true;
+    }
+    return converged;
+}
+
 struct WaldArgs {
     const int32_t *counts;
     const double *nf;
@@ -66,7 +125,7 @@ struct WaldArgs {
 
 // IRLS.  Tick k evaluates at beta_k: deviance(beta_k) for the convergence test and the
 // weighted sums that give beta_{k+1}.  DESeq2's loop index t equals k-1.
-__global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
+__global__ __launch_bounds__(256, 4) void wald_irls_kernel(WaldArgs A) {
     extern __shared__ double smem[];
     __shared__ LogEntry s_logtab[64];
     log_table_to_lds(s_logtab);
@@ -206,10 +265,15 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
                 }
             }
             if (stop) {
+                if (iter_out >= o.betaMaxit) {
+                    // fitNbinomGLMsOptim: start again from the least-squares start values, keep the optimum whatever happens
+                    b0 = A.w.binit0[row];
+                    b1 = A.w.binit1[row];
+                    A.w.optimConv[row] = optim_row(s_y + lane, s_nf + lane, 64, S, gmask, alpha, A.w.crow[row], b0, b1) ? 1 : 0;
+                }
                 A.w.beta0[row] = b0;
                 A.w.beta1[row] = b1;
                 A.w.betaIter[row] = iter_out;
-                if (iter_out >= o.betaMaxit) A.w.optimList[atomicAdd(A.w.queue + 16, 1ull)] = (int32_t)row;  // rows for the optim fallback (rare)
                 need = true;
             }
         }
@@ -221,99 +285,6 @@ __global__ __launch_bounds__(256) void wald_irls_kernel(WaldArgs A) {
 // 1.21 against 0.83 ms at S = 16.  The kernel is issue-bound at ~6.6 cycles per wave instruction like the line
 // searches; what idles half its lanes is the end of each wave's allotment — a third of the waves carry one row that
 // needs 20-100 ticks — not the refill, and refilling on every tick only adds instructions.)
-
-// Fallback for rows whose IRLS diverged or ran out of iterations.  DESeq2 hands them to
-// optim(L-BFGS-B, bounds +-30) on the log2-scale negative log posterior (fitNbinomGLMsOptim); what is
-// reproduced here is that optimiser's target — the posterior mode inside the box — by damped Fisher
-// scoring with backtracking on the same objective, started from the least-squares start values.
-// A handful of rows per million (single extreme count outliers): one thread per row is plenty.
-// counts / offsets of the row are read as y[j * stride], f[j * stride] (global memory, or the LDS copy below)
-__device__ __forceinline__ double optim_objective(const int32_t *y_, const double *f_, int64_t stride, int S, uint64_t gmask,
-                                                  double alpha, double size, double la, double crow, double lam, double b0,
-                                                  double b1) {
-    double f = 0.5 * lam * (b0 * b0 + b1 * b1) - crow;
-    const double E0 = exp(b0), E1 = exp(b0 + b1);
-    for (int j = 0; j < S; j++) {
-        const double y = (double)y_[j * stride];
-        const double mu = f_[j * stride] * (((gmask >> j) & 1) ? E1 : E0);
-        const double ma = alpha * mu, t = 1.0 + ma;
-        f += (size + y) * flog1p_from(ma, t, rcp(t));
-        if (y > 0) f -= y * (la + flog(mu));
-    }
-    return f;
-}
-__global__ __launch_bounds__(256) void wald_optim_kernel(const int32_t *__restrict__ counts, const double *__restrict__ nf,
-                                                         FitDims d, FitWork w, Opts o, int lds_rows) {
-    const int64_t n = d.n;
-    const int S = d.S;
-    const double lam = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
-    const double bound = 30.0 * 0.69314718055994530942;
-    const int64_t todo = (int64_t)w.queue[16];  // rows the IRLS listed (a few per million): the others need nothing here
-    // the few hundred serial objective evaluations of a fallback row read the row from LDS, not from L2
-    extern __shared__ double s_optim[];  // [S][256] offsets, then [S][256] counts (empty when S is too large)
-    const bool in_lds = lds_rows != 0;
-    double *s_f = s_optim + threadIdx.x;
-    int32_t *s_y = reinterpret_cast<int32_t *>(s_optim + (size_t)S * 256) + threadIdx.x;
-    for (int64_t t = blockIdx.x * 256 + threadIdx.x; t < todo; t += (int64_t)gridDim.x * 256) {
-        const int64_t i = w.optimList[t];
-        int flag = -1;  // not attempted
-        if (!w.allZero[i] && !(w.betaIter[i] < o.betaMaxit)) {
-            const double alpha = w.disp[i], size = rcp(alpha), la = flog(alpha), crow = w.crow[i];
-            const int32_t *y_ = counts + i;
-            const double *f_ = nf + i;
-            int64_t stride = n;
-            if (in_lds) {
-                for (int j = 0; j < S; j++) {
-                    s_f[j * 256] = nf[(int64_t)j * n + i];
-                    s_y[j * 256] = counts[(int64_t)j * n + i];
-                }
-                y_ = s_y;
-                f_ = s_f;
-                stride = 256;
-            }
-            double b0 = w.binit0[i], b1 = w.binit1[i];
-            double f = optim_objective(y_, f_, stride, S, d.gmask, alpha, size, la, crow, lam, b0, b1);
-            bool converged = false;
-            for (int it = 0; it < 200 && !converged; it++) {
-                double g0 = lam * b0, g1 = lam * b1, wA = 0, wB = 0;
-                const double E0 = exp(b0), E1 = exp(b0 + b1);
-                for (int j = 0; j < S; j++) {
-                    const bool g = (d.gmask >> j) & 1;
-                    const double y = (double)y_[j * stride];
-                    const double mu = f_[j * stride] * (g ? E1 : E0);
-                    const double rt = rcp(fma(alpha, mu, 1.0));
-                    const double sc = (y - mu) * rt, wj = mu * rt;
-                    g0 -= sc;
-                    if (g) { g1 -= sc; wB += wj; } else wA += wj;
-                }
-                const double m00 = wA + wB + lam, m01 = wB, m11 = wB + lam, det = m00 * m11 - m01 * m01;
-                const double d0 = -(m11 * g0 - m01 * g1) / det, d1 = -(m00 * g1 - m01 * g0) / det;
-                double t = 1.0;
-                bool moved = false;
-                for (int h = 0; h < 40; h++, t *= 0.5) {
-                    const double n0 = fmin(fmax(b0 + t * d0, -bound), bound), n1 = fmin(fmax(b1 + t * d1, -bound), bound);
-                    const double fn = optim_objective(y_, f_, stride, S, d.gmask, alpha, size, la, crow, lam, n0, n1);
-                    if (fn < f) {
-                        if (f - fn < 1e-13 * (fabs(f) + 1.0)) converged = true;
-                        b0 = n0; b1 = n1; f = fn; moved = true;
-                        break;
-                    }
-                }
-                if (!moved) converged = true;
-            }
-            w.beta0[i] = b0;
-            w.beta1[i] = b1;
-            flag = converged ? 1 : 0;
-        }
-        w.optimConv[i] = flag;
-    }
-}
-void launch_wald_optim(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
-    const size_t lds = (size_t)d.S * 256 * 12;
-    const int lds_rows = lds <= 48 * 1024;
-    // the rows to do are a device-side list (count in queue[16], normally a few per million): a small grid walks it
-    wald_optim_kernel<<<64, 256, lds_rows ? lds : 0, st>>>(counts, nf, d, w, o, lds_rows);
-}
 
 __device__ __forceinline__ int trim_lo(int n) {
     // trimratio c(1/3, 1/4, 1/8) on bins (0,3.5], (3.5,23.5], (23.5,Inf)
