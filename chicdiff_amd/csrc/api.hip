@@ -48,6 +48,15 @@ struct chicdiff_hip_ctx {
     size_t io_dev_bytes = 0, io_pin_bytes = 0;
     int opt_host_threads = 12;              // host threads that move caller buffers to / from the pinned staging area
     ChinputCols *chin = nullptr;            // columns of the .chinput file read last (chicdiff_hip_chinput_read)
+    // host-buffer entry point: columns that are final once the MAP dispersions exist leave for the host on a second
+    // stream while the Wald stage runs (set for the duration of one chicdiff_hip_nbglm_fit call)
+    struct EarlyCopy {
+        int n = 0;
+        struct Item { int col; char *pin; size_t bytes; } item[10];  // col: 0 baseMean 1 baseVar 2 dispGeneEst 3 dispFit 4 dispMAP 5 dispersion 6 dispGeneIter 7 dispIter 8 dispOutlier 9 allZero
+        hipEvent_t ready = nullptr, done = nullptr;
+        bool issued = false;
+    } *early = nullptr;
+    hipStream_t copy_stream = nullptr;
     std::vector<chicdiff_hip_ctx *> lanes;  // theta grid: child contexts (own stream + workspace), one per concurrent fit
     int opt_grid_lanes = 5;                 // theta grid: fits in flight at once (1 = one after the other)
     int cu_count = 0;  // compute units of the device (the persistent trend kernel needs one resident workgroup per CU it launches)
@@ -200,6 +209,7 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     if (c->h_sc) (void)hipHostFree(c->h_sc);
     if (c->h_sf) (void)hipHostFree(c->h_sf);
     if (c->rccl_comm && c->rccl_comm_destroy) (void)c->rccl_comm_destroy(c->rccl_comm);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -646,6 +656,15 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         Scope t(c, "disp_map");
         launch_disp_map(d_counts, d_nf, d, w, o, st);
     }
+    if (c->early && c->early->n > 0) {  // these columns are final: off to the host while the Wald stage runs
+        const void *src[10] = {w.baseMean, w.baseVar, w.dispGene, w.dispFit, w.dispMAP, w.disp, w.geneIter, w.mapIter, w.outlier, w.allZero};
+        HIPCHK(c, hipEventRecord(c->early->ready, st));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->early->ready, 0));
+        for (int k = 0; k < c->early->n; k++)
+            HIPCHK(c, hipMemcpyAsync(c->early->item[k].pin, src[c->early->item[k].col], c->early->item[k].bytes, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->early->done, c->copy_stream));
+        c->early->issued = true;
+    }
     static const chicdiff_nbglm_out none{};
     const chicdiff_nbglm_out &out = d_out ? *d_out : none;
     if (d.p == 2) {
@@ -816,34 +835,53 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const dou
         }
         if (trc[t]) return fail(c, CHICDIFF_E_HIP, "H2D copy failed");
     }
-    rc = chicdiff_hip_nbglm_fit_dev(c, d_counts, d_nf, n, S, group, opts, &dout, scalars);  // ends with a stream sync: the staging area is free again
-    if (rc) return rc;
-
-    // ---- D2H: one DMA per column into the staging area, host threads copy out as the columns land ----
-    struct Col { void *host; const void *dev; char *pin; size_t bytes; hipEvent_t ev; };
+    // ---- D2H: one DMA per column into the staging area, host threads copy out as the columns land.  The ten columns
+    //      of the dispersion stage are final once the MAP estimates exist: they go over a second stream, straight from
+    //      the workspace, while the Wald stage still runs (fit_dev_impl issues them); the others follow the fit ----
+    struct Col { void *host; const void *dev; char *pin; size_t bytes; hipEvent_t ev; bool early; };
     std::vector<Col> cols;
+    chicdiff_hip_ctx::EarlyCopy early;
     char *pp = c->io_pin;
-    for (int k = 0; k < 14; k++) if (*hd[k]) { cols.push_back({*hd[k], *dd[k], pp, sizeof(double) * (size_t)n, nullptr}); pp += nd; }
-    for (int k = 0; k < 7; k++) if (*hi[k]) { cols.push_back({*hi[k], *di[k], pp, sizeof(int32_t) * (size_t)n, nullptr}); pp += nd; }
+    static const int early_of_d[14] = {0, 1, 2, 3, 4, 5, -1, -1, -1, -1, -1, -1, -1, -1}, early_of_i[7] = {6, 7, 8, -1, -1, 9, -1};
+    for (int k = 0; k < 14; k++) if (*hd[k]) { cols.push_back({*hd[k], *dd[k], pp, sizeof(double) * (size_t)n, nullptr, early_of_d[k] >= 0}); if (early_of_d[k] >= 0) { early.item[early.n++] = {early_of_d[k], pp, sizeof(double) * (size_t)n}; *dd[k] = nullptr; } pp += nd; }
+    for (int k = 0; k < 7; k++) if (*hi[k]) { cols.push_back({*hi[k], *di[k], pp, sizeof(int32_t) * (size_t)n, nullptr, early_of_i[k] >= 0}); if (early_of_i[k] >= 0) { early.item[early.n++] = {early_of_i[k], pp, sizeof(int32_t) * (size_t)n}; *di[k] = nullptr; } pp += nd; }
     hipError_t e = hipSuccess;
+    if (early.n > 0) {
+        if (!c->copy_stream) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&early.ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&early.done, hipEventDisableTiming);
+        if (e != hipSuccess) return fail(c, CHICDIFF_E_HIP, "D2H setup: %s", hipGetErrorString(e));
+        c->early = &early;
+    }
+    rc = chicdiff_hip_nbglm_fit_dev(c, d_counts, d_nf, n, S, group, opts, &dout, scalars);  // ends with a sync of the fit's stream
+    c->early = nullptr;
+    auto cleanup = [&]() {
+        if (early.issued) (void)hipStreamSynchronize(c->copy_stream);  // the staging area must be quiet before it is reused
+        if (early.ready) (void)hipEventDestroy(early.ready);
+        if (early.done) (void)hipEventDestroy(early.done);
+    };
+    if (rc) { cleanup(); return rc; }
     for (auto &q : cols) {
+        if (q.early) continue;
         if (e == hipSuccess) e = hipEventCreateWithFlags(&q.ev, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMemcpyAsync(q.pin, q.dev, q.bytes, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipEventRecord(q.ev, c->stream);
     }
     if (e == hipSuccess && !cols.empty()) {
+        std::sort(cols.begin(), cols.end(), [](const Col &x, const Col &y) { return x.early > y.early; });  // those already on the host first
         int nt = c->opt_host_threads < (int)cols.size() ? c->opt_host_threads : (int)cols.size();
         std::vector<std::thread> th;
         for (int t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
                 for (size_t k = t; k < cols.size(); k += nt) {
-                    if (hipEventSynchronize(cols[k].ev) != hipSuccess) { trc[0] = 1; continue; }
+                    if (hipEventSynchronize(cols[k].early ? early.done : cols[k].ev) != hipSuccess) { trc[0] = 1; continue; }
                     memcpy(cols[k].host, cols[k].pin, cols[k].bytes);
                 }
             });
         for (auto &w : th) w.join();
     }
     for (auto &q : cols) if (q.ev) (void)hipEventDestroy(q.ev);
+    cleanup();
     if (e != hipSuccess || trc[0]) return fail(c, CHICDIFF_E_HIP, "D2H copy: %s", e != hipSuccess ? hipGetErrorString(e) : "event wait failed");
     return CHICDIFF_OK;
 }
