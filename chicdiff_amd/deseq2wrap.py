@@ -112,7 +112,11 @@ def DESeq2Wrap(chicdiff_settings, RU, FullRegionData, suffix="", theta=None, ctx
         ctx = hip.HipContext(0)
     torch = ctx.torch
     try:
-        samples, conds, fragN, fragFM, region_ptr = _dense_fragments(FullRegionData)
+        from .post import HipRegionData
+        if isinstance(FullRegionData, HipRegionData):  # the device-resident block of post.getFullRegionDataHip
+            samples, conds, region_ptr = FullRegionData["samples"], FullRegionData["condition"], None
+        else:
+            samples, conds, fragN, fragFM, region_ptr = _dense_fragments(FullRegionData)
         S = len(samples)
         levels = sorted(set(conds))  # character -> factor: alphabetical levels, first = reference (A0)
         if len(levels) != 2:
@@ -120,8 +124,11 @@ def DESeq2Wrap(chicdiff_settings, RU, FullRegionData, suffix="", theta=None, ctx
         group = np.array([levels.index(c) for c in conds], dtype=np.int32)
 
         # window sums (a2) -> counts and FullMean matrices, resident in HBM from here on
-        d_N, d_FM = ctx.window_sums(ctx.to_device(fragN, np.int32), ctx.to_device(fragFM, np.float64),
-                                    torch.as_tensor(region_ptr).to(ctx.device))
+        if region_ptr is None:
+            d_N, d_FM = ctx.window_sums(FullRegionData["fragN"], FullRegionData["fragFullMean"], FullRegionData["region_ptr"])
+        else:
+            d_N, d_FM = ctx.window_sums(ctx.to_device(fragN, np.int32), ctx.to_device(fragFM, np.float64),
+                                        torch.as_tensor(region_ptr).to(ctx.device))
         n = d_N.shape[1]
         null_sf = ctx.size_factors(d_N)  # estimateSizeFactors (a5)
 

@@ -7,7 +7,12 @@
   on the control set (training stays reference R): breaks from ``distLookup``, group cut, weight lookup and
   renormalisation, weighted p-values and their BH adjustment.
 
-Both keep their arrays on the GPU; no CPU fallback (the HIP library raises when it is missing).
+* ``getFullRegionDataHip`` — the chinput branch of ``getFullRegionData1`` (chicdiff.R:577-945) without the long
+  "recast" table: per replicate chinput text -> key table -> count join into one column of the fragment matrix;
+  per-fragment Chicago tables -> Bmean + Tmean = FullMean per RU row and replicate.  Returns the device-resident
+  block ``DESeq2Wrap`` takes in place of ``FullRegionData`` (tested twin of r/R/getFullRegionData_hip.R).
+
+All keep their arrays on the GPU; no CPU fallback (the HIP library raises when it is missing).
 """
 from __future__ import annotations
 
@@ -56,3 +61,43 @@ def applyIHWweights(ctx, avDist, pvalue, minLogDist, maxLogDist, avWeights):
     torch = ctx.torch
     dev = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(ctx.device)
     return ctx.ihw_apply(dev(avDist), dev(pvalue), ihw_breaks(minLogDist, maxLogDist), avWeights)
+
+
+class HipRegionData(dict):
+    """Device-resident fragment block: ``samples, condition, S, n, fragN (S, nfrag) int32, fragFullMean (S, nfrag)
+    float64, region_ptr (n + 1) int64`` — what r/R/getFullRegionData_hip.R calls a chicdiffHipRegionData object."""
+
+
+def getFullRegionDataHip(ctx, RU, chinput_files, condition, background):
+    """``RU``: dict / DataFrame with baitID, regionID (1..n), otherEndID; ``chinput_files``: one .chinput path per
+    replicate (chicdiff.R:811-831), ``condition``: one label per replicate (:921-923); ``background``: the dense
+    per-fragment tables of the Chicago data sets over IDs id_min .. id_min + nid - 1 —
+    ``id_min, midsum (nid,), sj, si (S, nid), tblb, tlb (S, nid; -1 = NA), T (S, ntblb, ntlb), distfun (S, 10)``
+    (what .hipBackgroundTables builds in R from ``x@x`` and ``.chicEstimateDistFun``)."""
+    torch = ctx.torch
+    S = len(chinput_files)
+    assert len(condition) == S
+    bait = np.asarray(RU["baitID"], dtype=np.int32)
+    region = np.asarray(RU["regionID"], dtype=np.int64)
+    oe = np.asarray(RU["otherEndID"], dtype=np.int32)
+    order = np.lexsort((oe, region))                      # (regionID, otherEndID): a region's fragments are consecutive
+    bait, region, oe = bait[order], region[order], oe[order]
+    ids, starts = np.unique(region, return_index=True)
+    if not np.array_equal(ids, np.arange(1, len(ids) + 1)):
+        raise ValueError("RU: regionID must be 1..n without gaps")
+    nfrag, n = len(bait), len(ids)
+    dev = lambda a, t: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(ctx.device)
+    d_bait, d_oe = dev(bait, np.int32), dev(oe, np.int32)
+    flags = np.zeros(int(bait.max()) + 1, dtype=np.uint8)
+    flags[np.unique(bait)] = 1                            # baits <- sort(unique(RU$baitID)), chicdiff.R:775
+    d_flags = torch.from_numpy(flags).to(ctx.device)
+    fragN = torch.empty((S, nfrag), dtype=torch.int32, device=ctx.device)
+    for s, path in enumerate(chinput_files):
+        keys, vals, _ = ctx.read_chinput(path, d_flags)   # fread + x[J(baits)] + setkey(baitID, otherEndID)
+        fragN[s] = ctx.count_join(d_bait, d_oe, keys, vals)   # merge(all.x = TRUE); N[is.na(N)] <- 0
+    b = background
+    _, _, fragFM = ctx.fragment_background(d_bait, d_oe, int(b["id_min"]), dev(b["midsum"], np.int64), dev(b["sj"], np.float64),
+                                           dev(b["si"], np.float64), dev(b["tblb"], np.int32), dev(b["tlb"], np.int32),
+                                           dev(b["T"], np.float64), np.asarray(b["distfun"], dtype=np.float64))
+    return HipRegionData(samples=[str(p) for p in chinput_files], condition=list(condition), S=S, n=n, fragN=fragN,
+                         fragFullMean=fragFM, region_ptr=dev(np.concatenate([starts, [nfrag]]), np.int64))

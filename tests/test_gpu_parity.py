@@ -1275,6 +1275,8 @@ def test_pipeline_from_peaks_and_chinput_text_to_weighted_padj(ctx, oracle, gold
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(ctx.device)
     # f4: peaks on the reference's chr19 HindIII geometry -> RU rows in (regionID, otherEndID) order
     pb, po, chr_of = region_universe_case(seed=11, n=6000)
+    nonempty = np.diff(oracle.region_universe(pb, po, RUexpand, chr_of)[0]) > 0   # a peak whose window has no fragment on the
+    pb, po = pb[nonempty], po[nonempty]                                            # map / chromosome is not a region
     ru = ctx.region_universe(t(pb), t(po), RUexpand, t(chr_of))
     ptr_ref, rb_ref, rr_ref, ro_ref = oracle.region_universe(pb, po, RUexpand, chr_of)
     ru_bait, ru_oe = ru["baitID"].cpu().numpy(), ru["otherEndID"].cpu().numpy()
@@ -1375,6 +1377,25 @@ def test_pipeline_from_peaks_and_chinput_text_to_weighted_padj(ctx, oracle, gold
     g_ref, w_ref, wp_ref, wpadj_ref = oracle.ihw_apply(avDist, got_p, breaks, avWeights)
     assert np.array_equal(w["group"].cpu().numpy(), g_ref)
     assert np.allclose(w["weighted_padj"].cpu().numpy(), wpadj_ref, rtol=1e-12, equal_nan=True)
+    # the same through the host mirrors a caller uses: getFullRegionDataHip() -> DESeq2Wrap() (r/R/*.R's tested twins)
+    import pandas as pd
+    from chicdiff_amd import post
+    from chicdiff_amd.deseq2wrap import DESeq2Wrap
+    RU_df = pd.DataFrame({"baitID": ru_bait, "regionID": rr_ref, "otherEndID": ru_oe}).sample(frac=1.0, random_state=3)  # any row order
+    conds = ["ctrl" if g == 0 else "treat" for g in group]
+    frd = post.getFullRegionDataHip(ctx, RU_df, [tmp_path / f"rep{s}.chinput" for s in range(S)], conds, a3)
+    assert torch.equal(frd["fragN"], fragN) and torch.equal(frd["region_ptr"], ru["region_ptr"])
+    assert torch.allclose(frd["fragFullMean"], fragFM, rtol=0, atol=0, equal_nan=True)
+    rmapfile = tmp_path / "renumbered.rmap"
+    with open(rmapfile, "w") as f:
+        for k in range(len(rmap)):
+            f.write(f"chr{max(int(chr_of[k + 1]), 0) + 1}\t{rmap[k, 1]}\t{rmap[k, 2]}\t{k + 1}\n")
+    settings = {"norm": "combined", "theta": theta, "theta_grid": [0, 0.25, 0.5, 0.75, 1], "rmapfile": str(rmapfile),
+                "saveAuxData": False, "outprefix": str(tmp_path / "x")}
+    tab = DESeq2Wrap(settings, RU_df, frd, ctx=ctx)
+    assert np.array_equal(tab["regionID"].to_numpy(), np.arange(1, n + 1)) and tab.attrs["theta"] == theta
+    assert np.array_equal(tab["pvalue"].to_numpy(), got_p, equal_nan=True) and np.array_equal(tab["padj"].to_numpy(), got_padj, equal_nan=True)
+    assert np.array_equal(tab["baitID"].to_numpy(), pb) and np.array_equal(tab["minOE"].to_numpy(), ru["minOE"].cpu().numpy())
     print(f"pipeline: {n} peaks, {nru} RU rows, {S} chinput files; filter index {info['index']} (oracle {info_ref['index']}), "
           f"padj < 0.05: {int(np.nansum(got_padj < 0.05))} (oracle {int(np.nansum(padj_ref < 0.05))})")
 
