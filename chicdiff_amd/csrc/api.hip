@@ -43,6 +43,7 @@ struct chicdiff_hip_ctx {
     bool no_persistent_trend = false;  // set after a grid-barrier timeout (see fit_dev_impl)
     // tuning / test options (chicdiff_hip_set_option); the defaults are what the benchmarks run
     int opt_spread = 1, opt_min_waves = 2, opt_select_rounds = 0, opt_trend_multilaunch = 0;
+    int opt_no_local_substitute = 0;  // 1: a failed parametric trend is reported (CHICDIFF_ST_TREND_FAILED), not replaced by the local fit
     // host-buffer entry point: device arena + pinned staging, both grow-only (no allocation per call once warm)
     char *io_dev = nullptr, *io_pin = nullptr;
     size_t io_dev_bytes = 0, io_pin_bytes = 0;
@@ -144,6 +145,7 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     const std::string k(name);
     if (k == "line_search_spread" && (value == 0 || value == 1)) c->opt_spread = (int)value;
     else if (k == "line_search_min_waves" && value >= 2 && value <= 4) c->opt_min_waves = (int)value;
+    else if (k == "local_trend_substitute" && (value == 0 || value == 1)) c->opt_no_local_substitute = value ? 0 : 1;
     else if (k == "theta_grid_concurrency" && value >= 1 && value <= 16) c->opt_grid_lanes = (int)value;
     else if (k == "host_copy_threads" && value >= 1 && value <= 64) c->opt_host_threads = (int)value;
     else if (k == "select_all_rounds" && (value == 0 || value == 1)) c->opt_select_rounds = (int)value;
@@ -562,6 +564,113 @@ static Opts make_opts(const chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *in, 
     return r;
 }
 
+// ---- DESeq2 localDispersionFit on the device (global_kernels.hip lf_*): the host grows locfit's tree ----------------
+// One order statistic of key(x) or key(|x - xv|) over the rows of the fit: byte-wise radix select, eight histogram rounds
+// (each a sum over rows, all-reduced when sharded).  rank is 0-based; *total gets the number of rows (first round).
+static int lf_order_stat(chicdiff_hip_ctx *c, FitDims d, const Opts &o, int use_dist, double xv, double rank, double *value, double *total) {
+    double *d_hist = c->w.hist;
+    uint64_t prefix = 0;
+    double h[256];
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        launch_lf_hist(d, c->w, o, use_dist, xv, prefix, shift, d_hist, c->stream);
+        if (int rc = do_allreduce(c, d_hist, 256)) return rc;
+        HIPCHK(c, hipMemcpyAsync(h, d_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        double cum = 0;
+        if (shift == 56 && total) {
+            *total = 0;
+            for (int b = 0; b < 256; b++) *total += h[b];
+        }
+        int b = 0;
+        for (; b < 255; b++) {
+            if (cum + h[b] > rank) break;
+            cum += h[b];
+        }
+        rank -= cum;
+        prefix |= (uint64_t)b << shift;
+    }
+    *value = value_of(prefix);
+    return CHICDIFF_OK;
+}
+// bandwidth, value and slope of the local quadratic at xv (locfit: nbhd / kordstat, tricube, Taylor basis 1, dx, dx^2/2)
+static int lf_vertex(chicdiff_hip_ctx *c, FitDims d, const Opts &o, double nfit, double xv, double *h, double *f, double *df) {
+    const double k = floor(nfit * 0.7);  // alpha = 0.7
+    if (k < 1) return CHICDIFF_E_NUMERIC;
+    int rc = lf_order_stat(c, d, o, 1, xv, k - 1, h, nullptr);
+    if (rc) return rc;
+    if (!(*h > 0)) return CHICDIFF_E_NUMERIC;
+    double *d_out = c->w.hist + 256, s[8];
+    launch_lf_sums(d, c->w, o, xv, *h, c->w.partials, d_out, c->stream);
+    if ((rc = do_allreduce(c, d_out, 8))) return rc;
+    HIPCHK(c, hipMemcpyAsync(s, d_out, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    long double A[3][4] = {{s[0], s[1], (long double)s[2] / 2, s[5]},
+                           {s[1], s[2], (long double)s[3] / 2, s[6]},
+                           {(long double)s[2] / 2, (long double)s[3] / 2, (long double)s[4] / 4, (long double)s[7] / 2}};
+    for (int col = 0; col < 3; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 3; r++)
+            if (fabsl(A[r][col]) > fabsl(A[piv][col])) piv = r;
+        if (!(fabsl(A[piv][col]) > 0)) return CHICDIFF_E_NUMERIC;
+        if (piv != col)
+            for (int q = 0; q < 4; q++) std::swap(A[col][q], A[piv][q]);
+        for (int r = col + 1; r < 3; r++) {
+            const long double m = A[r][col] / A[col][col];
+            for (int q = col; q < 4; q++) A[r][q] -= m * A[col][q];
+        }
+    }
+    long double b[3];
+    for (int r = 2; r >= 0; r--) {
+        long double t = A[r][3];
+        for (int q = r + 1; q < 3; q++) t -= A[r][q] * b[q];
+        b[r] = t / A[r][r];
+    }
+    *f = (double)b[0];
+    *df = (double)b[1];
+    return CHICDIFF_OK;
+}
+struct LfTree {
+    int nv = 0;
+    double x[kLfMaxV], h[kLfMaxV], f[kLfMaxV], d[kLfMaxV];
+};
+static int lf_add(chicdiff_hip_ctx *c, FitDims d, const Opts &o, double nfit, LfTree &t, double xv) {
+    if (t.nv >= kLfMaxV) return -1;
+    if (lf_vertex(c, d, o, nfit, xv, &t.h[t.nv], &t.f[t.nv], &t.d[t.nv])) return -1;
+    t.x[t.nv] = xv;
+    return t.nv++;
+}
+// locfit atree_grow in one dimension: cut the cell at its midpoint while its length exceeds cut = 0.8 bandwidths
+static bool lf_grow(chicdiff_hip_ctx *c, FitDims d, const Opts &o, double nfit, LfTree &t, int il, int ir, double range) {
+    const double le = t.x[ir] - t.x[il];
+    double hmin = t.h[il] > 0 ? t.h[il] : 0;
+    if (t.h[ir] > 0 && (hmin == 0 || t.h[ir] < hmin)) hmin = t.h[ir];
+    const double score = hmin == 0 ? 2 * le / range : le / hmin;
+    if (!(0.8 < score)) return true;
+    const int im = lf_add(c, d, o, nfit, t, (t.x[il] + t.x[ir]) / 2);
+    if (im < 0) return false;
+    return lf_grow(c, d, o, nfit, t, il, im, range) && lf_grow(c, d, o, nfit, t, im, ir, range);
+}
+// returns CHICDIFF_OK with dispFit[] filled and the trend marked local, or CHICDIFF_E_NUMERIC when no fit is possible
+static int local_trend_fit(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
+    double lo, hi, nfit = 0, dummy;
+    int rc = lf_order_stat(c, d, o, 0, 0.0, 0.0, &lo, &nfit);  // min(x) and the number of rows in the fit
+    if (rc) return rc;
+    if (nfit < 4) return CHICDIFF_E_NUMERIC;
+    if ((rc = lf_order_stat(c, d, o, 0, 0.0, nfit - 1, &hi, &dummy))) return rc;  // max(x)
+    if (!(hi > lo)) return CHICDIFF_E_NUMERIC;
+    LfTree t;
+    const int il = lf_add(c, d, o, nfit, t, lo), ir = il < 0 ? -1 : lf_add(c, d, o, nfit, t, hi);
+    if (il < 0 || ir < 0 || !lf_grow(c, d, o, nfit, t, il, ir, hi - lo)) return c->err[0] ? CHICDIFF_E_HIP : CHICDIFF_E_NUMERIC;
+    LfVerts v{};
+    std::vector<int> order(t.nv);
+    for (int i = 0; i < t.nv; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int p, int q) { return t.x[p] < t.x[q]; });
+    v.nv = t.nv;
+    for (int i = 0; i < t.nv; i++) { v.x[i] = t.x[order[i]]; v.f[i] = t.f[order[i]]; v.d[i] = t.d[order[i]]; }
+    launch_lf_eval(d, c->w, v, c->stream);
+    return CHICDIFF_OK;
+}
+
 static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const double *d_nf, FitDims d, Opts o,
                         const chicdiff_nbglm_out *d_out, chicdiff_nbglm_scalars *scalars) {
     int rc;
@@ -611,6 +720,18 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_trend_init(d, w, o, st);
         HIPCHK(c, hipMemcpyAsync(w.sc->coefs, coefs, sizeof coefs, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));
+    } else if (o.fit_type == 2) {
+        // fitType = "local": on request, or — from the re-entry at the end of this function — DESeq2's own substitute for
+        // a parametric fit that failed ("a local regression fit was automatically substituted")
+        Scope t(c, "trend_fit");
+        launch_trend_init(d, w, o, st);
+        rc = local_trend_fit(c, d, o);
+        if (rc == CHICDIFF_E_NUMERIC) {
+            const int32_t one = 1;  // no local fit either (fewer than four usable rows): report the trend as failed
+            HIPCHK(c, hipMemcpyAsync(&w.sc->failed, &one, sizeof one, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+        } else if (rc)
+            return rc;
     } else if (!c->allreduce && !c->no_persistent_trend && c->cu_count >= trend_persistent_blocks() && !c->opt_trend_multilaunch) {
         Scope t(c, "trend_fit");  // single rank: one persistent launch (LDS-resident rows, grid barrier per IRLS pass)
         launch_trend_persistent(d, w, o, st);  // no host round trip: `failed` comes back with the final scalars
@@ -706,7 +827,14 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         c->no_persistent_trend = true;
         return fit_dev_impl(c, d_counts, d_nf, d, o, d_out, scalars);
     }
+    if (c->h_sc->failed && o.fit_type == 0 && !(o.trendIn[0] == o.trendIn[0]) && !c->opt_no_local_substitute) {
+        // estimateDispersionsFit: the parametric fit failed -> fitType <- "local", and the fit is done again from the trend on
+        // (everything before it is recomputed too: a rare path, kept simple)
+        o.fit_type = 2;
+        return fit_dev_impl(c, d_counts, d_nf, d, o, d_out, scalars);
+    }
     if (c->h_sc->failed) status |= CHICDIFF_ST_TREND_FAILED;
+    if (c->h_sc->trend_local) status |= CHICDIFF_ST_TREND_LOCAL;
     if (scalars) {
         const FitScalars *s = c->h_sc;
         scalars->trendCoef[0] = s->coefs[0];
@@ -1047,6 +1175,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         chicdiff_hip_ctx *l = c->lanes[k];
         l->opt_spread = c->opt_spread;
         l->opt_min_waves = c->opt_min_waves;
+        l->opt_no_local_substitute = c->opt_no_local_substitute;
         l->opt_select_rounds = c->opt_select_rounds;
         l->opt_trend_multilaunch = c->opt_trend_multilaunch;
         l->no_persistent_trend = true;  // a grid barrier needs its workgroups co-resident: not guaranteed beside other fits

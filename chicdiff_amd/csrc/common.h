@@ -54,6 +54,11 @@ void launch_trend_init(FitDims d, FitWork w, Opts o, hipStream_t st);
 int trend_blocks();                                                       // grid of the trend pass = rows of 8 partial sums
 void launch_trend_pass(FitDims d, FitWork w, Opts o, hipStream_t st, bool fused_step);  // pass (+ reduce + step when single rank)
 void launch_trend_step(FitDims d, FitWork w, Opts o, hipStream_t st);   // fixed-order sum of the (all-reduced) partials + state machine step
+constexpr int kLfMaxV = 100;  // locfit's maxk
+struct LfVerts { int nv; int _pad; double x[kLfMaxV], f[kLfMaxV], d[kLfMaxV]; };  // vertices of the local trend, ascending x
+void launch_lf_hist(FitDims d, FitWork w, Opts o, int use_dist, double xv, uint64_t prefix, int shift, double *hist, hipStream_t st);
+void launch_lf_sums(FitDims d, FitWork w, Opts o, double xv, double h, double *partials, double *out8, hipStream_t st);
+void launch_lf_eval(FitDims d, FitWork w, const LfVerts &v, hipStream_t st);
 void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_resid_hist(FitDims d, FitWork w, double *out40, hipStream_t st);  // residual histogram for the d.f. <= 3 prior

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
             w.rough[i] = a0;
             w.resid[i] = log(a0);
         } else {
-            const double dg = w.dispGene[i], df = c0 + c1 / bm;
+            const double dg = w.dispGene[i], df = sc->trend_local ? w.dispFit[i] : c0 + c1 / bm;
             const double ldf = log(df);
             w.dispFit[i] = df;
             w.resid[i] = ldf;

@@ -35,7 +35,8 @@ struct FitScalars {
     double coefs[2];       // outer-loop coefficients (define the `good` set)
     double b[2];           // inner IRLS iterate
     double devold;
-    int32_t inner_it, outer_it, phase, finished, failed, conv, neg_counts /* a count < 0 (NA_integer_) was seen by prep */, _pad1;
+    int32_t inner_it, outer_it, phase, finished, failed, conv, neg_counts /* a count < 0 (NA_integer_) was seen by prep */,
+        trend_local /* dispFit[] holds the local-regression trend (DESeq2 fitType "local"): coefs are not used */;
     double nfit;
     // MAD / prior
     double med, mad, varLogDispEsts, dispPriorVar;

@@ -257,11 +257,12 @@ void launch_trend_step(FitDims, FitWork w, Opts, hipStream_t st) { trend_reduce_
 // residuals of log gene-wise estimates around the trend (rows with dispGeneEst >= 100*minDisp)
 __global__ __launch_bounds__(256) void resid_kernel(FitDims d, FitWork w, double minDisp) {
     const double c0 = w.sc->coefs[0], c1 = w.sc->coefs[1];
+    const bool local = w.sc->trend_local != 0;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
         double r = NAN;
         if (!w.allZero[i]) {
             const double y = w.dispGene[i];
-            if (y >= 100 * minDisp) r = log(y) - log(c0 + c1 / w.baseMean[i]);
+            if (y >= 100 * minDisp) r = log(y) - log(local ? w.dispFit[i] : c0 + c1 / w.baseMean[i]);
         }
         w.resid[i] = r;
     }
@@ -269,6 +270,100 @@ __global__ __launch_bounds__(256) void resid_kernel(FitDims d, FitWork w, double
 void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st) {
     resid_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp);
 }
+
+// ---- local-regression trend: DESeq2 localDispersionFit = locfit(log disp ~ log mean, weights = mean) with locfit's
+// defaults (alpha = 0.7 nearest-neighbour bandwidth, local quadratic, tricube kernel, rbox(cut = 0.8) tree, Hermite
+// interpolation) — DESeq2's own substitute when the parametric trend fails, or fitType = "local" on request.  A handful
+// of vertices (about ten), each needing one order statistic (the k-th smallest |x_i - x_v|: a byte-wise radix select,
+// eight histogram rounds) and eight weighted sums over the rows; the tree itself grows on the host (api.hip,
+// local_trend_fit).  Every statistic is a sum over rows, so the sharded path all-reduces it like the others.  Rare
+// path: clarity over speed.  Rows in the fit: dispGeneEst > 100 minDisp (useForFit), x = log baseMean.
+__device__ __forceinline__ bool lf_row(const FitWork &w, int64_t i, double minDisp, double &x) {
+    if (w.allZero[i] || !(w.dispGene[i] > 100 * minDisp)) return false;
+    x = log(w.baseMean[i]);
+    return true;
+}
+// hist[b] += rows whose key (of x, or of |x - xv|) agrees with `prefix` above bit shift + 8 and has byte b at `shift`
+__global__ __launch_bounds__(256) void lf_hist_kernel(FitDims d, FitWork w, double minDisp, int use_dist, double xv, uint64_t prefix, int shift,
+                                                      double *hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+        double x;
+        if (!lf_row(w, i, minDisp, x)) continue;
+        const uint64_t key = key_of(use_dist ? fabs(x - xv) : x);
+        if (shift < 56 && (key >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+        atomicAdd(&h[(key >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (double)h[threadIdx.x]);  // integer counts: exact in any order
+}
+// partial sums of w K(u) dx^q (q = 0..4) and w K(u) y dx^q (q = 0..2) per block; lf_sums_finish adds them in a fixed order
+__global__ __launch_bounds__(256) void lf_sums_kernel(FitDims d, FitWork w, double minDisp, double xv, double h, double *partials) {
+    __shared__ double red[256];
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+        double x;
+        if (!lf_row(w, i, minDisp, x)) continue;
+        const double dx = x - xv, u = fabs(dx) / h;
+        if (u >= 1.0) continue;
+        const double c = 1.0 - u * u * u, y = log(w.dispGene[i]);
+        double p = w.baseMean[i] * (c * c * c);
+        for (int q = 0; q < 5; q++) {
+            v[q] += p;
+            if (q < 3) v[5 + q] += p * y;
+            p *= dx;
+        }
+    }
+    for (int k = 0; k < 8; k++) {
+        red[threadIdx.x] = v[k];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 8 + k] = red[0];
+        __syncthreads();
+    }
+}
+__global__ void lf_sums_finish_kernel(const double *partials, int nblocks, double *out) {
+    const int k = threadIdx.x;
+    if (k >= 8) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; b++) s += partials[(size_t)b * 8 + k];
+    out[k] = s;
+}
+// dispFit = exp(predict(fit, log baseMean)) for every row with counts; marks the trend as local
+__global__ __launch_bounds__(256) void lf_eval_kernel(FitDims d, FitWork w, LfVerts v) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        w.sc->trend_local = 1;
+        w.sc->coefs[0] = w.sc->coefs[1] = NAN;
+        w.sc->failed = 0;
+        w.sc->finished = 1;
+    }
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+        if (w.allZero[i]) continue;
+        const double x = log(w.baseMean[i]);
+        int j = 0;
+        while (j + 2 < v.nv && x >= v.x[j + 1]) j++;  // the cell a descent with "left when x < midpoint" ends in
+        const double z = v.x[j + 1] - v.x[j], t = (x - v.x[j]) / z;
+        double p0, p1, p2, p3;  // locfit hermite2: cubic inside the cell, the end vertex's line outside the data range
+        if (t < 0) { p0 = 1; p1 = 0; p2 = t; p3 = 0; }
+        else if (t > 1) { p0 = 0; p1 = 1; p2 = 0; p3 = t - 1; }
+        else { p1 = t * t * (3 - 2 * t); p0 = 1 - p1; p2 = t * (1 - t) * (1 - t); p3 = t * t * (t - 1); }
+        w.dispFit[i] = exp(p0 * v.f[j] + p1 * v.f[j + 1] + (p2 * v.d[j] + p3 * v.d[j + 1]) * z);
+    }
+}
+void launch_lf_hist(FitDims d, FitWork w, Opts o, int use_dist, double xv, uint64_t prefix, int shift, double *hist, hipStream_t st) {
+    (void)hipMemsetAsync(hist, 0, sizeof(double) * 256, st);
+    lf_hist_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp, use_dist, xv, prefix, shift, hist);
+}
+void launch_lf_sums(FitDims d, FitWork w, Opts o, double xv, double h, double *partials, double *out8, hipStream_t st) {
+    lf_sums_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp, xv, h, partials);
+    lf_sums_finish_kernel<<<1, 64, 0, st>>>(partials, kRedBlocks, out8);
+}
+void launch_lf_eval(FitDims d, FitWork w, const LfVerts &v, hipStream_t st) { lf_eval_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, v); }
 
 // 40-bin histogram of the log dispersion residuals inside (-10, 10) (hist(breaks = -20:20/2) as hist.default counts
 // it, pmc_bin): input of the simulation-matched prior variance for residual d.f. <= 3 (prior_mc.h).  Counts as

@@ -160,14 +160,18 @@ def DESeq2Wrap(chicdiff_settings, RU, FullRegionData, suffix="", theta=None, ctx
             label = "combined normalisation"
 
         out, sc = ctx.nbglm_fit(d_N, d_nf, group, want=want)
+        if sc["status"] & hip.ST_TREND_LOCAL:
+            # DESeq2's own reaction to a failed parametric fit, and its message (estimateDispersionsFit)
+            message("-- note: fitType='parametric', but the dispersion trend was not well captured by the\n"
+                    "   function: y = a/x + b, and a local regression fit was automatically substituted.\n"
+                    "   specify fitType='local' or 'mean' to avoid this message next time.")
         if sc["status"] & hip.ST_TREND_FAILED:
-            # DESeq2 switches to fitType = "local" (locfit) here, which the library does not restate; its other
-            # documented alternative, fitType = "mean", is available on request (new optional setting)
+            # not even the local regression could be fitted (fewer than four rows with a usable dispersion estimate);
+            # DESeq2's other documented alternative, fitType = "mean", is available on request (new optional setting)
             if chicdiff_settings.get("trendFallback") != "mean":
-                raise RuntimeError('parametric dispersion trend failed; DESeq2 would fall back to a local fit: set '
+                raise RuntimeError('no dispersion trend could be fitted (parametric and local fits both failed): set '
                                    'chicdiff_settings["trendFallback"] = "mean" to refit with fitType = "mean"')
-            message("-- note: fitType='parametric', but the dispersion trend was not well captured by the function: "
-                    'y = a/x + b, and fitType = "mean" was substituted (DESeq2 itself would substitute a local regression fit).')
+            message('-- note: no dispersion trend could be fitted; fitType = "mean" was used instead.')
             out, sc = ctx.nbglm_fit(d_N, d_nf, group, want=want, opts=hip.default_opts(fitType=1))
 
         message("Processing model output")

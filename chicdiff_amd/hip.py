@@ -17,7 +17,7 @@ from .dist import ALLREDUCE_FN
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libchicdiff_hip.so")
 
-ST_TREND_FAILED, ST_PRIORVAR_MC, ST_BETA_NONCONV, ST_ALLZERO_ROWS = 1, 2, 4, 8
+ST_TREND_FAILED, ST_PRIORVAR_MC, ST_BETA_NONCONV, ST_ALLZERO_ROWS, ST_TREND_LOCAL = 1, 2, 4, 8, 16
 
 
 # every symbol include/chicdiff_hip.h declares (tests check the library exports each)

@@ -37,11 +37,15 @@ extern "C" {
 #define CHICDIFF_E_NUMERIC 5   /* e.g. every row has a zero (size factors undefined)          */
 
 /* status bits reported in chicdiff_nbglm_scalars.status (fit completed, with caveats) */
-#define CHICDIFF_ST_TREND_FAILED 1 /* parametric trend failed; DESeq2 would switch to fitType "local" (locfit, not restated):
-                                      the results use the coefficients reached — refit with opts.fitType = 1 ("mean") or supply trendCoef */
+#define CHICDIFF_ST_TREND_FAILED 1 /* no dispersion trend: the parametric fit failed and so did its substitute, the local regression
+                                      (fewer than four usable rows), or the substitution was switched off (option
+                                      local_trend_substitute = 0) — refit with opts.fitType = 1 ("mean") or supply trendCoef */
 #define CHICDIFF_ST_PRIORVAR_MC 2  /* m-p<=3 and no dispPriorVar given: matched by simulation as DESeq2 does it (its set.seed(2) stream, hist(), loess()) */
 #define CHICDIFF_ST_BETA_NONCONV 4 /* some rows hit betaMaxit (DESeq2 would call optim)        */
 #define CHICDIFF_ST_ALLZERO_ROWS 8 /* some rows are all zero: their outputs are NaN (R: NA)    */
+#define CHICDIFF_ST_TREND_LOCAL 16 /* dispFit is DESeq2's local-regression trend (localDispersionFit = locfit with its defaults): asked for
+                                      (fitType 2), or substituted for a failed parametric fit as estimateDispersionsFit does;
+                                      trendCoef is NaN */
 
 typedef struct chicdiff_hip_ctx chicdiff_hip_ctx;
 
@@ -68,7 +72,9 @@ int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, 
  *   "theta_grid_concurrency"    5 (default), 1 .. 16: fits of the theta grid in flight at once (single rank only)
  *   "host_copy_threads"         12 (default), 1 .. 64: host threads staging caller buffers in chicdiff_hip_nbglm_fit
  *   "select_all_rounds"         0 (default) | 1: exact medians by histogram rounds only (no candidate-sort shortcut)
- *   "trend_one_launch_per_pass" 0 (default) | 1: trend fit as one launch per IRLS pass instead of one persistent kernel */
+ *   "trend_one_launch_per_pass" 0 (default) | 1: trend fit as one launch per IRLS pass instead of one persistent kernel
+ * and one that does change the outcome of a fit whose parametric trend fails (DESeq2 offers the same choice through fitType):
+ *   "local_trend_substitute"    1 (default) | 0: report CHICDIFF_ST_TREND_FAILED instead of substituting the local regression */
 int chicdiff_hip_set_option(chicdiff_hip_ctx *ctx, const char *name, int64_t value);
 
 /* Direct RCCL (backend of choice on one node: RCCL over xGMI).  The library dlopen()s librccl (librccl_path, or
@@ -99,9 +105,11 @@ typedef struct {
     double outlierSD;    /* 2.0  */
     double dispPriorVar; /* NaN = estimate; DESeq2's estimateDispersionsMAP(dispPriorVar=) */
     double trendCoef[2]; /* NaN = fit; else use alpha(mu) = c0 + c1/mu as given (DESeq2: dispersionFunction<-) */
-    int32_t fitType;     /* 0 = "parametric" (DESeq2's and Chicdiff's default; a failed fit sets CHICDIFF_ST_TREND_FAILED);
+    int32_t fitType;     /* 0 = "parametric" (DESeq2's and Chicdiff's default; when that fit fails the local regression is
+                            substituted, as DESeq2 does, and CHICDIFF_ST_TREND_LOCAL is set);
                             1 = "mean": dispFit = mean(dispGeneEst[dispGeneEst > 10 minDisp], trim = 0.001) for every row,
-                            DESeq2's estimateDispersions(fitType = "mean") (single process only) */
+                            DESeq2's estimateDispersions(fitType = "mean") (single process only);
+                            2 = "local": locfit(log dispGeneEst ~ log baseMean, weights = baseMean) with locfit's defaults */
     int32_t _pad;
 } chicdiff_nbglm_opts;
 void chicdiff_hip_default_opts(chicdiff_nbglm_opts *opts);

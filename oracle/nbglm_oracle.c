@@ -47,7 +47,7 @@ void oracle_nbglm_default_opts(oracle_nbglm_opts *o) {
     o->_pad = 0;
     o->trendCoef[0] = o->trendCoef[1] = NAN;
     o->fitType = 0;
-    o->_pad2 = 0;
+    o->noLocalSubstitute = 0;
     o->varLogDispEsts = NAN;
 }
 
@@ -564,8 +564,20 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
             coefs[0] = (double)mean;
             coefs[1] = 0.0;
         }
-    } else
+    } else if (o.fitType != 2)
         trc = nfit > 0 ? oracle_parametric_dispersion_fit(fm, fd, nfit, coefs, &outer) : 4;
+    /* estimateDispersionsFit: fitType = "local" on request, and as the substitute for a failed parametric fit
+     * ("a local regression fit was automatically substituted") — locfit_oracle.c */
+    oracle_locfit lfit;
+    int use_local = 0;
+    if (o.fitType == 2 || (o.fitType == 0 && trc && isnan(o.trendCoef[0]) && !o.noLocalSubstitute)) {
+        trc = oracle_local_dispersion_fit(fm, fd, nfit, &lfit);
+        if (!trc) {
+            use_local = 1;
+            status |= ORACLE_ST_TREND_LOCAL;
+            coefs[0] = coefs[1] = NAN;
+        }
+    }
     if (trc) status |= ORACLE_ST_TREND_FAILED;
     out->trendCoef[0] = coefs[0];
     out->trendCoef[1] = coefs[1];
@@ -574,7 +586,7 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
     /* varLogDispEsts = mad(log dispGeneEst - log dispFit)[dispGeneEst >= 100*minDisp]^2 */
     int64_t nres = 0;
     for (int64_t i = 0; i < n; i++) {
-        dispFit[i] = allZero[i] ? NAN : coefs[0] + coefs[1] / baseMean[i];
+        dispFit[i] = allZero[i] ? NAN : (use_local ? exp(oracle_locfit_eval(&lfit, log(baseMean[i]))) : coefs[0] + coefs[1] / baseMean[i]);
         SET(dispFit, i, dispFit[i]);
         if (!allZero[i] && dispGene[i] >= 100 * o.minDisp) fm[nres++] = log(dispGene[i]) - log(dispFit[i]);
     }

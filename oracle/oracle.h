@@ -33,8 +33,9 @@ typedef struct {
     int32_t nthreads;    /* OpenMP threads over rows (1 = DESeq2-like single thread)  */
     int32_t _pad;
     double trendCoef[2]; /* NaN = fit; else alpha(mu) = c0 + c1/mu as given (DESeq2: dispersionFunction<-) */
-    int32_t fitType;     /* 0 parametric; 1 "mean": dispFit = mean(dispGeneEst[> 10 minDisp], trim = .001) (DESeq2 fitType="mean") */
-    int32_t _pad2;
+    int32_t fitType;     /* 0 parametric (a failed fit is replaced by the local one, as DESeq2 does); 1 "mean": dispFit =
+                          * mean(dispGeneEst[> 10 minDisp], trim = .001); 2 "local": locfit (locfit_oracle.c) */
+    int32_t noLocalSubstitute; /* 1: a failed parametric fit is reported (ORACLE_ST_TREND_FAILED) and the coefficients reached are kept */
     double varLogDispEsts; /* NaN = estimate (mad^2 of the log residuals); else as given: lets a SLICE of a larger fit be checked with
                               all three global scalars (trend, prior variance, this) pinned to the whole fit's */
 } oracle_nbglm_opts;
@@ -46,6 +47,7 @@ void oracle_nbglm_default_opts(oracle_nbglm_opts *o);
 #define ORACLE_ST_PRIORVAR_MC 2      /* m-p <= 3: dispPriorVar matched by simulation as DESeq2 does (set.seed(2)) */
 #define ORACLE_ST_BETA_NONCONV 4     /* some rows hit betaMaxit (DESeq2 would call optim)           */
 #define ORACLE_ST_ALLZERO_ROWS 8     /* some rows are all-zero (NA outputs)                         */
+#define ORACLE_ST_TREND_LOCAL 16      /* dispFit comes from the local regression (fitType "local", or DESeq2's substitute for a failed parametric fit) */
 
 typedef struct {
     /* per-row, length n (any pointer may be NULL) */
@@ -163,4 +165,14 @@ int64_t oracle_region_universe(const int32_t *bait, const int32_t *oe, int64_t n
 #ifdef __cplusplus
 }
 #endif
+/* locfit_oracle.c: DESeq2 localDispersionFit (locfit defaults: alpha 0.7, deg 2, tricube, rbox(cut 0.8), Hermite) */
+#define ORACLE_LOCFIT_MAXV 100 /* locfit's maxk */
+typedef struct {
+    int32_t nv, _pad;
+    double x[ORACLE_LOCFIT_MAXV], h[ORACLE_LOCFIT_MAXV], f[ORACLE_LOCFIT_MAXV], d[ORACLE_LOCFIT_MAXV]; /* vertices, ascending x */
+} oracle_locfit;
+int oracle_locfit_build(const double *x, const double *y, const double *w, int64_t n, double alpha, double cut, oracle_locfit *fit);
+double oracle_locfit_eval(const oracle_locfit *fit, double x);
+int oracle_local_dispersion_fit(const double *means, const double *disps, int64_t n, oracle_locfit *fit);
+
 #endif

@@ -35,7 +35,7 @@ class Opts(C.Structure):
                 ("maxit", C.c_int32), ("betaMaxit", C.c_int32), ("betaTol", C.c_double),
                 ("minmu", C.c_double), ("outlierSD", C.c_double), ("dispPriorVar", C.c_double),
                 ("nthreads", C.c_int32), ("_pad", C.c_int32), ("trendCoef", C.c_double * 2), ("fitType", C.c_int32),
-                ("_pad2", C.c_int32), ("varLogDispEsts", C.c_double)]
+                ("noLocalSubstitute", C.c_int32), ("varLogDispEsts", C.c_double)]
 
 
 _PD, _PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)
@@ -368,3 +368,24 @@ def r_random(kind, seed, n, *args) -> np.ndarray:
     else:
         getattr(lib(), {"runif": "oracle_r_runif", "rnorm": "oracle_r_rnorm", "rexp": "oracle_r_rexp"}[kind])(seed, n, _pd(out))
     return out
+
+
+class LocFit(C.Structure):
+    _fields_ = [("nv", C.c_int32), ("_pad", C.c_int32), ("x", C.c_double * 100), ("h", C.c_double * 100), ("f", C.c_double * 100),
+                ("d", C.c_double * 100)]
+
+
+def local_dispersion_fit(means, disps):
+    """DESeq2 localDispersionFit (locfit defaults).  Returns (vertices dict, predict(log means) -> log dispersion)."""
+    m = np.ascontiguousarray(means, dtype=np.float64)
+    d = np.ascontiguousarray(disps, dtype=np.float64)
+    fit = LocFit()
+    L = lib()
+    L.oracle_locfit_eval.restype = C.c_double
+    L.oracle_locfit_eval.argtypes = [C.POINTER(LocFit), C.c_double]
+    rc = L.oracle_local_dispersion_fit(_pd(m), _pd(d), C.c_int64(len(m)), C.byref(fit))
+    if rc:
+        raise RuntimeError(f"oracle_local_dispersion_fit rc={rc}")
+    nv = fit.nv
+    vert = dict(x=np.array(fit.x[:nv]), h=np.array(fit.h[:nv]), f=np.array(fit.f[:nv]), d=np.array(fit.d[:nv]))
+    return vert, lambda lx: np.array([L.oracle_locfit_eval(C.byref(fit), float(v)) for v in np.atleast_1d(lx)])

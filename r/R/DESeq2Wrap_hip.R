@@ -41,18 +41,22 @@
   fit
 }
 
-## DESeq2 reacts to a failed parametric trend by switching to fitType = "local" (locfit), which the library does not
-## restate.  options(chicdiff.hip.trendFallback = "mean") refits such a data set with DESeq2's other documented
-## alternative, fitType = "mean", and says so; the default is to stop.
+## A failed parametric trend is replaced by the local regression inside the library, as estimateDispersionsFit does
+## (status bit 16); DESeq2's message is repeated here.  Only when not even the local fit exists (fewer than four rows
+## with a usable dispersion estimate, status bit 1) is there a choice to make: options(chicdiff.hip.trendFallback =
+## "mean") refits with DESeq2's other documented alternative, fitType = "mean"; the default is to stop.
 .hipTrendFailed <- function(fit) bitwAnd(fit$status, 1L) != 0L
 .hipFitWithFallback <- function(run) {
   fit <- run(0L)
+  if (bitwAnd(fit$status, 16L) != 0L)
+    message("-- note: fitType='parametric', but the dispersion trend was not well captured by the\n",
+            "   function: y = a/x + b, and a local regression fit was automatically substituted.\n",
+            "   specify fitType='local' or 'mean' to avoid this message next time.")
   if (.hipTrendFailed(fit)) {
     if (!identical(getOption("chicdiff.hip.trendFallback"), "mean"))
-      stop("the parametric dispersion trend did not converge; DESeq2 would switch to a local fit here (fitType = \"local\"): ",
+      stop("no dispersion trend could be fitted (parametric and local fits both failed): ",
            "set options(chicdiff.hip.trendFallback = \"mean\") to refit with fitType = \"mean\"")
-    message("-- note: fitType='parametric', but the dispersion trend was not well captured by the function: y = a/x + b, ",
-            "and fitType = \"mean\" was substituted (DESeq2 itself would substitute a local regression fit).")
+    message("-- note: no dispersion trend could be fitted; fitType = \"mean\" was used instead.")
     fit <- run(1L)
   }
   fit

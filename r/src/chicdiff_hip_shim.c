@@ -170,7 +170,7 @@ static SEXP named_list(int n, const char **names) {
 static void set_opts(chicdiff_nbglm_opts *o, SEXP dispPriorVar, SEXP fitType) {
     chicdiff_hip_default_opts(o);
     if (Rf_length(dispPriorVar) == 1 && !ISNAN(Rf_asReal(dispPriorVar))) o->dispPriorVar = Rf_asReal(dispPriorVar);
-    o->fitType = Rf_asInteger(fitType); /* 0 "parametric", 1 "mean" (DESeq2 estimateDispersions(fitType = )) */
+    o->fitType = Rf_asInteger(fitType); /* 0 "parametric" (local fit substituted on failure), 1 "mean", 2 "local" (DESeq2 estimateDispersions(fitType = )) */
 }
 static void check_group(SEXP group, int S) {
     if (!Rf_isInteger(group) || LENGTH(group) != S) Rf_error("chicdiff_hip: group must be an integer vector with one 0/1 entry per sample");

@@ -259,3 +259,54 @@ def fit_beta(y, nf, X, alpha, lam, beta0, minmu=0.5, tol=1e-8, maxit=100, large=
     xtwx = X.T @ (w[:, None] * X)
     inv = np.linalg.inv(xtwx + ridge)
     return beta, it, dev, np.diag(inv @ xtwx @ inv), mu
+
+
+# ------------------------------------------------------------------------------------------------
+# locfit(y ~ x, weights = w) with locfit's defaults, one dimension — an independent restatement (sorted windows for
+# the nearest neighbours, numpy lstsq for the local quadratic) of what oracle/locfit_oracle.c does
+def locfit_1d(x, y, w, alpha=0.7, cut=0.8, deg=2):
+    x, y, w = (np.asarray(a, float) for a in (x, y, w))
+    n = len(x)
+    k = int(n * alpha)
+
+    def vertex(xv):
+        dist = np.sort(np.abs(x - xv))
+        h = dist[k - 1]                                   # the k-th smallest distance
+        u = np.abs(x - xv) / h
+        use = u < 1
+        ww = w[use] * (1 - u[use] ** 3) ** 3
+        dx = x[use] - xv
+        B = np.column_stack([np.ones(use.sum()), dx, dx ** 2 / 2])[:, : deg + 1]
+        sw = np.sqrt(ww)
+        beta = np.linalg.lstsq(B * sw[:, None], y[use] * sw, rcond=None)[0]
+        return h, beta[0], beta[1]
+
+    verts = {}
+    for xv in (x.min(), x.max()):
+        verts[xv] = vertex(xv)
+
+    def grow(l, r):
+        hmin = min(verts[l][0], verts[r][0])
+        if (r - l) / hmin > cut:
+            m = (l + r) / 2
+            verts[m] = vertex(m)
+            grow(l, m)
+            grow(m, r)
+
+    grow(x.min(), x.max())
+    vx = np.array(sorted(verts))
+    vh, vf, vd = (np.array([verts[v][q] for v in vx]) for q in range(3))
+
+    def predict(z):
+        z = np.atleast_1d(np.asarray(z, float))
+        j = np.clip(np.searchsorted(vx, z, side="right") - 1, 0, len(vx) - 2)
+        width = vx[j + 1] - vx[j]
+        t = (z - vx[j]) / width
+        inside = (t >= 0) & (t <= 1)
+        p1 = np.where(inside, t * t * (3 - 2 * t), (t > 1).astype(float))
+        p0 = 1 - p1
+        p2 = np.where(inside, t * (1 - t) ** 2, np.where(t < 0, t, 0.0))
+        p3 = np.where(inside, t * t * (t - 1), np.where(t > 1, t - 1, 0.0))
+        return p0 * vf[j] + p1 * vf[j + 1] + (p2 * vd[j] + p3 * vd[j + 1]) * width
+
+    return dict(x=vx, h=vh, f=vf, d=vd), predict

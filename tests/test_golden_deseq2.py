@@ -30,7 +30,9 @@ def _load(tag):
 
 def _compare(got, gold, sc_got, sc):
     nz = gold["allZero"] == 0
-    assert np.allclose(sc_got["trendCoef"], [float(x) for x in sc["trendCoef"].split()], rtol=1e-6)
+    assert np.allclose(sc_got["trendCoef"], [float(x) for x in sc["trendCoef"].split()], rtol=1e-6, equal_nan=True)
+    if "dispFit" in got:
+        assert np.allclose(got["dispFit"][nz], gold["dispFit"][nz], rtol=1e-6), "dispFit"
     assert np.isclose(sc_got["dispPriorVar"], float(sc["dispPriorVar"]), rtol=1e-9), (sc_got["dispPriorVar"], sc["dispPriorVar"])
     for k, g in (("dispersion", "dispersion"), ("log2FoldChange", "log2FoldChange"), ("pvalue", "waldPvalue")):
         if g not in gold:
@@ -47,7 +49,7 @@ def _compare(got, gold, sc_got, sc):
 def test_oracle_against_deseq2(tag):
     from oracle import oracle
     counts, nf, group, gold, sc = _load(tag)
-    ref = oracle.nbglm_fit(counts, nf, group)
+    ref = oracle.nbglm_fit(counts, nf, group, fitType=2 if sc.get("fitType") == "local" else 0)  # "<tag>_local": DESeq2 run with fitType = "local"
     _compare(ref, gold, ref, sc)
 
 
@@ -59,7 +61,8 @@ def test_hip_against_deseq2(tag):
     counts, nf, group, gold, sc = _load(tag)
     ctx = hip.HipContext(0)
     out, scg = ctx.nbglm_fit(ctx.to_device(counts, np.int32), ctx.to_device(nf, np.float64), group,
-                             want=["dispersion", "log2FoldChange", "pvalue"])
+                             want=["dispFit", "dispersion", "log2FoldChange", "pvalue"],
+                             opts=hip.default_opts(fitType=2) if sc.get("fitType") == "local" else None)
     _compare({k: v.cpu().numpy() for k, v in out.items()}, gold, scg, sc)
 
 

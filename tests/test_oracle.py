@@ -466,3 +466,64 @@ def test_map_search_matches_procedure_twin():
         same += it == r["dispIter"][i]
         assert np.isclose(np.log(est), np.log(r["dispMAP"][i]), atol=1e-6 if it == r["dispIter"][i] else 5e-2), i
     assert same >= len(pick) - 2
+
+
+# ---------------------------------------------------------------- local-regression trend (DESeq2 fitType = "local")
+def test_local_dispersion_fit_matches_twin():
+    """oracle/locfit_oracle.c against the numpy restatement (sorted-window nearest neighbours, lstsq local quadratic):
+    same tree, same bandwidths, values and slopes at the vertices, same predictions inside and outside the data range."""
+    rng = np.random.default_rng(5)
+    for n in (40, 700, 6000):
+        means = rng.lognormal(np.log(19), 1.4, n)
+        disps = (0.05 + 2 / means) * rng.lognormal(0, 0.5, n)
+        v, pred = oracle.local_dispersion_fit(means, disps)
+        tv, tpred = np_twin.locfit_1d(np.log(means), np.log(disps), means)
+        assert len(v["x"]) == len(tv["x"]) >= 3 and np.array_equal(v["x"], tv["x"]) and np.array_equal(v["h"], tv["h"])
+        assert np.allclose(v["f"], tv["f"], rtol=0, atol=1e-10) and np.allclose(v["d"], tv["d"], rtol=0, atol=1e-10)
+        z = np.log(rng.lognormal(np.log(19), 2.2, 500))
+        assert (z < v["x"][0]).any() and (z > v["x"][-1]).any()  # linear continuation beyond the data range
+        assert np.allclose(pred(z), tpred(z), rtol=0, atol=1e-10)
+        # every cell is at most 0.8 bandwidths wide (the rule that grew the tree), and the curve is C1 at the vertices
+        assert np.all(np.diff(v["x"]) <= 0.8 * np.minimum(v["h"][:-1], v["h"][1:]) * (1 + 1e-12))
+        eps = 1e-6
+        inner = v["x"][1:-1]
+        assert np.allclose((pred(inner + eps) - pred(inner - eps)) / (2 * eps), v["d"][1:-1], atol=1e-5)
+    # the fit recovers a smooth trend
+    means = rng.lognormal(np.log(19), 1.4, 20000)
+    _, pred = oracle.local_dispersion_fit(means, (0.05 + 2 / means) * rng.lognormal(0, 0.3, 20000))
+    zz = np.linspace(np.log(3), np.log(300), 9)
+    assert np.max(np.abs(pred(zz) - np.log(0.05 + 2 / np.exp(zz)))) < 0.05
+
+
+def test_fit_type_local_and_substitution_for_a_failed_parametric_fit():
+    """fitType = 2 uses the local regression; fitType = 0 substitutes it when the parametric fit fails (as DESeq2 does),
+    unless told not to; downstream quantities are the ones the parametric path would compute from that dispFit."""
+    d = synth.make(3000, 8)
+    r = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], fitType=2)
+    assert r["status"] & 16 and not r["status"] & 1 and np.all(np.isnan(r["trendCoef"]))
+    nz = r["allZero"] == 0
+    use = nz & (r["dispGeneEst"] > 1e-6)
+    _, pred = oracle.local_dispersion_fit(r["baseMean"][use], r["dispGeneEst"][use])
+    assert np.allclose(r["dispFit"][nz], np.exp(pred(np.log(r["baseMean"][nz]))), rtol=1e-12)
+    res = np.log(r["dispGeneEst"][use]) - np.log(r["dispFit"][use])
+    assert np.isclose(r["varLogDispEsts"], (1.4826 * np.median(np.abs(res - np.median(res)))) ** 2, rtol=1e-12)
+    p = oracle.nbglm_fit(d["counts"], d["nf"], d["group"])
+    # the local fit averages log dispersions, the Gamma GLM dispersions: with the spread of gene-wise estimates from eight
+    # samples (sd of the log ~ 0.9) the two trends differ by about sigma^2 / 2, the same everywhere along the curve
+    lr = np.log(p["dispFit"] / r["dispFit"])[nz]
+    assert not p["status"] & 16 and 0.1 < np.median(lr) < 0.8 and np.std(lr) < 0.3
+    # a matrix whose parametric fit fails: substituted by default, reported when the substitution is switched off
+    rng = np.random.default_rng(17)
+    n, S = 4000, 6
+    dd = synth.make(n, S)
+    counts, nf = dd["counts"].copy(), dd["nf"].copy()
+    big = rng.choice(n, 300, replace=False)
+    counts[big] = rng.integers(2 ** 20, 2 ** 30, size=(300, S))
+    counts[big[:100], 0] = 0
+    nf[big[100:200]] *= np.exp(rng.normal(0, 2.0, size=(100, S)))
+    nf /= np.exp(np.log(nf).mean(axis=1, keepdims=True))
+    a = oracle.nbglm_fit(counts, nf, dd["group"])
+    b = oracle.nbglm_fit(counts, nf, dd["group"], noLocalSubstitute=1)
+    c = oracle.nbglm_fit(counts, nf, dd["group"], fitType=2)
+    assert a["status"] & 16 and not a["status"] & 1 and b["status"] & 1 and not b["status"] & 16
+    assert np.array_equal(a["dispFit"], c["dispFit"], equal_nan=True) and np.array_equal(a["pvalue"], c["pvalue"], equal_nan=True)

@@ -62,6 +62,26 @@ for (tag in tags) {
   file.copy(file.path(indir, paste0(tag, c(".counts.i32", ".nf.f64", ".meta.txt"))), outdir, overwrite = TRUE)  # inputs travel with the goldens
   message(tag, ": dispPriorVar ", attr(df, "dispPriorVar"), "  fitType ", attr(df, "fitType"))
 
+  ## the same data with DESeq2's local-regression trend (localDispersionFit = locfit; also what DESeq2 substitutes when
+  ## the parametric fit fails): pins oracle/locfit_oracle.c and the library's fitType = 2.  Written as tag "<tag>_local".
+  ddl <- DESeqDataSetFromMatrix(countData = counts, colData = colData, design = if (intercept) ~ 1 else ~ condition)
+  normalizationFactors(ddl) <- nf
+  ddl <- nbinomWaldTest(estimateDispersions(ddl, fitType = "local"))
+  ml <- mcols(ddl); dl <- dispersionFunction(ddl)
+  lcols <- list(baseMean = ml$baseMean, allZero = as.numeric(ml$allZero), dispGeneEst = ml$dispGeneEst, dispFit = ml$dispFit,
+                dispMAP = ml$dispMAP, dispersion = ml$dispersion)
+  if (!intercept) lcols <- c(lcols, list(log2FoldChange = ml$condition_B_vs_A, waldPvalue = ml$WaldPvalue_condition_B_vs_A))
+  ltag <- paste0(tag, "_local")
+  writeBin(as.double(do.call(cbind, lcols)), file.path(outdir, paste0(ltag, ".deseq2.f64")), size = 8)
+  writeLines(names(lcols), file.path(outdir, paste0(ltag, ".deseq2.cols")))
+  writeLines(c(sprintf("n %d", n), sprintf("S %d", S), sprintf("group %s", paste(group, collapse = " ")),
+               "trendCoef NaN NaN", sprintf("varLogDispEsts %.17g", attr(dl, "varLogDispEsts")),
+               sprintf("dispPriorVar %.17g", attr(dl, "dispPriorVar")), sprintf("fitType %s", attr(dl, "fitType")),
+               sprintf("locfit %s", as.character(packageVersion("locfit")))),
+             file.path(outdir, paste0(ltag, ".deseq2.scalars.txt")))
+  for (ext in c(".counts.i32", ".nf.f64", ".meta.txt"))
+    file.copy(file.path(indir, paste0(tag, ext)), file.path(outdir, paste0(ltag, ext)), overwrite = TRUE)
+
   if (withHip && !intercept) {
     source("r/R/DESeq2Wrap_hip.R")
     dyn.load("r/src/chicdiff_hip_shim.so")
