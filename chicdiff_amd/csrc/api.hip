@@ -633,22 +633,25 @@ struct LfTree {
     int nv = 0;
     double x[kLfMaxV], h[kLfMaxV], f[kLfMaxV], d[kLfMaxV];
 };
-static int lf_add(chicdiff_hip_ctx *c, FitDims d, const Opts &o, double nfit, LfTree &t, double xv) {
-    if (t.nv >= kLfMaxV) return -1;
-    if (lf_vertex(c, d, o, nfit, xv, &t.h[t.nv], &t.f[t.nv], &t.d[t.nv])) return -1;
+// a new vertex at xv: its index, or -1 with *rc set (CHICDIFF_E_NUMERIC: no fit possible there / too many vertices)
+static int lf_add(chicdiff_hip_ctx *c, FitDims d, const Opts &o, double nfit, LfTree &t, double xv, int *rc) {
+    if (t.nv >= kLfMaxV) { *rc = CHICDIFF_E_NUMERIC; return -1; }
+    if ((*rc = lf_vertex(c, d, o, nfit, xv, &t.h[t.nv], &t.f[t.nv], &t.d[t.nv]))) return -1;
     t.x[t.nv] = xv;
     return t.nv++;
 }
 // locfit atree_grow in one dimension: cut the cell at its midpoint while its length exceeds cut = 0.8 bandwidths
-static bool lf_grow(chicdiff_hip_ctx *c, FitDims d, const Opts &o, double nfit, LfTree &t, int il, int ir, double range) {
+static int lf_grow(chicdiff_hip_ctx *c, FitDims d, const Opts &o, double nfit, LfTree &t, int il, int ir, double range) {
     const double le = t.x[ir] - t.x[il];
     double hmin = t.h[il] > 0 ? t.h[il] : 0;
     if (t.h[ir] > 0 && (hmin == 0 || t.h[ir] < hmin)) hmin = t.h[ir];
     const double score = hmin == 0 ? 2 * le / range : le / hmin;
-    if (!(0.8 < score)) return true;
-    const int im = lf_add(c, d, o, nfit, t, (t.x[il] + t.x[ir]) / 2);
-    if (im < 0) return false;
-    return lf_grow(c, d, o, nfit, t, il, im, range) && lf_grow(c, d, o, nfit, t, im, ir, range);
+    if (!(0.8 < score)) return CHICDIFF_OK;
+    int rc = CHICDIFF_OK;
+    const int im = lf_add(c, d, o, nfit, t, (t.x[il] + t.x[ir]) / 2, &rc);
+    if (im < 0) return rc;
+    if ((rc = lf_grow(c, d, o, nfit, t, il, im, range))) return rc;
+    return lf_grow(c, d, o, nfit, t, im, ir, range);
 }
 // returns CHICDIFF_OK with dispFit[] filled and the trend marked local, or CHICDIFF_E_NUMERIC when no fit is possible
 static int local_trend_fit(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
@@ -659,8 +662,9 @@ static int local_trend_fit(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
     if ((rc = lf_order_stat(c, d, o, 0, 0.0, nfit - 1, &hi, &dummy))) return rc;  // max(x)
     if (!(hi > lo)) return CHICDIFF_E_NUMERIC;
     LfTree t;
-    const int il = lf_add(c, d, o, nfit, t, lo), ir = il < 0 ? -1 : lf_add(c, d, o, nfit, t, hi);
-    if (il < 0 || ir < 0 || !lf_grow(c, d, o, nfit, t, il, ir, hi - lo)) return c->err[0] ? CHICDIFF_E_HIP : CHICDIFF_E_NUMERIC;
+    const int il = lf_add(c, d, o, nfit, t, lo, &rc), ir = il < 0 ? -1 : lf_add(c, d, o, nfit, t, hi, &rc);
+    if (il < 0 || ir < 0) return rc;
+    if ((rc = lf_grow(c, d, o, nfit, t, il, ir, hi - lo))) return rc;
     LfVerts v{};
     std::vector<int> order(t.nv);
     for (int i = 0; i < t.nv; i++) order[i] = i;
