@@ -43,6 +43,9 @@ struct chicdiff_hip_ctx {
     bool no_persistent_trend = false;  // set after a grid-barrier timeout (see fit_dev_impl)
     // tuning / test options (chicdiff_hip_set_option); the defaults are what the benchmarks run
     int opt_spread = 1, opt_min_waves = 2, opt_select_rounds = 0, opt_trend_multilaunch = 0;
+    int opt_trend_gather = 1;  // sharded fits: gather the rows of the trend on every rank (two collectives) instead of one all-reduce per IRLS pass
+    char *tg_buf = nullptr;    // ... the gathered rows (grow-only)
+    size_t tg_bytes = 0;
     int opt_no_local_substitute = 0;  // 1: a failed parametric trend is reported (CHICDIFF_ST_TREND_FAILED), not replaced by the local fit
     // host-buffer entry point: device arena + pinned staging, both grow-only (no allocation per call once warm)
     char *io_dev = nullptr, *io_pin = nullptr;
@@ -146,6 +149,7 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     if (k == "line_search_spread" && (value == 0 || value == 1)) c->opt_spread = (int)value;
     else if (k == "line_search_min_waves" && value >= 2 && value <= 4) c->opt_min_waves = (int)value;
     else if (k == "local_trend_substitute" && (value == 0 || value == 1)) c->opt_no_local_substitute = value ? 0 : 1;
+    else if (k == "sharded_trend_gather" && (value == 0 || value == 1)) c->opt_trend_gather = (int)value;
     else if (k == "theta_grid_concurrency" && value >= 1 && value <= 16) c->opt_grid_lanes = (int)value;
     else if (k == "host_copy_threads" && value >= 1 && value <= 64) c->opt_host_threads = (int)value;
     else if (k == "select_all_rounds" && (value == 0 || value == 1)) c->opt_select_rounds = (int)value;
@@ -204,6 +208,7 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     c->lanes.clear();
     if (c->ws) (void)hipFree(c->ws);
     if (c->aux) (void)hipFree(c->aux);
+    if (c->tg_buf) (void)hipFree(c->tg_buf);
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->d_logfact) (void)hipFree(c->d_logfact);
     for (int k = 0; k < 4; k++)
@@ -675,6 +680,53 @@ static int local_trend_fit(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
     return CHICDIFF_OK;
 }
 
+// Sharded fits: the parametric trend on ALL ranks' rows, on every rank.  The fit is ~20 dependent IRLS passes over two
+// doubles per row; sharding it costs one latency-bound all-reduce per pass (20 of a sharded fit's ~38 collectives), while
+// the rows themselves are small: 16 bytes each.  So the ranks exchange them once — their sizes (one all-reduce of `world`
+// doubles), then the rows (a sum-all-reduce over zero-initialised all-ranks arrays = an all-gather; 32 MB at 2 M rows) —
+// and each runs the single-launch persistent kernel on the whole set: two collectives instead of twenty, and the trend of
+// a sharded fit is bit-identical to the single-rank one (same rows, same order, same kernel).
+static int gathered_trend(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
+    hipStream_t st = c->stream;
+    FitWork &w = c->w;
+    const int world = c->world > 0 ? c->world : 1, rank = c->rank;
+    std::vector<double> cnt((size_t)world, 0.0);
+    cnt[(size_t)rank] = (double)d.n;
+    double *d_cnt = w.hist;
+    HIPCHK(c, hipMemcpyAsync(d_cnt, cnt.data(), sizeof(double) * world, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));  // cnt lives on this frame
+    int rc = do_allreduce(c, d_cnt, world);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(double) * world, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    int64_t off = 0, total = 0;
+    for (int r = 0; r < world; r++) {
+        if (r < rank) off += (int64_t)cnt[(size_t)r];
+        total += (int64_t)cnt[(size_t)r];
+    }
+    const size_t nd = align256(sizeof(double) * (size_t)total), ni = align256(sizeof(int32_t) * (size_t)total);
+    if (c->tg_bytes < 2 * nd + ni) {
+        if (c->tg_buf) HIPCHK(c, hipFree(c->tg_buf));
+        c->tg_buf = nullptr;
+        c->tg_bytes = 0;
+        HIPCHK(c, hipMalloc((void **)&c->tg_buf, 2 * nd + ni));
+        c->tg_bytes = 2 * nd + ni;
+    }
+    double *xg = (double *)c->tg_buf, *yg = (double *)(c->tg_buf + nd);
+    int32_t *flags = (int32_t *)(c->tg_buf + 2 * nd);
+    HIPCHK(c, hipMemsetAsync(c->tg_buf, 0, 2 * nd + ni, st));
+    launch_trend_gather(d, w, o, xg + off, yg + off, st);
+    if ((rc = do_allreduce(c, xg, (int64_t)(2 * nd / sizeof(double))))) return rc;  // x and y are contiguous (padding included)
+    FitDims dg = d;
+    dg.n = total;
+    FitWork wg = w;
+    wg.baseMean = xg;
+    wg.dispGene = yg;
+    wg.allZero = flags;  // all zero: a row that does not take part carries y = NaN
+    launch_trend_persistent(dg, wg, o, st);
+    return CHICDIFF_OK;
+}
+
 static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const double *d_nf, FitDims d, Opts o,
                         const chicdiff_nbglm_out *d_out, chicdiff_nbglm_scalars *scalars) {
     int rc;
@@ -739,6 +791,10 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     } else if (!c->allreduce && !c->no_persistent_trend && c->cu_count >= trend_persistent_blocks() && !c->opt_trend_multilaunch) {
         Scope t(c, "trend_fit");  // single rank: one persistent launch (LDS-resident rows, grid barrier per IRLS pass)
         launch_trend_persistent(d, w, o, st);  // no host round trip: `failed` comes back with the final scalars
+    } else if (c->allreduce && c->opt_trend_gather && !c->no_persistent_trend && c->cu_count >= trend_persistent_blocks() &&
+               !c->opt_trend_multilaunch) {
+        Scope t(c, "trend_fit");
+        if ((rc = gathered_trend(c, d, o))) return rc;
     } else {
         Scope t(c, "trend_fit");
         HipBackend be{c, d, o, SelArgs{}};
@@ -808,7 +864,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_wald_intercept(d_counts, d_nf, d, w, o, out, st);
     }
     launch_dev_sum_finish(d, w, st);
-    if ((rc = do_allreduce(c, sums_of(w), 3))) return rc;
+    if ((rc = do_allreduce(c, sums_of(w), 4))) return rc;  // deviance sum, non-converged rows, all-zero rows, ranks whose trend kernel timed out
     // copy the per-row workspace columns the caller asked for
     const size_t nb = sizeof(double) * (size_t)d.n, ib = sizeof(int32_t) * (size_t)d.n;
 #define CPY(dst, src, bytes) \
@@ -818,13 +874,13 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     CPY(dispGeneIter, w.geneIter, ib); CPY(dispIter, w.mapIter, ib); CPY(dispOutlier, w.outlier, ib);
     CPY(allZero, w.allZero, ib);
 #undef CPY
-    double hs[3];
+    double hs[4];
     HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(hs, sums_of(w), sizeof hs, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     if (c->h_sc->neg_counts) return fail(c, CHICDIFF_E_INVALID, "counts contain a negative value or NA_integer_");
-    if (c->h_sc->failed == 3) {
+    if (c->h_sc->failed == 3 || hs[3] > 0) {  // (hs[3]: some rank of a sharded fit — every rank takes this branch together)
         // the persistent trend kernel's workgroups were not all resident within the barrier's patience (a GPU shared
         // with other work): fit again with one launch per IRLS pass, and stay with that for this context
         if (c->no_persistent_trend) return fail(c, CHICDIFF_E_HIP, "trend fit: grid barrier timed out");
@@ -1180,6 +1236,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         l->opt_spread = c->opt_spread;
         l->opt_min_waves = c->opt_min_waves;
         l->opt_no_local_substitute = c->opt_no_local_substitute;
+        l->opt_trend_gather = c->opt_trend_gather;
         l->opt_select_rounds = c->opt_select_rounds;
         l->opt_trend_multilaunch = c->opt_trend_multilaunch;
         l->no_persistent_trend = true;  // a grid barrier needs its workgroups co-resident: not guaranteed beside other fits

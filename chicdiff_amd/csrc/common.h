@@ -59,6 +59,7 @@ struct LfVerts { int nv; int _pad; double x[kLfMaxV], f[kLfMaxV], d[kLfMaxV]; };
 void launch_lf_hist(FitDims d, FitWork w, Opts o, int use_dist, double xv, uint64_t prefix, int shift, double *hist, hipStream_t st);
 void launch_lf_sums(FitDims d, FitWork w, Opts o, double xv, double h, double *partials, double *out8, hipStream_t st);
 void launch_lf_eval(FitDims d, FitWork w, const LfVerts &v, hipStream_t st);
+void launch_trend_gather(FitDims d, FitWork w, Opts o, double *xg, double *yg, hipStream_t st);
 void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_resid_hist(FitDims d, FitWork w, double *out40, hipStream_t st);  // residual histogram for the d.f. <= 3 prior

@@ -232,6 +232,18 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
         sc->finished = 1;
     }
 }
+// sharded fits: this rank's slice of the rows the trend is fitted to, written into the all-ranks arrays (zero elsewhere; the
+// sum-all-reduce that follows is then an all-gather).  y = NaN marks a row that does not take part.
+__global__ __launch_bounds__(256) void trend_gather_kernel(FitDims d, FitWork w, double minDisp, double *xg, double *yg) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+        const double y = w.dispGene[i];
+        xg[i] = w.baseMean[i];
+        yg[i] = (!w.allZero[i] && y > 100 * minDisp) ? y : NAN;
+    }
+}
+void launch_trend_gather(FitDims d, FitWork w, Opts o, double *xg, double *yg, hipStream_t st) {
+    trend_gather_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp, xg, yg);
+}
 int trend_persistent_blocks() { return kTpBlocks; }
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
     // (the barrier counters were zeroed with the fit's scalars; the trend runs once per fit)

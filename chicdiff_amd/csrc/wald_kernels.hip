@@ -513,6 +513,9 @@ __global__ void dev_sum_kernel(FitWork w) {
         if (threadIdx.x == 0) sums[k] = red[0];
         __syncthreads();
     }
+    // a rank whose persistent trend kernel lost its grid barrier (sharded fits with the gathered trend): summed over the
+    // ranks with the three above, so that every rank learns of it and all of them refit the same way
+    if (threadIdx.x == 0) sums[3] = w.sc->failed == 3 ? 1.0 : 0.0;
 }
 
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts, hipStream_t st) {

@@ -73,6 +73,8 @@ int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, 
  *   "host_copy_threads"         12 (default), 1 .. 64: host threads staging caller buffers in chicdiff_hip_nbglm_fit
  *   "select_all_rounds"         0 (default) | 1: exact medians by histogram rounds only (no candidate-sort shortcut)
  *   "trend_one_launch_per_pass" 0 (default) | 1: trend fit as one launch per IRLS pass instead of one persistent kernel
+ *   "sharded_trend_gather"      1 (default) | 0: sharded fits exchange the trend's rows once and fit them on every rank,
+ *                               instead of one all-reduce per IRLS pass (same coefficients up to summation order)
  * and one that does change the outcome of a fit whose parametric trend fails (DESeq2 offers the same choice through fitType):
  *   "local_trend_substitute"    1 (default) | 0: report CHICDIFF_ST_TREND_FAILED instead of substituting the local regression */
 int chicdiff_hip_set_option(chicdiff_hip_ctx *ctx, const char *name, int64_t value);
