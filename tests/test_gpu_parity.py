@@ -245,6 +245,44 @@ def test_count_join(ctx, oracle):
     assert np.array_equal(ctx.count_join(t(xb), t(xo), t(keys), t(vals)).cpu().numpy(), oracle.count_join(xb, xo, keys, vals))
 
 
+def test_count_join_randomised_shapes(ctx, oracle):
+    """The join kernel's paths (coarse level, LDS window, global search, ragged tail, unaligned pointers) under random
+    table / query shapes: tiny and empty tables, queries entirely below or above the table, long runs of duplicates,
+    clustered keys (one tile spanning thousands of keys), sorted and unsorted callers.  Bit-exact against the oracle."""
+    import torch
+    rng = np.random.default_rng(123)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(ctx.device)
+    for trial in range(60):
+        nk = int(rng.choice([0, 1, 2, 63, 64, 65, 511, 513, 4097, 20000]))
+        nq = int(rng.choice([1, 5, 64, 500, 512, 520, 3000, 9000]))
+        nb = int(rng.choice([1, 3, 50]))                                   # baits in play
+        span = int(rng.choice([40, 2000, 200000]))                         # other-end IDs per bait
+        kb = rng.integers(100, 100 + nb, nk).astype(np.int64)
+        ko = rng.integers(0, span, nk).astype(np.int64)
+        keys = np.unique((kb << 32) | ko)
+        vals = rng.integers(1, 1000, len(keys)).astype(np.int32)
+        mode = trial % 4
+        if mode == 0 or len(keys) == 0:                                    # random queries around the table
+            qb = rng.integers(99, 101 + nb, nq).astype(np.int32)
+            qo = rng.integers(0, span, nq).astype(np.int32)
+        elif mode == 1:                                                    # mostly hits, with duplicates
+            pick = keys[rng.integers(0, len(keys), nq)]
+            qb, qo = (pick >> 32).astype(np.int32), (pick & 0xFFFFFFFF).astype(np.int32)
+        elif mode == 2:                                                    # everything below / above the table
+            qb = np.full(nq, 99 if trial % 8 < 4 else 100 + nb + 5, dtype=np.int32)
+            qo = rng.integers(0, span, nq).astype(np.int32)
+        else:                                                              # two far-apart clusters in one tile
+            qb = np.where(rng.uniform(size=nq) < 0.5, 100, 100 + nb - 1).astype(np.int32)
+            qo = rng.integers(0, span, nq).astype(np.int32)
+        if trial % 3:                                                      # RU order (sorted), else an arbitrary caller
+            order = np.lexsort((qo, qb))
+            qb, qo = qb[order], qo[order]
+        ref = oracle.count_join(qb, qo, keys, vals)
+        off = int(rng.integers(0, 4)) if nq > 8 else 0                     # now and then pointers that are not 16-byte aligned
+        got = ctx.count_join(t(qb)[off:], t(qo)[off:], t(keys), t(vals)).cpu().numpy()
+        assert np.array_equal(got, ref[off:]), (trial, nk, nq, nb, span, mode, off)
+
+
 def test_theta_grid(ctx, oracle):
     d = synth.make(6000, 8, fragments=3)
     keep = d["counts"].sum(1) > 0
