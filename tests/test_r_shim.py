@@ -10,7 +10,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "r", "src", "chicdiff_hip_shim.c")
 RSRC = [os.path.join(ROOT, "r", "R", "DESeq2Wrap_hip.R"), os.path.join(ROOT, "tools", "make_golden.R"),
-        os.path.join(ROOT, "r", "R", "getFullRegionData_hip.R")]
+        os.path.join(ROOT, "r", "R", "getFullRegionData_hip.R"), os.path.join(ROOT, "r", "R", "post_hip.R")]
 
 
 def test_shim_compiles_against_declaration_only_r_headers():
@@ -74,7 +74,8 @@ def test_every_dot_call_is_registered_with_matching_arity():
             seen.add(name)
     for must in ("chicdiff_hip_open", "chicdiff_hip_window_sums", "chicdiff_hip_size_factors", "chicdiff_hip_theta_grid",
                  "chicdiff_hip_wald_test", "chicdiff_hip_fit", "chicdiff_hip_release", "chicdiff_hip_chinput_table",
-                 "chicdiff_hip_count_join", "chicdiff_hip_fragment_background", "chicdiff_hip_alloc"):
+                 "chicdiff_hip_count_join", "chicdiff_hip_fragment_background", "chicdiff_hip_alloc", "chicdiff_hip_region_universe",
+                 "chicdiff_hip_ihw_apply"):
         assert must in seen, must
 
 
