@@ -60,7 +60,8 @@ struct chicdiff_hip_ctx {
         hipEvent_t ready = nullptr, done = nullptr;
         bool issued = false;
     } *early = nullptr;
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr;      // also the second stream of the independent-filtering sorts
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<chicdiff_hip_ctx *> lanes;  // theta grid: child contexts (own stream + workspace), one per concurrent fit
     int opt_grid_lanes = 5;                 // theta grid: fits in flight at once (1 = one after the other)
     int cu_count = 0;  // compute units of the device (the persistent trend kernel needs one resident workgroup per CU it launches)
@@ -216,6 +217,8 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     if (c->h_sc) (void)hipHostFree(c->h_sc);
     if (c->h_sf) (void)hipHostFree(c->h_sf);
     if (c->rccl_comm && c->rccl_comm_destroy) (void)c->rccl_comm_destroy(c->rccl_comm);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1551,10 +1554,13 @@ extern "C" int chicdiff_hip_independent_filtering_dev(chicdiff_hip_ctx *c, const
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_aux(c, if_workspace_bytes(n));
     if (rc) return rc;
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (!c->ev_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     timing_reset(c);
     {
         Scope t(c, "independent_filtering");
-        if (run_independent_filtering(d_baseMean, d_pvalue, n, alpha, d_padj, c->aux, c->stream, info))
+        if (run_independent_filtering(d_baseMean, d_pvalue, n, alpha, d_padj, c->aux, c->stream, c->copy_stream, c->ev_fork, c->ev_join, info))
             return fail(c, CHICDIFF_E_HIP, "independent_filtering: %s", hipGetErrorString(hipGetLastError()));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -115,7 +115,7 @@ void launch_cooks_filter(const int32_t *counts, int64_t n, int S, int p, const d
                          double cutoff, double *pvalue, unsigned long long *nout, hipStream_t st);
 size_t if_workspace_bytes(int64_t n);
 int run_independent_filtering(const double *d_bm, const double *d_p, int64_t n, double alpha, double *d_padj, char *ws, hipStream_t st,
-                              chicdiff_results_info *info);  // synchronises (three small read-backs)
+                              hipStream_t st2, hipEvent_t fork, hipEvent_t join, chicdiff_results_info *info);  // synchronises (three small read-backs)
 size_t ct_workspace_bytes(int64_t n);
 int launch_count_table(const int32_t *bait, const int32_t *oe, const int32_t *N, int64_t n, const uint8_t *keep, int32_t max_id,
                        int64_t *keys_out, int32_t *vals_out, char *ws, hipStream_t st);

@@ -598,8 +598,11 @@ size_t if_workspace_bytes(int64_t n) {
 }
 
 // returns 0 ok.  info: filterThreshold, filterTheta, index (1-based), theta[50], numRej[50], lowess[50]
+// st2 / fork / join: a second stream and two events of the caller's, so that the two independent sorts (baseMean keys
+// for the cutoffs, p-values for everything else — each a chain of ~20 small launches that does not fill the GPU at
+// 2 M rows) run side by side
 int run_independent_filtering(const double *d_bm, const double *d_p, int64_t n, double alpha, double *d_padj, char *ws, hipStream_t st,
-                              chicdiff_results_info *info) {
+                              hipStream_t st2, hipEvent_t fork, hipEvent_t join, chicdiff_results_info *info) {
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     const int nblocks = (int)((n + kIfBlock - 1) / kIfBlock);
     char *bh_ws = ws;
@@ -616,10 +619,12 @@ int run_independent_filtering(const double *d_bm, const double *d_p, int64_t n, 
     if (g < 1) g = 1;
     if (g > 2048) g = 2048;
     if (hipMemsetAsync(state, 0, sizeof(IfState), st) != hipSuccess) return 1;
-    // 1. lower = mean(baseMean == 0); cutoffs = quantile(baseMean, theta) (type 7)
-    if_keys_kernel<<<g, 256, 0, st>>>(d_bm, n, k0, state);
-    if (rocprim::radix_sort_keys(sort_tmp, sort_bytes, k0, k1, (size_t)n, 0, 64, st) != hipSuccess) return 1;
-    if_cuts_kernel<<<1, 64, 0, st>>>(k1, n, alpha, state);
+    // 1. lower = mean(baseMean == 0); cutoffs = quantile(baseMean, theta) (type 7) — on the second stream
+    if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess) return 1;
+    if_keys_kernel<<<g, 256, 0, st2>>>(d_bm, n, k0, state);
+    if (rocprim::radix_sort_keys(sort_tmp, sort_bytes, k0, k1, (size_t)n, 0, 64, st2) != hipSuccess) return 1;
+    if_cuts_kernel<<<1, 64, 0, st2>>>(k1, n, alpha, state);
+    if (hipEventRecord(join, st2) != hipSuccess) return 1;
     // 2. one sort by p-value (NA last) in the BH machinery's buffers, then the 50 filtered rejection counts
     //    (bh_ws layout: count | k0 | k1 | i0 | i1 | q | s — see launch_bh_adjust)
     uint64_t *pk0 = (uint64_t *)(bh_ws + 256), *pk1 = (uint64_t *)((char *)pk0 + al(8 * (size_t)n));
@@ -632,6 +637,7 @@ int run_independent_filtering(const double *d_bm, const double *d_p, int64_t n, 
                                   rocprim::minimum<double>(), st);
     bh_keys_kernel<<<g, 256, 0, st>>>(d_p, n, pk0, pi0, &state->count);
     if (rocprim::radix_sort_pairs(ptmp, psort, pk0, pk1, pi0, pi1, (size_t)n, 0, 64, st) != hipSuccess) return 1;
+    if (hipStreamWaitEvent(st, join, 0) != hipSuccess) return 1;  // the cutoffs are there
     if_count_kernel<<<nblocks, kIfBlock, 0, st>>>(pi1, d_bm, n, state, T, blockcnt, nblocks);
     if_scan_kernel<<<kIfN, 1024, 0, st>>>(blockcnt, nblocks, state);
     if_rej_kernel<<<nblocks, kIfBlock, 0, st>>>(pk1, T, n, blockcnt, nblocks, alpha, state);
