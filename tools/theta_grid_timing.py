@@ -11,6 +11,9 @@ dk = ctx.to_device(d["counts"], np.int32)
 dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)
 sf = ctx.size_factors(dk)
 grid = [0.0, 0.25, 0.5, 0.75, 1.0]
+for kv in sys.argv[3:]:
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
 for lanes in (1, 2, 3, 5):
     ctx.set_option("theta_grid_concurrency", lanes)
     ctx.theta_grid(dk, dfm, sf, grid)
