@@ -18,8 +18,12 @@ g.manual_seed(1)
 n, F = 2_000_000, 11
 keys = torch.unique(torch.randint(0, 2 ** 40, (int(n * F * dens),), dtype=torch.int64, device=dev, generator=g))
 vals = torch.randint(1, 100, (keys.numel(),), dtype=torch.int32, device=dev, generator=g)
-qk = keys[torch.randint(0, keys.numel(), (n * F,), device=dev, generator=g)]
-qk = torch.sort(torch.where(torch.rand(n * F, device=dev, generator=g) < 0.5, qk + 1, qk)).values
+if len(sys.argv) > 3 and sys.argv[3] == "regions":  # RU as Chicdiff builds it: runs of F consecutive other-end IDs around a peak
+    peak = keys[torch.randint(0, keys.numel(), (n,), device=dev, generator=g)]
+    qk = torch.sort((peak[:, None] + torch.arange(-(F // 2), F // 2 + 1, device=dev)[None, :]).reshape(-1)).values
+else:
+    qk = keys[torch.randint(0, keys.numel(), (n * F,), device=dev, generator=g)]
+    qk = torch.sort(torch.where(torch.rand(n * F, device=dev, generator=g) < 0.5, qk + 1, qk)).values
 bait, oe = (qk >> 32).to(torch.int32), (qk & 0xFFFFFFFF).to(torch.int32)
 ctx.enable_timing(True)
 ctx.count_join(bait, oe, keys, vals)
