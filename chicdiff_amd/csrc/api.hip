@@ -1446,6 +1446,45 @@ extern "C" int chicdiff_hip_count_table_dev(chicdiff_hip_ctx *c, const int32_t *
     return CHICDIFF_OK;
 }
 
+// IHWcorrection's covariate (chicdiff.R:1965-1967): per-region mean of distSign over the CSR of RU rows
+extern "C" int chicdiff_hip_region_avdist_dev(chicdiff_hip_ctx *c, const int32_t *d_ru_bait, const int32_t *d_ru_oe, int64_t nru,
+                                              const int64_t *d_region_ptr, int64_t n, int32_t id_min, int32_t nid,
+                                              const int64_t *d_midsum, const int32_t *d_chr, double *d_avDist) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_region_ptr || !d_midsum || !d_avDist || n < 1 || nru < 0 || nid < 1 || (nru > 0 && (!d_ru_bait || !d_ru_oe)))
+        return fail(c, CHICDIFF_E_INVALID, "region_avdist: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    {
+        Scope t(c, "region_avdist");
+        launch_region_avdist(d_ru_bait, d_ru_oe, d_region_ptr, n, id_min, nid, d_midsum, d_chr, d_avDist, c->stream);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return CHICDIFF_OK;
+}
+
+// a1 without chinput files (chicdiff.R:774-807): N of every RU row from the replicates' Chicago tables, inner-merged
+extern "C" int chicdiff_hip_count_join_inner_dev(chicdiff_hip_ctx *c, const int32_t *d_ru_bait, const int32_t *d_ru_oe, int64_t nru,
+                                                 int32_t S, const int64_t *const *d_keys, const int32_t *const *d_vals,
+                                                 const int64_t *nkeys, int32_t *d_out) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_ru_bait || !d_ru_oe || !d_out || !d_keys || !d_vals || !nkeys || nru < 0 || S < 1 || S > kMaxS)
+        return fail(c, CHICDIFF_E_INVALID, "count_join_inner: bad arguments");
+    for (int s = 0; s < S; s++)
+        if (nkeys[s] < 0 || (nkeys[s] > 0 && (!d_keys[s] || !d_vals[s])))
+            return fail(c, CHICDIFF_E_INVALID, "count_join_inner: bad table %d", s);
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    if (nru > 0) {
+        Scope t(c, "count_join_inner");
+        launch_count_join_inner(d_ru_bait, d_ru_oe, nru, S, d_keys, d_vals, nkeys, d_out, c->stream);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return CHICDIFF_OK;
+}
+
 // host-side self test of the .chinput parser (no device, no context): the three columns of up to `cap` rows
 extern "C" int chicdiff_hip_selftest_chinput(const char *path, int32_t nthreads, int64_t cap, int32_t *bait, int32_t *oe, int32_t *N,
                                              int64_t *nrows, char *err, int32_t errcap) {
@@ -1478,7 +1517,12 @@ extern "C" int chicdiff_hip_chinput_read(chicdiff_hip_ctx *c, const char *path, 
 extern "C" int chicdiff_hip_chinput_table_dev(chicdiff_hip_ctx *c, const uint8_t *d_bait_in_RU, int32_t max_id, int64_t *d_keys,
                                               int32_t *d_vals, int64_t *nkeys_host) {
     if (!c) return CHICDIFF_E_INVALID;
-    if (!c->chin || c->chin->bait.empty()) return fail(c, CHICDIFF_E_INVALID, "chinput_table: no rows read (call chicdiff_hip_chinput_read first)");
+    if (!c->chin) return fail(c, CHICDIFF_E_INVALID, "chinput_table: nothing read (call chicdiff_hip_chinput_read first)");
+    if (!nkeys_host) return fail(c, CHICDIFF_E_INVALID, "chinput_table: bad arguments");
+    if (c->chin->bait.empty()) {  // a header without data rows: fread gives an empty table, merge(all.x = TRUE) then N = 0 for every RU row
+        *nkeys_host = 0;
+        return CHICDIFF_OK;
+    }
     const size_t n = c->chin->bait.size(), col = align256(sizeof(int32_t) * n);
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_io(c, 3 * col, 0);

@@ -313,6 +313,89 @@ void launch_ru_fill(const int32_t *bait, const int32_t *oe, int64_t n, int s, co
     ru_fill_kernel<<<blocks, 256, 0, st>>>(bait, oe, n, s, chr_of, maxfrag, region_ptr, ru_bait, ru_region, ru_oe);
 }
 
+
+// ---- IHWcorrection's covariate: avDist = mean(distSign) by regionID (chicdiff.R:1965-1967, :1980-1982) ----------------
+// The reference takes it from the long "recast" table (one row per region, fragment and sample — 176 M rows at 2 M
+// regions x 8 samples, 3.5 G at 20 M x 16): RU.recast[, list(avDist = mean(distSign)), by = "regionID"].  Every
+// (region, fragment) pair appears once per sample there with the same distSign, so the mean over the table is the mean
+// over the region's fragments.  distSign is the one of CountOut (chicdiff.R:868-882): midpoint := round(0.5 * (start +
+// end)) per fragment (R's round(): half to even), distSign := midpoint[otherEndID] - midpoint[baitID], NA when the two
+// fragments lie on different chromosomes.  Sums of integers below 2^53 are exact, so one division gives R's mean().
+// One thread per region over the CSR of (regionID, otherEndID)-ordered RU rows; the midpoint table is L2-resident.
+__global__ __launch_bounds__(256) void region_avdist_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
+                                                            const int64_t *__restrict__ ptr, int64_t n, int32_t id_min, int32_t nid,
+                                                            const int64_t *__restrict__ midsum, const int32_t *__restrict__ chr,
+                                                            double *__restrict__ avDist) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t lo = ptr[i], hi = ptr[i + 1];
+        double sum = 0.0;
+        int64_t cnt = 0;
+        bool na = false;
+        for (int64_t r = lo; r < hi; r++) {
+            const int32_t b = bait[r] - id_min, o = oe[r] - id_min;
+            if (b < 0 || b >= nid || o < 0 || o >= nid || (chr && (chr[b] < 0 || chr[o] < 0)))
+                continue;  // a fragment the map does not hold: merge(x, rmap) drops the row (chicdiff.R:873-874)
+            cnt++;
+            if (chr && chr[b] != chr[o]) na = true;  // ifelse(chr.x == chr.y, ., NA), :877-880; mean() has no na.rm
+            sum += rint(0.5 * (double)midsum[o]) - rint(0.5 * (double)midsum[b]);
+        }
+        avDist[i] = (na || cnt == 0) ? NAN : sum / (double)cnt;
+    }
+}
+void launch_region_avdist(const int32_t *bait, const int32_t *oe, const int64_t *ptr, int64_t n, int32_t id_min, int32_t nid,
+                          const int64_t *midsum, const int32_t *chr, double *avDist, hipStream_t st) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    region_avdist_kernel<<<blocks, 256, 0, st>>>(bait, oe, ptr, n, id_min, nid, midsum, chr, avDist);
+}
+
+// ---- a1, no-chinput branch (chicdiff.R:774-807, = :1202-1260 in getFullRegionData2) ------------------------------------
+// Without chinput files N comes from the Chicago objects: tempForCounts[[i]] = x[, c(baitID, otherEndID, N)] keyed by
+// (baitID, otherEndID); mergedFiles <- Reduce(merge, tempForCounts) is an INNER join over the replicates (merge()'s
+// default), so a pair survives only when every replicate's object holds it; then per replicate merge(RU, ., all.x = TRUE)
+// and N[is.na(N)] <- 0.  Net effect per RU row: its N in every replicate when all S tables hold the pair, 0 in every
+// replicate otherwise.  One thread per RU row, S lower-bound searches in global memory: this is the fallback path (the
+// chinput path is the tuned count_join_kernel), 22 M rows x 8 tables x ~24 probes is a few milliseconds.
+struct JoinInnerArgs {
+    const int64_t *keys[64];
+    const int32_t *vals[64];
+    int64_t nkeys[64];
+};
+__global__ __launch_bounds__(256) void count_join_inner_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
+                                                               int64_t nru, int S, JoinInnerArgs a, int32_t *__restrict__ out) {
+    for (int64_t r = blockIdx.x * 256 + threadIdx.x; r < nru; r += (int64_t)gridDim.x * 256) {
+        const int64_t key = ((int64_t)bait[r] << 32) | (uint32_t)oe[r];
+        bool all = true;
+        for (int s = 0; s < S; s++) {
+            const int64_t *k = a.keys[s];
+            int64_t lo = 0, hi = a.nkeys[s];
+            while (lo < hi) {
+                const int64_t mid = lo + ((hi - lo) >> 1);
+                if (k[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            const bool hit = lo < a.nkeys[s] && k[lo] == key;
+            out[(int64_t)s * nru + r] = hit ? a.vals[s][lo] : 0;
+            all = all && hit;
+        }
+        if (!all)
+            for (int s = 0; s < S; s++) out[(int64_t)s * nru + r] = 0;
+    }
+}
+void launch_count_join_inner(const int32_t *bait, const int32_t *oe, int64_t nru, int S, const int64_t *const *keys,
+                             const int32_t *const *vals, const int64_t *nkeys, int32_t *out, hipStream_t st) {
+    JoinInnerArgs a;
+    for (int s = 0; s < 64; s++) {
+        a.keys[s] = s < S ? keys[s] : nullptr;
+        a.vals[s] = s < S ? vals[s] : nullptr;
+        a.nkeys[s] = s < S ? nkeys[s] : 0;
+    }
+    int blocks = (int)((nru + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    count_join_inner_kernel<<<blocks, 256, 0, st>>>(bait, oe, nru, S, a, out);
+}
+
 }  // namespace cd
 
 // ================================================================================================================

@@ -85,6 +85,15 @@ def DESeq2Wrap(chicdiff_settings, RU, FullRegionData, suffix="", theta=None, ctx
 
     from . import hip
 
+    from .settings import asChicdiffSettings, hipDevice
+
+    if chicdiff_settings.get("norm") is not None:
+        nm = chicdiff_settings["norm"]
+        nm = nm[0] if isinstance(nm, (list, tuple)) and len(nm) == 1 else nm
+        if str(nm) not in ("standard", "fullmean", "combined"):
+            raise ValueError("DESeq2Wrap error: Unknown normalisation method.")   # chicdiff.R:1507-1509
+    # the reference's list, unchanged: every one of its 17 keys keeps its meaning (`device` = plot device, chicdiff.R:20)
+    chicdiff_settings = asChicdiffSettings({k: v for k, v in chicdiff_settings.items()})
     Grid = list(chicdiff_settings["theta_grid"])
     rmapfile = chicdiff_settings["rmapfile"]
     save_rds = chicdiff_settings.get("saveAuxData", False)
@@ -94,8 +103,6 @@ def DESeq2Wrap(chicdiff_settings, RU, FullRegionData, suffix="", theta=None, ctx
         theta = chicdiff_settings["theta"]
 
     norm = chicdiff_settings["norm"]
-    if norm not in ("standard", "fullmean", "combined"):
-        raise ValueError("DESeq2Wrap error: Unknown normalisation method.")
 
     if theta is not None:
         if theta == 1 and norm != "standard":
@@ -109,7 +116,7 @@ def DESeq2Wrap(chicdiff_settings, RU, FullRegionData, suffix="", theta=None, ctx
 
     own_ctx = ctx is None
     if own_ctx:
-        ctx = hip.HipContext(0)
+        ctx = hip.HipContext(hipDevice(chicdiff_settings))   # the new key `hipDevice`; never the reference's `device`
     torch = ctx.torch
     try:
         from .post import HipRegionData
@@ -176,13 +183,18 @@ def DESeq2Wrap(chicdiff_settings, RU, FullRegionData, suffix="", theta=None, ctx
 
         message("Processing model output")
         rmap = _read_rmap(rmapfile)
-        ru = RU.groupby("regionID", sort=True).agg(baitID=("baitID", "first"), minOE=("otherEndID", "min"),
-                                                   maxOE=("otherEndID", "max")).reset_index()
+        if isinstance(RU, dict) and "region_ptr" in RU:   # pipeline.RegionUniverse: the CSR view already holds min / max per region
+            mn, mx = RU["minOE"].cpu().numpy(), RU["maxOE"].cpu().numpy()
+            ru = pd.DataFrame({"regionID": np.arange(1, len(mn) + 1), "baitID": RU["peak_baitID"], "minOE": mn, "maxOE": mx})
+            ru = ru[ru["minOE"] != np.iinfo(np.int32).min]   # a region without any fragment left has no RU row
+        else:
+            ru = RU.groupby("regionID", sort=True).agg(baitID=("baitID", "first"), minOE=("otherEndID", "min"),
+                                                       maxOE=("otherEndID", "max")).reset_index()
         anno = ru.merge(rmap[["otherEndID", "OEchr", "OEstart"]], left_on="minOE", right_on="otherEndID").drop(columns="otherEndID")
         anno = anno.merge(rmap[["otherEndID", "OEend"]], left_on="maxOE", right_on="otherEndID").drop(columns="otherEndID")
         bait = rmap.rename(columns={"OEchr": "baitchr", "OEstart": "baitstart", "OEend": "baitend", "otherEndID": "baitID"})
         anno = anno.merge(bait, on="baitID").sort_values("regionID", kind="stable").reset_index(drop=True)
-        if not np.array_equal(anno["regionID"].to_numpy(), np.arange(1, n + 1)):
+        if len(anno) != n or not np.array_equal(anno["regionID"].to_numpy(), np.arange(1, n + 1)):
             raise AssertionError("identical(1:nrow(annoData), annoData$regionID) is not TRUE")
 
         # results(): Cook's cutoff, independent filtering, BH (a9) — on the device

@@ -27,7 +27,8 @@ EXPORTS = [
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
     "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
-    "chicdiff_hip_chinput_read", "chicdiff_hip_chinput_table_dev",
+    "chicdiff_hip_chinput_read", "chicdiff_hip_chinput_table_dev", "chicdiff_hip_region_avdist_dev",
+    "chicdiff_hip_count_join_inner_dev",
     "chicdiff_hip_malloc", "chicdiff_hip_free", "chicdiff_hip_memcpy_h2d", "chicdiff_hip_memcpy_d2h",
     "chicdiff_hip_rccl_unique_id", "chicdiff_hip_rccl_init", "chicdiff_hip_cooks_filter_dev",
     "chicdiff_hip_independent_filtering_dev",
@@ -120,6 +121,8 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_chinput_read.argtypes = [vp, C.c_char_p, i32, C.POINTER(i64)]
     L.chicdiff_hip_chinput_table_dev.argtypes = [vp, vp, i32, vp, vp, C.POINTER(i64)]
     L.chicdiff_hip_bh_adjust_dev.argtypes = [vp, vp, i64, vp]
+    L.chicdiff_hip_region_avdist_dev.argtypes = [vp, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp]
+    L.chicdiff_hip_count_join_inner_dev.argtypes = [vp, vp, vp, i64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]
     L.chicdiff_hip_ihw_apply_dev.argtypes = [vp, vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl), i32, vp, vp, vp, vp]
     L.chicdiff_hip_region_universe_count_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, C.POINTER(i64)]
     L.chicdiff_hip_region_universe_fill_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, vp]
@@ -296,6 +299,30 @@ class HipContext:
         self._check(self.lib.chicdiff_hip_count_join_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), d_bait.numel(),
                                                          d_keys.data_ptr(), d_vals.data_ptr(), d_keys.numel(),
                                                          out.data_ptr()))
+        return out
+
+    def count_join_inner(self, d_bait, d_oe, tables):
+        """No-chinput branch (chicdiff.R:774-807): ``tables`` = [(keys, vals)] per replicate (device tensors as
+        ``count_table`` returns them); N (S, nru) with the reference's Reduce(merge) semantics — a pair keeps its
+        counts only when every replicate's table holds it."""
+        S, nru = len(tables), d_bait.numel()
+        out = self.torch.empty((S, nru), dtype=self.torch.int32, device=self.device)
+        kp = (C.c_void_p * S)(*[k.data_ptr() for k, _ in tables])
+        vp_ = (C.c_void_p * S)(*[v.data_ptr() for _, v in tables])
+        nk = (C.c_int64 * S)(*[k.numel() for k, _ in tables])
+        self._check(self.lib.chicdiff_hip_count_join_inner_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), nru, S, kp, vp_, nk,
+                                                               out.data_ptr()))
+        return out
+
+    def region_avdist(self, d_bait, d_oe, d_region_ptr, id_min, d_midsum, d_chr=None):
+        """avDist = mean(distSign) by regionID (chicdiff.R:1965-1967, :868-882) for CSR-ordered RU rows: the covariate
+        IHWcorrection() takes from the long table."""
+        n = d_region_ptr.numel() - 1
+        out = self.torch.empty(n, dtype=self.torch.float64, device=self.device)
+        self._check(self.lib.chicdiff_hip_region_avdist_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), d_bait.numel(),
+                                                            d_region_ptr.data_ptr(), n, int(id_min), d_midsum.numel(),
+                                                            d_midsum.data_ptr(), d_chr.data_ptr() if d_chr is not None else None,
+                                                            out.data_ptr()))
         return out
 
     # -- a3 ---------------------------------------------------------------------------------

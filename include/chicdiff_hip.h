@@ -170,6 +170,31 @@ int chicdiff_hip_count_join_dev(chicdiff_hip_ctx *ctx, const int32_t *d_ru_bait,
                                 int64_t nru, const int64_t *d_keys, const int32_t *d_vals, int64_t nkeys,
                                 int32_t *d_out);
 
+/* a1, branch without chinput files (chicdiff.R:774-807, = :1202-1260 in getFullRegionData2): N comes from the
+ * replicates' Chicago objects.  tempForCounts[[i]] = x[, c("baitID", "otherEndID", "N")] per replicate;
+ * mergedFiles <- Reduce(merge, tempForCounts) is merge()'s default INNER join on (baitID, otherEndID), so a pair keeps its
+ * counts only when every replicate's table holds it; then merge(RU, ., all.x = TRUE) and N[is.na(N)] <- 0 per replicate.
+ * d_keys / d_vals / nkeys are HOST arrays of S entries: one sorted key table per replicate as chicdiff_hip_count_table_dev
+ * builds it (device pointers inside).  d_out is nru x S (column s = replicate s). */
+int chicdiff_hip_count_join_inner_dev(chicdiff_hip_ctx *ctx, const int32_t *d_ru_bait, const int32_t *d_ru_oe, int64_t nru,
+                                      int32_t S, const int64_t *const *d_keys, const int32_t *const *d_vals,
+                                      const int64_t *nkeys, int32_t *d_out);
+
+/* IHWcorrection's covariate (chicdiff.R:1965-1967 for the test set, :1980-1982 for the control set):
+ *   RU.distances <- RU.recast[, list(avDist = mean(distSign)), by = "regionID"]
+ * over the long table.  Every (region, fragment) row is repeated once per sample there with the same distSign, so this is
+ * the mean over the region's RU rows of CountOut's distSign (chicdiff.R:868-882):
+ *   midpoint <- round(0.5 * (start + end))  (per fragment; R's round(), half to even)
+ *   distSign <- midpoint[otherEndID] - midpoint[baitID], NA when the fragments lie on different chromosomes.
+ * RU rows [d_region_ptr[i], d_region_ptr[i+1]) belong to region i (the CSR chicdiff_hip_region_universe_count_dev
+ * returns, or (regionID, otherEndID)-ordered RU rows of any origin).  d_midsum[nid] = start + end of fragment id_min + k;
+ * d_chr[nid] = chromosome code (-1 = ID not on the map: such rows are dropped, as merge(x, rmap) drops them) or NULL =
+ * all rows cis and on the map.  d_avDist[n]; NaN = NA (a trans row, or no row left).  Pinned by the reference's own
+ * result table: its avDist column is reproduced exactly on all 24 863 regions (tests/test_results_postprocessing.py). */
+int chicdiff_hip_region_avdist_dev(chicdiff_hip_ctx *ctx, const int32_t *d_ru_bait, const int32_t *d_ru_oe, int64_t nru,
+                                   const int64_t *d_region_ptr, int64_t n, int32_t id_min, int32_t nid,
+                                   const int64_t *d_midsum, const int32_t *d_chr, double *d_avDist);
+
 /* a3 — per-fragment background, the offset ingredients (chicdiff.R:628-703, 894-896 and Chicago's
  * .estimateBMean/.distFun): for every RU row r = (bait, oe) and replicate s
  *   distSign = round(((start+end)[oe] - (start+end)[bait]) / 2)                         (:648)

@@ -216,3 +216,59 @@ int64_t oracle_region_universe(const int32_t *bait, const int32_t *oe, int64_t n
     if (region_ptr) region_ptr[n] = pos;
     return pos;
 }
+
+/* IHWcorrection's covariate, chicdiff.R:1965-1967 (test set) / :1980-1982 (control set):
+ *   RU.distances <- RU.recast[, list(avDist = mean(distSign)), by = "regionID"]
+ * with the long table's distSign from chicdiff.R:868-882:
+ *   rmap[, midpoint := round(0.5 * (start + end))]                              (:871; R's round(): half to even)
+ *   x <- merge(x, rmap, by.x = "otherEndID", ...); x <- merge(x, rmap, by.x = "baitID", ...)   (:873-874: inner joins —
+ *        a row whose fragment the map does not hold is dropped)
+ *   distSign := ifelse(chr.x == chr.y, midpoint.x - midpoint.y, NA)              (:877-880; .x = other end, .y = bait)
+ * The long table repeats every (region, fragment) row once per sample, so its mean equals the mean over the region's
+ * RU rows; mean() without na.rm is NA as soon as one row is NA.  Rows [region_ptr[i], region_ptr[i+1]) = region i.
+ * Pinned by the reference's own result table (avDist column, 24 863 regions, exact: tests/test_results_postprocessing.py). */
+int oracle_region_avdist(const int32_t *ru_bait, const int32_t *ru_oe, const int64_t *region_ptr, int64_t n, int32_t id_min,
+                         int32_t nid, const int64_t *midsum, const int32_t *chr, double *avDist) {
+    for (int64_t i = 0; i < n; i++) {
+        long double sum = 0; /* data.table's gmean accumulates in long double */
+        int64_t cnt = 0;
+        int na = 0;
+        for (int64_t r = region_ptr[i]; r < region_ptr[i + 1]; r++) {
+            const int32_t b = ru_bait[r] - id_min, o = ru_oe[r] - id_min;
+            if (b < 0 || b >= nid || o < 0 || o >= nid) continue;
+            if (chr && (chr[b] < 0 || chr[o] < 0)) continue;
+            cnt++;
+            if (chr && chr[b] != chr[o]) { na = 1; continue; }
+            const double mo = nearbyint(0.5 * (double)midsum[o]), mb = nearbyint(0.5 * (double)midsum[b]);
+            sum += (long double)(mo - mb);
+        }
+        avDist[i] = (na || cnt == 0) ? NAN : (double)(sum / (long double)cnt);
+    }
+    return 0;
+}
+
+/* a1 without chinput files, chicdiff.R:774-807 (getFullRegionData1) = :1202-1260 (getFullRegionData2):
+ *   tempForCounts[[i]] <- x[, c("baitID", "otherEndID", "N")], keyed (baitID, otherEndID)              (:742-747)
+ *   mergedFiles <- Reduce(merge, tempForCounts)        -- merge() default: INNER join over the replicates (:779)
+ *   countData[[i]] <- mergedFiles[, c(baitID, otherEndID, N.i)][J(baits), ]                            (:782-787)
+ *   x <- merge(x, temp, all.x = TRUE); x[is.na(N), N := 0]                                             (:799-800)
+ * keys[s] ascending (baitID << 32 | otherEndID), one table per replicate; out is nru x S column-major. */
+int oracle_count_join_inner(const int32_t *ru_bait, const int32_t *ru_oe, int64_t nru, int32_t S, const int64_t *const *keys,
+                            const int32_t *const *vals, const int64_t *nkeys, int32_t *out) {
+    for (int64_t r = 0; r < nru; r++) {
+        const int64_t key = ((int64_t)ru_bait[r] << 32) | (uint32_t)ru_oe[r];
+        int all = 1;
+        for (int s = 0; s < S; s++) {
+            int64_t lo = 0, hi = nkeys[s];
+            while (lo < hi) {
+                const int64_t mid = lo + ((hi - lo) >> 1);
+                if (keys[s][mid] < key) lo = mid + 1; else hi = mid;
+            }
+            if (lo < nkeys[s] && keys[s][lo] == key) out[(int64_t)s * nru + r] = vals[s][lo];
+            else all = 0;
+        }
+        if (!all)
+            for (int s = 0; s < S; s++) out[(int64_t)s * nru + r] = 0;
+    }
+    return 0;
+}

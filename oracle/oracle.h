@@ -162,6 +162,14 @@ int oracle_ihw_apply(const double *avDist, const double *pvalue, int64_t n, cons
 int64_t oracle_region_universe(const int32_t *bait, const int32_t *oe, int64_t n, int32_t s, const int32_t *chr_of,
                                int32_t maxfrag, int64_t *region_ptr, int32_t *ru_bait, int32_t *ru_region, int32_t *ru_oe);
 
+/* IHWcorrection's covariate: per-region mean of distSign, chicdiff.R:1965-1967 + :868-882 (see chicdiff_oracle.c) */
+int oracle_region_avdist(const int32_t *ru_bait, const int32_t *ru_oe, const int64_t *region_ptr, int64_t n, int32_t id_min,
+                         int32_t nid, const int64_t *midsum, const int32_t *chr, double *avDist);
+
+/* a1 without chinput files: Reduce(merge) over the replicates' Chicago tables, chicdiff.R:774-807 (see chicdiff_oracle.c) */
+int oracle_count_join_inner(const int32_t *ru_bait, const int32_t *ru_oe, int64_t nru, int32_t S, const int64_t *const *keys,
+                            const int32_t *const *vals, const int64_t *nkeys, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

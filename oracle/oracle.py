@@ -100,6 +100,9 @@ def lib():
         L.oracle_r_qnorm.argtypes = [C.c_double]
         L.oracle_ihw_apply.argtypes = [_PD, _PD, C.c_int64, _PD, _PD, C.c_int32, _PI, _PD, _PD, _PD]
         L.oracle_region_universe.restype = C.c_int64
+        L.oracle_region_avdist.argtypes = [_PI, _PI, C.POINTER(C.c_int64), C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _PI, _PD]
+        L.oracle_count_join_inner.argtypes = [_PI, _PI, C.c_int64, C.c_int32, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(_PI),
+                                              C.POINTER(C.c_int64), _PI]
         L.oracle_region_universe.argtypes = [_PI, _PI, C.c_int64, C.c_int32, _PI, C.c_int32, P64, _PI, _PI, _PI]
         _lib = L
     return _lib
@@ -311,6 +314,37 @@ def region_universe(bait, oe, RUexpand, chr_of):
     rb, rr, ro = (np.empty(total, dtype=np.int32) for _ in range(3))
     lib().oracle_region_universe(_pi(b), _pi(o), n, int(RUexpand), _pi(c), maxfrag, ptr.ctypes.data_as(P64), _pi(rb), _pi(rr), _pi(ro))
     return ptr, rb, rr, ro
+
+
+def region_avdist(ru_bait, ru_oe, region_ptr, id_min, midsum, chr_codes=None):
+    """IHWcorrection's avDist = mean(distSign) by regionID (chicdiff.R:1965-1967, :868-882) over CSR-ordered RU rows."""
+    b = np.ascontiguousarray(ru_bait, dtype=np.int32)
+    o = np.ascontiguousarray(ru_oe, dtype=np.int32)
+    ptr = np.ascontiguousarray(region_ptr, dtype=np.int64)
+    ms = np.ascontiguousarray(midsum, dtype=np.int64)
+    ch = None if chr_codes is None else np.ascontiguousarray(chr_codes, dtype=np.int32)
+    n = len(ptr) - 1
+    out = np.empty(n)
+    P64 = C.POINTER(C.c_int64)
+    lib().oracle_region_avdist(_pi(b), _pi(o), ptr.ctypes.data_as(P64), n, int(id_min), len(ms), ms.ctypes.data_as(P64),
+                               None if ch is None else _pi(ch), _pd(out))
+    return out
+
+
+def count_join_inner(ru_bait, ru_oe, tables):
+    """No-chinput branch (chicdiff.R:774-807): ``tables`` = [(keys, vals)] per replicate; returns N (nru, S)."""
+    b = np.ascontiguousarray(ru_bait, dtype=np.int32)
+    o = np.ascontiguousarray(ru_oe, dtype=np.int32)
+    S, nru = len(tables), len(b)
+    ks = [np.ascontiguousarray(k, dtype=np.int64) for k, _ in tables]
+    vs = [np.ascontiguousarray(v, dtype=np.int32) for _, v in tables]
+    P64 = C.POINTER(C.c_int64)
+    kp = (P64 * S)(*[k.ctypes.data_as(P64) for k in ks])
+    vp = (_PI * S)(*[_pi(v) for v in vs])
+    nk = (C.c_int64 * S)(*[len(k) for k in ks])
+    out = np.empty((S, nru), dtype=np.int32)
+    lib().oracle_count_join_inner(_pi(b), _pi(o), nru, S, kp, vp, nk, _pi(out))
+    return out.T.copy()
 
 
 def count_table(bait, oe, N, bait_in_RU=None):

@@ -6,7 +6,8 @@
 ## attr "theta" as :1759-1760).  With chicdiff.settings[["backend"]] == "hip" the DESeq2 hand-off of
 ## chicdiff.R:1540-1691 (+ results(), :1720-1750) runs in libchicdiff_hip.so through the .Call routines of
 ## r/src/chicdiff_hip_shim.c; with any other value the reference's own body runs (the maintainer keeps it under the
-## name .DESeq2WrapReference, see INTEGRATION.md).  New optional settings: backend ("hip"), device (GPU index, 0).
+## name .DESeq2WrapReference, see INTEGRATION.md).  New optional settings: backend ("hip"), hipDevice (GPU index, default 0;
+## NOT `device`, which is the reference's plot device "png", chicdiff.R:20), trendFallback ("mean").
 ##
 ## NOT run in this repository: there is no R in the authoring image or on the GPU box (SURVEY.md §0).  The tested
 ## twin with the same control flow is chicdiff_amd/deseq2wrap.py (pandas standing in for data.table).
@@ -126,7 +127,7 @@ DESeq2Wrap <- function(chicdiff.settings, RU, FullRegionData, suffix = "", theta
   rmapfile <- chicdiff.settings[["rmapfile"]]
   saveAux <- chicdiff.settings[["saveAuxData"]]
   outprefix <- chicdiff.settings[["outprefix"]]
-  device <- if (is.null(chicdiff.settings[["device"]])) 0L else as.integer(chicdiff.settings[["device"]])
+  device <- .hipDeviceIndex(chicdiff.settings)   # the new key `hipDevice` (r/R/getFullRegionData_hip.R); never `device`
 
   if (is.null(theta) & !is.null(chicdiff.settings[["theta"]])) theta <- chicdiff.settings[["theta"]]
 

@@ -1,24 +1,41 @@
 ## getFullRegionData_hip.R -- the step before DESeq2Wrap() with the MI355X backend behind it (SURVEY.md §8 f2, a1, a3).
 ##
-## getFullRegionDataHip(chicdiff.settings, RU, is_control = FALSE, suffix = "") does what the reference's
-## getFullRegionData1() (chicdiff.R:577-945) does for the chinput case, but never builds the long "recast" table
-## (one row per region, fragment and sample: 176 M rows at 2 M regions x 8 samples).  It returns a
-## "chicdiffHipRegionData" object that DESeq2Wrap() (r/R/DESeq2Wrap_hip.R) takes in place of FullRegionData:
-## per-sample fragment columns N and FullMean, resident on the device in (regionID, otherEndID) order, plus the
-## offsets of each region's first fragment.
+## Drop-in for the exported function of the reference (chicdiff.R:1460-1478):
+##     getFullRegionData(chicdiff.settings, RU, RUcontrol, suffix = "")
+## With chicdiff.settings[["backend"]] == "hip" it returns list(test, control, countput) like the reference, but the
+## first two entries are "chicdiffHipRegionData" blocks instead of the long "recast" tables (one row per region,
+## fragment and sample: 176 M rows at 2 M regions x 8 samples, 3.5 G at 20 M x 16): per-sample fragment columns N and
+## FullMean resident on the device in (regionID, otherEndID) order, the offsets of each region's first fragment, and
+## the per-region avDist that IHWcorrection() otherwise takes from the long table (chicdiff.R:1965).  DESeq2Wrap()
+## (r/R/DESeq2Wrap_hip.R) and IHWcorrection() (r/R/post_hip.R) accept the blocks in place of the tables.  Every
+## Chicago data set and every chinput file is read ONCE for both universes -- what parallel = TRUE
+## (getFullRegionData2, chicdiff.R:948-1456) does in the reference; the result does not depend on it.  With any other
+## backend the reference's own function runs (kept by the maintainer as .getFullRegionDataReference, INTEGRATION.md).
 ##
 ##   reference step                                              here
 ##   fread(chinput); setkey; x[J(baits)]        chicdiff.R:828-831   chicdiff_hip_chinput_table (host threads + device sort)
 ##   merge(x, temp, all.x = TRUE); N[NA] <- 0   chicdiff.R:843-858   chicdiff_hip_count_join
+##   no chinput: Reduce(merge, tempForCounts)   chicdiff.R:742-747, 774-807   chicdiff_hip_count_table + chicdiff_hip_count_join_inner
 ##   s_j / s_i / tblb / tlb / Tmean collection  chicdiff.R:656-692   .hipBackgroundTables (R: reads the Chicago objects)
 ##   .chicEstimateDistFun, .estimateBMean       chicdiff.R:538-573, 695-702   R lm() refit, then chicdiff_hip_fragment_background
 ##   FullMean := Bmean + Tmean                  chicdiff.R:896       chicdiff_hip_fragment_background
+##   distSign of CountOut, mean by regionID     chicdiff.R:868-882, 1965   chicdiff_hip_region_avdist
+##   countput                                   chicdiff.R:708-735, 754-769   the reference's own data.table statements
 ##
-## NOT run in this repository (no R in the authoring image or on the GPU box, SURVEY.md §0); the device routines it
-## calls are tested through the same C-ABI from Python (tests/test_gpu_parity.py: count table, count join, fragment
-## background on the reference's chr19 geometry, chinput ingestion).
+## NOT run in this repository (no R in the authoring image or on the GPU box, SURVEY.md §0); the tested twin with the
+## same control flow is chicdiff_amd/pipeline.py:getFullRegionData (tests/test_gpu_parity.py::test_chicdiffPipeline_*).
 
 .hipCall <- function(name, ...) .Call(name, ..., PACKAGE = "chicdiffhip")
+
+## GPU index of this R process: the NEW optional key `hipDevice` (default 0).  Never `device`: that key is the
+## reference's plot device ("png", chicdiff.R:20, used at :1960 and :2058).
+.hipDeviceIndex <- function(chicdiff.settings) {
+  d <- chicdiff.settings[["hipDevice"]]
+  if (is.null(d)) return(0L)
+  d <- suppressWarnings(as.integer(d))
+  if (length(d) != 1L || is.na(d) || d < 0L) stop("chicdiff.settings[[\"hipDevice\"]] must be one non-negative GPU index")
+  d
+}
 
 ## dense lookup tables over fragment IDs 1..nid for one Chicago data set `x` (a data.table with the columns of a
 ## chicagoData@x): first s_j / tblb per bait, first s_i / tlb per other end (chicdiff.R:656-672), the Tmean of every
@@ -42,46 +59,61 @@
        distfun = as.double(c(p$cubicFit[1:4], p$head.coef, p$tail.coef, p$obs.min, p$obs.max)))
 }
 
-getFullRegionDataHip <- function(chicdiff.settings, RU, is_control = FALSE, suffix = "") {
+## countput (chicdiff.R:708-735 per replicate, :754-769 afterwards): what plotDiffBaits() draws.  `xs`: the Chicago
+## tables, `conditions`: one label per replicate, `rmap`: data.table chr, start, end, ID.
+.hipCountput <- function(xs, conditions, rmap, outprefix) {
+  mid <- data.table::data.table(otherEndID = rmap$ID, midpoint = (rmap$start + rmap$end) / 2)
+  countput <- lapply(unique(conditions), function(cond) {
+    parts <- lapply(which(conditions == cond), function(i) {
+      x <- xs[[i]][!is.na(distSign)]
+      sc <- if ("newScore" %in% names(x)) "newScore" else "score"
+      x <- x[, c("baitID", "otherEndID", "N", "Bmean", sc), with = FALSE]
+      data.table::setnames(x, sc, "score")
+      merge(x, mid, by = "otherEndID")
+    })
+    z <- data.table::rbindlist(parts)
+    z <- z[, list(Nav = mean(N), Bav = mean(Bmean), score = max(score), midpoint = midpoint[1L]), by = c("baitID", "otherEndID")]
+    z[, condition := cond]
+    z
+  })
+  countput <- data.table::rbindlist(countput)
+  data.table::setnames(countput, "midpoint", "oeID_mid")
+  saveRDS(countput, paste0(outprefix, "_countput.Rds"))
+  countput
+}
+
+## RU in (regionID, otherEndID) order + the offsets of each region's first row: what the device kernels consume
+.hipRegionCSR <- function(RU) {
+  ru <- RU[order(regionID, otherEndID)]
+  ids <- unique(ru$regionID)
+  if (!identical(as.integer(ids), seq_along(ids)))
+    stop("identical(1:nrow(annoData), annoData$regionID) is not TRUE")  # what the reference's stopifnot says later (chicdiff.R:1717)
+  list(baitID = as.integer(ru$baitID), otherEndID = as.integer(ru$otherEndID), n = length(ids), nfrag = nrow(ru),
+       region_ptr = as.double(c(match(ids, ru$regionID) - 1L, nrow(ru))))
+}
+
+.getFullRegionDataHip <- function(chicdiff.settings, RU, RUcontrol, suffix = "") {
   countData <- chicdiff.settings[["countData"]]
   chicagoData <- chicdiff.settings[["chicagoData"]]
   rmapfile <- chicdiff.settings[["rmapfile"]]
-  device <- if (is.null(chicdiff.settings[["device"]])) 0L else as.integer(chicdiff.settings[["device"]])
-  if (is.null(countData)) stop("getFullRegionDataHip: the chinput files (countData) are required")
+  outprefix <- chicdiff.settings[["outprefix"]]
   targetRDSorRDAFiles <- unlist(chicagoData)
-  targetChFiles <- unlist(countData)
-  S <- length(targetChFiles)
-  if (length(targetRDSorRDAFiles) != S) stop("getFullRegionDataHip: one Chicago data set per chinput file expected")
-  condition <- rep(names(chicagoData), sapply(chicagoData, length))   # chicdiff.R:921-923
-
-  ## RU in (regionID, otherEndID) order: a region's fragments are consecutive and ascending, as the window sums need
-  ru <- RU[order(regionID, otherEndID)]
-  ids <- unique(ru$regionID)
-  if (!identical(as.integer(ids), seq_along(ids))) stop("RU: regionID must be 1..n without gaps")
-  nfrag <- nrow(ru); n <- length(ids)
-  region_ptr <- as.double(c(match(ids, ru$regionID) - 1L, nfrag))
-  baits <- sort(unique(ru$baitID))                                     # chicdiff.R:775
-
-  ctx <- .hipContext(device)
-  dBait <- .hipCall("chicdiff_hip_upload", ctx, as.integer(ru$baitID))
-  dOE <- .hipCall("chicdiff_hip_upload", ctx, as.integer(ru$otherEndID))
-  on.exit({ .hipCall("chicdiff_hip_release", dBait); .hipCall("chicdiff_hip_release", dOE) }, add = TRUE)
-
-  ## 2) read counts: one key table per replicate, joined onto RU straight into column i of the fragment matrix
-  fragN <- .hipCall("chicdiff_hip_alloc", ctx, "integer", as.double(nfrag) * S)
-  for (i in seq_len(S)) {
-    message("Reading count data for ", names(targetChFiles)[i])
-    tab <- .hipCall("chicdiff_hip_chinput_table", ctx, targetChFiles[i], as.integer(baits))
-    .hipCall("chicdiff_hip_count_join", ctx, dBait, dOE, tab, fragN, as.double(i - 1L))
-    .hipCall("chicdiff_hip_release", tab$keys); .hipCall("chicdiff_hip_release", tab$vals)
+  S <- length(targetRDSorRDAFiles)
+  haveChinput <- !is.null(countData) && !all(is.na(unlist(countData)))
+  if (haveChinput) {
+    targetChFiles <- unlist(countData)
+    if (length(targetChFiles) != S) stop("Must provide the same number of RDS/RDA files as chinputs")
   }
+  conditions <- rep(names(chicagoData), sapply(chicagoData, length))   # chicdiff.R:921-923
+  ctx <- .hipContext(.hipDeviceIndex(chicdiff.settings))
 
-  ## 1) interaction parameters: the per-fragment tables of every Chicago data set, then Bmean / Tmean / FullMean of
-  ##    every RU row on the device
   rmap <- data.table::fread(rmapfile)
   data.table::setnames(rmap, c("chr", "start", "end", "ID"))
   nid <- max(rmap$ID)
   midsum <- rep(NA_real_, nid); midsum[rmap$ID] <- as.double(rmap$start) + as.double(rmap$end)
+  chrcode <- rep(-1L, nid); chrcode[rmap$ID] <- as.integer(factor(rmap$chr)) - 1L
+
+  ## 1) the Chicago data sets, each read once: dispersion, per-fragment tables, countput, (no chinput:) the counts
   xs <- vector("list", S)
   dispersions <- numeric(S)
   for (i in seq_len(S)) {
@@ -89,19 +121,65 @@ getFullRegionDataHip <- function(chicdiff.settings, RU, is_control = FALSE, suff
     x <- readRDSorRDA(targetRDSorRDAFiles[i])
     if ("chicagoData" %in% class(x)) { dispersions[i] <- x@params$dispersion; x <- data.table::as.data.table(x@x) }
     else { dispersions[i] <- attributes(x)$dispersion; data.table::setDT(x) }
-    xs[[i]] <- x[, c("baitID", "otherEndID", "s_j", "s_i", "tblb", "tlb", "Tmean", "distbin", "refBinMean"), with = FALSE]
+    data.table::setkey(x, baitID, otherEndID)                          # chicdiff.R:630: "first per bait / other end" is in this order
+    xs[[i]] <- x
   }
   levB <- sort(unique(unlist(lapply(xs, function(x) as.character(x$tblb[!is.na(x$tblb)])))))
   levL <- sort(unique(unlist(lapply(xs, function(x) as.character(x$tlb[!is.na(x$tlb)])))))
   tabs <- lapply(xs, .hipBackgroundTables, nid = nid, levB = levB, levL = levL)
-  bg <- .hipCall("chicdiff_hip_fragment_background", ctx, dBait, dOE, 1L, midsum,
-                 unlist(lapply(tabs, function(t) t$sj)), unlist(lapply(tabs, function(t) t$si)),
-                 unlist(lapply(tabs, function(t) t$tblb)), unlist(lapply(tabs, function(t) t$tlb)),
-                 array(unlist(lapply(tabs, function(t) t$Tmean)), dim = c(length(levL), length(levB), S)),
-                 unlist(lapply(tabs, function(t) t$distfun)), S)
-  .hipCall("chicdiff_hip_release", bg$Bmean); .hipCall("chicdiff_hip_release", bg$Tmean)
+  message("Saving counts\n")
+  countput <- .hipCountput(xs, conditions, rmap, outprefix)
 
-  structure(list(samples = names(targetRDSorRDAFiles), condition = condition, S = S, n = n, fragN = fragN,
-                 fragFullMean = bg$FullMean, region_ptr = region_ptr, dispersions = dispersions, is_control = is_control),
-            class = "chicdiffHipRegionData")
+  ## 2) one key table per replicate, restricted to the baits of both universes (chicdiff.R:775, 828-831)
+  baits <- sort(unique(c(RU$baitID, RUcontrol$baitID)))
+  flags <- .hipCall("chicdiff_hip_bait_flags", ctx, as.integer(baits))   # built and uploaded once, not once per replicate
+  tables <- vector("list", S)
+  if (haveChinput) {
+    for (i in seq_len(S)) {
+      message("Reading count data for ", names(targetChFiles)[i])
+      tables[[i]] <- .hipCall("chicdiff_hip_chinput_table", ctx, targetChFiles[i], flags)
+    }
+  } else {
+    message("Reconstructing countData")                                # chicdiff.R:742-747, 774-787
+    for (i in seq_len(S))
+      tables[[i]] <- .hipCall("chicdiff_hip_count_table", ctx, as.integer(xs[[i]]$baitID), as.integer(xs[[i]]$otherEndID),
+                              as.integer(xs[[i]]$N), flags)
+  }
+  .hipCall("chicdiff_hip_release", flags)
+
+  ## 3) per universe: counts, Bmean + Tmean = FullMean, avDist -- all of them stay on the device
+  block <- function(ru, is_control) {
+    message(if (!is_control) "Reading data for significant interactions" else "\nReading data for control interactions")
+    csr <- .hipRegionCSR(ru)
+    dBait <- .hipCall("chicdiff_hip_upload", ctx, csr$baitID)
+    dOE <- .hipCall("chicdiff_hip_upload", ctx, csr$otherEndID)
+    on.exit({ .hipCall("chicdiff_hip_release", dBait); .hipCall("chicdiff_hip_release", dOE) }, add = TRUE)
+    if (haveChinput) {
+      fragN <- .hipCall("chicdiff_hip_alloc", ctx, "integer", as.double(csr$nfrag) * S)
+      for (i in seq_len(S)) .hipCall("chicdiff_hip_count_join", ctx, dBait, dOE, tables[[i]], fragN, as.double(i - 1L))
+    } else {
+      message("Merging countData")                                     # chicdiff.R:789-805: inner merge over the replicates
+      fragN <- .hipCall("chicdiff_hip_count_join_inner", ctx, dBait, dOE, tables)
+    }
+    bg <- .hipCall("chicdiff_hip_fragment_background", ctx, dBait, dOE, 1L, midsum,
+                   unlist(lapply(tabs, function(t) t$sj)), unlist(lapply(tabs, function(t) t$si)),
+                   unlist(lapply(tabs, function(t) t$tblb)), unlist(lapply(tabs, function(t) t$tlb)),
+                   array(unlist(lapply(tabs, function(t) t$Tmean)), dim = c(length(levL), length(levB), S)),
+                   unlist(lapply(tabs, function(t) t$distfun)), S)
+    .hipCall("chicdiff_hip_release", bg$Bmean); .hipCall("chicdiff_hip_release", bg$Tmean)
+    avDist <- .hipCall("chicdiff_hip_region_avdist", ctx, dBait, dOE, csr$region_ptr, 1L, midsum, chrcode)
+    structure(list(samples = names(targetRDSorRDAFiles), condition = conditions, S = S, n = csr$n, fragN = fragN,
+                   fragFullMean = bg$FullMean, region_ptr = csr$region_ptr, avDist = avDist, dispersions = dispersions,
+                   is_control = is_control),
+              class = "chicdiffHipRegionData")
+  }
+  out <- list(block(RU, FALSE), block(RUcontrol, TRUE), countput)
+  for (t in tables) { .hipCall("chicdiff_hip_release", t$keys); .hipCall("chicdiff_hip_release", t$vals) }
+  out
+}
+
+getFullRegionData <- function(chicdiff.settings, RU, RUcontrol, suffix = "") {
+  if (!identical(chicdiff.settings[["backend"]], "hip"))
+    return(.getFullRegionDataReference(chicdiff.settings, RU, RUcontrol, suffix = suffix))
+  .getFullRegionDataHip(chicdiff.settings, RU, RUcontrol, suffix = suffix)
 }

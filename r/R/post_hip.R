@@ -19,7 +19,7 @@ getRegionUniverse <- function(chicdiff.settings, suffix = "") {
   chicagoData <- chicdiff.settings[["chicagoData"]]
   saveAux <- chicdiff.settings[["saveAuxData"]]
   outprefix <- chicdiff.settings[["outprefix"]]
-  device <- if (is.null(chicdiff.settings[["device"]])) 0L else as.integer(chicdiff.settings[["device"]])
+  device <- .hipDeviceIndex(chicdiff.settings)   # the new key `hipDevice`; `device` stays the reference's plot device
 
   ## reading and filtering the peak matrix stays the reference's R (chicdiff.R:230-277)
   x <- readAndFilterPeakMatrix(peakFiles = chicdiff.settings[["peakfiles"]], score = chicdiff.settings[["score"]],
@@ -60,6 +60,79 @@ getRegionUniverse <- function(chicdiff.settings, suffix = "") {
   out[, weight := w$weight]
   out[, weighted_pvalue := w$weighted_pvalue]
   out[, weighted_padj := w$weighted_padj]
+  data.table::setcolorder(out, c("group", setdiff(names(out), "group")))   # merge(out, distLookup, by = "group") puts the key first
   data.table::setkey(out, group)
+  out
+}
+
+## IHWcorrection(), chicdiff.R:1956-2065, for the device path.  Same signature as the reference.  FullRegionData /
+## FullControlRegionData may be the "chicdiffHipRegionData" blocks of getFullRegionData(): the per-region covariate
+## avDist = mean(distSign) (chicdiff.R:1965-1967, :1980-1982) then comes from the device (chicdiff_hip_region_avdist)
+## instead of a group-by over the long table, and the application side (:2036-2049) runs on the device.  ihw() training
+## (:1994), the distance look-up (:2004-2031) and the plots (:1999-2002, :2053-2060) are the reference's own statements.
+## With long tables and any other backend the reference's function runs (kept as .IHWcorrectionReference).
+IHWcorrection <- function(chicdiff.settings, DESeqOut, FullRegionData, DESeqOutControl, FullControlRegionData,
+                          countput, DiagPlot = TRUE, diffbaitPlot = TRUE, suffix = "") {
+
+  hip <- inherits(FullRegionData, "chicdiffHipRegionData") && inherits(FullControlRegionData, "chicdiffHipRegionData")
+  if (!hip)
+    return(.IHWcorrectionReference(chicdiff.settings, DESeqOut, FullRegionData, DESeqOutControl, FullControlRegionData,
+                                   countput, DiagPlot = DiagPlot, diffbaitPlot = diffbaitPlot, suffix = suffix))
+
+  baitmapfile <- chicdiff.settings[["baitmapfile"]]
+  device <- chicdiff.settings[["device"]]          # the PLOT device, as in the reference (chicdiff.R:1960, :2058)
+  outprefix <- chicdiff.settings[["outprefix"]]
+  gpu <- .hipDeviceIndex(chicdiff.settings)
+
+  out <- data.table::copy(DESeqOut)
+  out$avDist <- .Call("chicdiff_hip_download", FullRegionData$avDist, PACKAGE = "chicdiffhip")   # by position = regionID order
+  out$uniform <- runif(nrow(out))
+  out$shuff <- sample(out$pvalue)
+  message("Comparison against p-vals for out")
+  data.table::setDT(out)
+
+  out.control <- data.table::copy(DESeqOutControl)
+  out.control$avDist <- .Call("chicdiff_hip_download", FullControlRegionData$avDist, PACKAGE = "chicdiffhip")
+  out.control$uniform <- runif(nrow(out.control))
+  out.control$shuff <- sample(out.control$pvalue)
+  message("Comparison against p-vals for outcontrol")
+
+  ## Train weights on the control sample (IHW stays R)
+  ihwRes <- IHW::ihw(pvalue ~ abs(avDist), data = as.data.frame(out.control), alpha = 0.05)
+  message("Trained weights on the control sample")
+  if (DiagPlot == TRUE) {
+    plot(ihwRes)
+    ggplot2::ggsave(paste0(outprefix, "_IHWweightPlot.png"), device = "png", path = "./")
+    plot(ihwRes, what = "decisionboundary")
+    ggplot2::ggsave(paste0(outprefix, "_IHWdecisionBoundaryPlot.png"), device = "png", path = "./")
+  }
+
+  ## Learn distance dependency (chicdiff.R:2004-2031)
+  test <- ihwRes@df
+  data.table::setDT(test)
+  distLookup <- test[, list(avgLogDist = mean(log(covariate)), minLogDist = min(log(covariate)), maxLogDist = max(log(covariate))),
+                     by = "group"]
+  distLookup <- distLookup[!is.na(group), ]
+  data.table::setkey(distLookup, group)
+  if (distLookup[, !identical(as.integer(group), seq_along(group))]) stop("Assumption violated")
+  w <- ihwRes@weights
+  distLookup[, group := as.integer(group)]
+  distLookup$avWeights <- rowSums(w) / ncol(w)
+  distLookup$minLogDist[1] <- 0
+  distLookup$maxLogDist[nrow(distLookup)] <- Inf
+  message("Learned distance dependency")
+
+  ## Apply to test data, on the device (chicdiff.R:2036-2049)
+  out <- .hipApplyIHWweights(out, distLookup, device = gpu)
+  message("applied to test data")
+
+  if (diffbaitPlot == TRUE) {
+    sel <- order(out$weighted_padj)
+    baits <- sample(head(unique(out[sel]$baitID), 100), 4)
+    plotDiffBaits(output = out, countput = countput, baitmapfile = baitmapfile, baits = baits)
+    cowplot::ggsave2(paste0(outprefix, "_diffbaitPlot", ".", device), device = device, path = "./")
+    dev.off()
+  }
+  saveRDS(out, paste0(outprefix, "_results", suffix, ".Rds"))
   out
 }

@@ -21,6 +21,9 @@
  *   chicdiff_hip_region_universe chicdiff.R:376-401
  *   chicdiff_hip_chinput_table chicdiff.R:828-831, 849              fread(chinput), RU baits only, keyed (baitID, otherEndID)
  *   chicdiff_hip_count_join    chicdiff.R:843-858                   N per RU row and replicate, 0 where unobserved
+ *   chicdiff_hip_bait_flags    chicdiff.R:775                       sort(unique(RU$baitID)) as a device flag table, built once
+ *   chicdiff_hip_count_table / chicdiff_hip_count_join_inner  chicdiff.R:742-747, 774-807   the same without chinput files
+ *   chicdiff_hip_region_avdist chicdiff.R:868-882, 1965             avDist = mean(distSign) by region for IHWcorrection()
  *   chicdiff_hip_fragment_background chicdiff.R:628-703, 894-896    Bmean, Tmean, FullMean per RU row and replicate
  *
  * Conventions: R matrices are column-major = the library's sample-major layout, so INTEGER()/REAL() pass through
@@ -489,48 +492,172 @@ SEXP chicdiff_hip_region_universe(SEXP ctx, SEXP baitID, SEXP oeID, SEXP RUexpan
 }
 
 /* ---- f2 + a1: chinput -> count table -> per-replicate fragment counts, chicdiff.R:811-858 ------------------------------ */
-/* .Call(chicdiff_hip_chinput_table, ctx, path, baits (integer: sort(unique(RU$baitID)), or NULL = keep every row))
+/* one byte per fragment ID 0..max_id (non-zero = a bait of the region universe), kept in a 4-byte device vector whose
+ * length fixes max_id = 4 * words - 1 (the padding bytes are zero = "not a bait") */
+static SEXP bait_flags_new(SEXP ctx, SEXP baits) {
+    if (!Rf_isInteger(baits)) Rf_error("chicdiff_hip: baits must be integer IDs");
+    int32_t max_id = -1;
+    for (R_xlen_t i = 0; i < XLENGTH(baits); i++) {
+        const int b = INTEGER(baits)[i];
+        if (b == NA_INTEGER || b < 0) Rf_error("chicdiff_hip: NA or negative bait ID");
+        if (b > max_id) max_id = b;
+    }
+    const R_xlen_t words = ((R_xlen_t)max_id + 1 + 3) / 4 + 1;
+    unsigned char *map = (unsigned char *)R_alloc((size_t)words, 4);
+    memset(map, 0, (size_t)words * 4);
+    for (R_xlen_t i = 0; i < XLENGTH(baits); i++) map[INTEGER(baits)[i]] = 1;
+    SEXP dMap = devbuf_new(ctx, INTSXP, words); /* PROTECTed */
+    check_rc(ctx, chicdiff_hip_memcpy_h2d(ctx_of(ctx), dptr(dMap), map, (uint64_t)words * 4), "chicdiff_hip_bait_flags");
+    return dMap;
+}
+/* .Call(chicdiff_hip_bait_flags, ctx, baits (integer: sort(unique(RU$baitID)), chicdiff.R:775)) -> device flag table,
+ * built and uploaded once and handed to chicdiff_hip_chinput_table / chicdiff_hip_count_table for every replicate */
+SEXP chicdiff_hip_bait_flags(SEXP ctx, SEXP baits) {
+    SEXP p = bait_flags_new(ctx, baits);
+    UNPROTECT(1);
+    return p;
+}
+/* `baits`: NULL (keep every row), integer IDs (a temporary flag table is made), or a chicdiff_hip_bait_flags table;
+ * returned PROTECTed (R_NilValue counts too); *max_id = last ID the table covers */
+static SEXP flags_arg(SEXP ctx, SEXP baits, int32_t *max_id) {
+    SEXP d = R_NilValue;
+    *max_id = -1;
+    if (Rf_isNull(baits)) {
+        PROTECT(d);
+    } else if (TYPEOF(baits) == EXTPTRSXP) {
+        devbuf_of(baits, INTSXP, -1, "baits");
+        d = baits;
+        PROTECT(d);
+    } else {
+        d = bait_flags_new(ctx, baits);
+    }
+    if (d != R_NilValue) *max_id = (int32_t)(((devbuf *)R_ExternalPtrAddr(d))->len * 4 - 1);
+    return d;
+}
+static SEXP key_table_result(SEXP dK, SEXP dV, int64_t nkeys, int64_t nrows) {
+    static const char *names[] = {"keys", "vals", "nkeys", "nrows"};
+    SEXP out = PROTECT(named_list(4, names));
+    SET_VECTOR_ELT(out, 0, dK);
+    SET_VECTOR_ELT(out, 1, dV);
+    SET_VECTOR_ELT(out, 2, Rf_ScalarReal((double)nkeys));
+    SET_VECTOR_ELT(out, 3, Rf_ScalarReal((double)nrows));
+    UNPROTECT(1);
+    return out;
+}
+/* .Call(chicdiff_hip_chinput_table, ctx, path, baits (integer sort(unique(RU$baitID)), a chicdiff_hip_bait_flags table, or
+ *       NULL = keep every row))
  * -> list(keys = device (baitID << 32 | otherEndID, ascending; carried in an 8-byte vector), vals = device integer N,
  *         nkeys, nrows): `x <- fread(chinput); setkey(x, baitID); x <- x[J(baits), ]` (:828-831) and the
- * `setkey(temp, baitID, otherEndID)` of :849, as one table per replicate */
+ * `setkey(temp, baitID, otherEndID)` of :849, as one table per replicate.  A header without data rows gives nkeys = 0
+ * (fread's empty table: every RU row then gets N = 0 from the left join). */
 SEXP chicdiff_hip_chinput_table(SEXP ctx, SEXP path, SEXP baits) {
     if (!Rf_isString(path) || LENGTH(path) != 1) Rf_error("chicdiff_hip_chinput_table: one file name expected");
     chicdiff_hip_ctx *c = ctx_of(ctx);
-    int np = 0;
-    int32_t max_id = -1;
-    SEXP dMap = R_NilValue;
-    if (!Rf_isNull(baits)) {
-        if (!Rf_isInteger(baits)) Rf_error("chicdiff_hip_chinput_table: baits must be integer IDs");
-        for (R_xlen_t i = 0; i < XLENGTH(baits); i++) {
-            const int b = INTEGER(baits)[i];
-            if (b == NA_INTEGER || b < 0) Rf_error("chicdiff_hip_chinput_table: NA or negative bait ID");
-            if (b > max_id) max_id = b;
-        }
-        /* one byte per ID 0..max_id, staged in R-managed memory and kept in a 4-byte device vector */
-        const R_xlen_t words = ((R_xlen_t)max_id + 1 + 3) / 4 + 1;
-        unsigned char *map = (unsigned char *)R_alloc((size_t)words, 4);
-        memset(map, 0, (size_t)words * 4);
-        for (R_xlen_t i = 0; i < XLENGTH(baits); i++) map[INTEGER(baits)[i]] = 1;
-        dMap = devbuf_new(ctx, INTSXP, words); np++;
-        check_rc(ctx, chicdiff_hip_memcpy_h2d(c, dptr(dMap), map, (uint64_t)words * 4), "chicdiff_hip_chinput_table");
-    }
+    int32_t max_id;
+    SEXP dMap = flags_arg(ctx, baits, &max_id);
     int64_t nrows = 0, nkeys = 0;
     check_rc(ctx, chicdiff_hip_chinput_read(c, CHAR(STRING_ELT(path, 0)), 0, &nrows), "chicdiff_hip_chinput_table");
-    static const char *names[] = {"keys", "vals", "nkeys", "nrows"};
-    SEXP out = PROTECT(named_list(4, names)); np++;
-    SEXP dK = devbuf_new(ctx, REALSXP, (R_xlen_t)nrows); np++;
-    SET_VECTOR_ELT(out, 0, dK);
-    SEXP dV = devbuf_new(ctx, INTSXP, (R_xlen_t)nrows); np++;
-    SET_VECTOR_ELT(out, 1, dV);
-    if (nrows > 0)
-        check_rc(ctx, chicdiff_hip_chinput_table_dev(c, Rf_isNull(baits) ? NULL : (const uint8_t *)dptr(dMap), max_id, (int64_t *)dptr(dK),
-                                                     (int32_t *)dptr(dV), &nkeys),
-                 "chicdiff_hip_chinput_table");
-    SET_VECTOR_ELT(out, 2, Rf_ScalarReal((double)nkeys));
-    SET_VECTOR_ELT(out, 3, Rf_ScalarReal((double)nrows));
-    if (!Rf_isNull(baits)) devbuf_finalizer(dMap);
-    UNPROTECT(np);
+    SEXP dK = devbuf_new(ctx, REALSXP, (R_xlen_t)nrows);
+    SEXP dV = devbuf_new(ctx, INTSXP, (R_xlen_t)nrows);
+    check_rc(ctx, chicdiff_hip_chinput_table_dev(c, dMap == R_NilValue ? NULL : (const uint8_t *)dptr(dMap), max_id, (int64_t *)dptr(dK),
+                                                 (int32_t *)dptr(dV), &nkeys),
+             "chicdiff_hip_chinput_table");
+    SEXP out = PROTECT(key_table_result(dK, dV, nkeys, nrows));
+    if (dMap != R_NilValue) release_if_temp(dMap, baits);
+    UNPROTECT(4);
     return out;
+}
+
+/* .Call(chicdiff_hip_count_table, ctx, baitID, otherEndID, N (integer vectors of one Chicago data set), baits as above)
+ * -> the same list as chicdiff_hip_chinput_table.  The branch without chinput files: tempForCounts[[i]] <- x[, c("baitID",
+ * "otherEndID", "N")]; setkey(x, baitID, otherEndID) (chicdiff.R:742-747) and countData[[i]][J(baits), ] (:782-787) */
+SEXP chicdiff_hip_count_table(SEXP ctx, SEXP bait, SEXP oe, SEXP N, SEXP baits) {
+    if (!Rf_isInteger(bait) || !Rf_isInteger(oe) || !Rf_isInteger(N) || XLENGTH(oe) != XLENGTH(bait) || XLENGTH(N) != XLENGTH(bait))
+        Rf_error("chicdiff_hip_count_table: three integer vectors of one length expected");
+    chicdiff_hip_ctx *c = ctx_of(ctx);
+    const R_xlen_t n = XLENGTH(bait);
+    int32_t max_id;
+    SEXP dMap = flags_arg(ctx, baits, &max_id);
+    SEXP dB = as_device(ctx, bait, INTSXP, n, "baitID"), dO = as_device(ctx, oe, INTSXP, n, "otherEndID"), dN = as_device(ctx, N, INTSXP, n, "N");
+    SEXP dK = devbuf_new(ctx, REALSXP, n);
+    SEXP dV = devbuf_new(ctx, INTSXP, n);
+    int64_t nkeys = 0;
+    if (n > 0)
+        check_rc(ctx, chicdiff_hip_count_table_dev(c, (const int32_t *)dptr(dB), (const int32_t *)dptr(dO), (const int32_t *)dptr(dN), (int64_t)n,
+                                                   dMap == R_NilValue ? NULL : (const uint8_t *)dptr(dMap), max_id, (int64_t *)dptr(dK),
+                                                   (int32_t *)dptr(dV), &nkeys),
+                 "chicdiff_hip_count_table");
+    SEXP out = PROTECT(key_table_result(dK, dV, nkeys, (int64_t)n));
+    devbuf_finalizer(dB); devbuf_finalizer(dO); devbuf_finalizer(dN);
+    if (dMap != R_NilValue) release_if_temp(dMap, baits);
+    UNPROTECT(7);
+    return out;
+}
+
+/* .Call(chicdiff_hip_count_join_inner, ctx, ru_bait, ru_oe (device or host integer nru), tables (list of S key tables))
+ * -> device integer nru x S.  mergedFiles <- Reduce(merge, tempForCounts) (an inner join over the replicates), then
+ * merge(x, temp, all.x = TRUE); x[is.na(N), N := 0] per replicate (chicdiff.R:779-803) */
+SEXP chicdiff_hip_count_join_inner(SEXP ctx, SEXP ru_bait, SEXP ru_oe, SEXP tables) {
+    if (TYPEOF(tables) != VECSXP || LENGTH(tables) < 1 || LENGTH(tables) > 64) Rf_error("chicdiff_hip_count_join_inner: a list of 1..64 key tables expected");
+    const int S = LENGTH(tables);
+    const R_xlen_t nru = TYPEOF(ru_bait) == EXTPTRSXP ? devbuf_of(ru_bait, INTSXP, -1, "ru_bait")->len : XLENGTH(ru_bait);
+    const int64_t *keys[64];
+    const int32_t *vals[64];
+    int64_t nkeys[64];
+    for (int s = 0; s < S; s++) {
+        SEXP t = VECTOR_ELT(tables, s);
+        if (TYPEOF(t) != VECSXP || LENGTH(t) < 3) Rf_error("chicdiff_hip_count_join_inner: table %d does not come from chicdiff_hip_count_table", s + 1);
+        devbuf *k = devbuf_of(VECTOR_ELT(t, 0), REALSXP, -1, "table$keys"), *v = devbuf_of(VECTOR_ELT(t, 1), INTSXP, -1, "table$vals");
+        nkeys[s] = (int64_t)Rf_asReal(VECTOR_ELT(t, 2));
+        if (nkeys[s] < 0 || nkeys[s] > k->len || nkeys[s] > v->len) Rf_error("chicdiff_hip_count_join_inner: table$nkeys does not fit table %d", s + 1);
+        keys[s] = (const int64_t *)k->d;
+        vals[s] = (const int32_t *)v->d;
+    }
+    SEXP dB = as_device(ctx, ru_bait, INTSXP, nru, "ru_bait"), dO = as_device(ctx, ru_oe, INTSXP, nru, "ru_oe");
+    SEXP res = devbuf_new(ctx, INTSXP, nru * S);
+    check_rc(ctx, chicdiff_hip_count_join_inner_dev(ctx_of(ctx), (const int32_t *)dptr(dB), (const int32_t *)dptr(dO), (int64_t)nru, S, keys, vals, nkeys,
+                                                    (int32_t *)dptr(res)),
+             "chicdiff_hip_count_join_inner");
+    release_if_temp(dB, ru_bait);
+    release_if_temp(dO, ru_oe);
+    UNPROTECT(3);
+    return res;
+}
+
+/* .Call(chicdiff_hip_region_avdist, ctx, ru_bait, ru_oe (device or host integer, (regionID, otherEndID) order), region_ptr
+ *       (double n + 1: 0-based offset of each region's first row), id_min, midsum (double nid: start + end of fragment
+ *       id_min + k), chr (integer nid: chromosome code, -1 = ID not on the map; or NULL))
+ * -> device double n: RU.recast[, list(avDist = mean(distSign)), by = "regionID"] (chicdiff.R:1965) without the long table */
+SEXP chicdiff_hip_region_avdist(SEXP ctx, SEXP ru_bait, SEXP ru_oe, SEXP region_ptr, SEXP id_min, SEXP midsum, SEXP chr) {
+    if (!Rf_isReal(region_ptr) || XLENGTH(region_ptr) < 2 || !Rf_isReal(midsum) || (!Rf_isNull(chr) && (!Rf_isInteger(chr) || XLENGTH(chr) != XLENGTH(midsum))))
+        Rf_error("chicdiff_hip_region_avdist: bad arguments");
+    chicdiff_hip_ctx *c = ctx_of(ctx);
+    const R_xlen_t nru = TYPEOF(ru_bait) == EXTPTRSXP ? devbuf_of(ru_bait, INTSXP, -1, "ru_bait")->len : XLENGTH(ru_bait);
+    const R_xlen_t n = XLENGTH(region_ptr) - 1, nid = XLENGTH(midsum);
+    int64_t *hp = (int64_t *)R_alloc((size_t)(n + 1), 8), *hm = (int64_t *)R_alloc((size_t)nid, 8);
+    for (R_xlen_t i = 0; i <= n; i++) {
+        const double v = REAL(region_ptr)[i];
+        if (!(v >= 0) || v > (double)nru || (i > 0 && v < REAL(region_ptr)[i - 1])) Rf_error("chicdiff_hip_region_avdist: region_ptr must ascend within 0..nru");
+        hp[i] = (int64_t)v;
+    }
+    for (R_xlen_t i = 0; i < nid; i++) hm[i] = ISNAN(REAL(midsum)[i]) ? 0 : (int64_t)REAL(midsum)[i];
+    SEXP dB = as_device(ctx, ru_bait, INTSXP, nru, "ru_bait"), dO = as_device(ctx, ru_oe, INTSXP, nru, "ru_oe");
+    SEXP dP = devbuf_new(ctx, REALSXP, n + 1), dM = devbuf_new(ctx, REALSXP, nid);
+    check_rc(ctx, chicdiff_hip_memcpy_h2d(c, dptr(dP), hp, 8 * (uint64_t)(n + 1)), "chicdiff_hip_region_avdist");
+    check_rc(ctx, chicdiff_hip_memcpy_h2d(c, dptr(dM), hm, 8 * (uint64_t)nid), "chicdiff_hip_region_avdist");
+    SEXP dC = R_NilValue;
+    if (!Rf_isNull(chr)) dC = as_device(ctx, chr, INTSXP, nid, "chr"); else PROTECT(dC);
+    SEXP res = devbuf_new(ctx, REALSXP, n);
+    check_rc(ctx, chicdiff_hip_region_avdist_dev(c, (const int32_t *)dptr(dB), (const int32_t *)dptr(dO), (int64_t)nru, (const int64_t *)dptr(dP), (int64_t)n,
+                                                 Rf_asInteger(id_min), (int32_t)nid, (const int64_t *)dptr(dM),
+                                                 Rf_isNull(chr) ? NULL : (const int32_t *)dptr(dC), (double *)dptr(res)),
+             "chicdiff_hip_region_avdist");
+    release_if_temp(dB, ru_bait);
+    release_if_temp(dO, ru_oe);
+    devbuf_finalizer(dP); devbuf_finalizer(dM);
+    if (!Rf_isNull(chr)) release_if_temp(dC, chr);
+    UNPROTECT(6);
+    return res;
 }
 
 /* .Call(chicdiff_hip_count_join, ctx, ru_bait, ru_oe (integer nru, host or device), table (chicdiff_hip_chinput_table),
@@ -648,7 +775,11 @@ static const R_CallMethodDef call_methods[] = {{"chicdiff_hip_open", (DL_FUNC)&c
                                                {"chicdiff_hip_padj", (DL_FUNC)&chicdiff_hip_padj, 4},
                                                {"chicdiff_hip_ihw_apply", (DL_FUNC)&chicdiff_hip_ihw_apply, 5},
                                                {"chicdiff_hip_region_universe", (DL_FUNC)&chicdiff_hip_region_universe, 5},
+                                               {"chicdiff_hip_bait_flags", (DL_FUNC)&chicdiff_hip_bait_flags, 2},
                                                {"chicdiff_hip_chinput_table", (DL_FUNC)&chicdiff_hip_chinput_table, 3},
+                                               {"chicdiff_hip_count_table", (DL_FUNC)&chicdiff_hip_count_table, 5},
+                                               {"chicdiff_hip_count_join_inner", (DL_FUNC)&chicdiff_hip_count_join_inner, 4},
+                                               {"chicdiff_hip_region_avdist", (DL_FUNC)&chicdiff_hip_region_avdist, 7},
                                                {"chicdiff_hip_count_join", (DL_FUNC)&chicdiff_hip_count_join, 6},
                                                {"chicdiff_hip_fragment_background", (DL_FUNC)&chicdiff_hip_fragment_background, 12},
                                                {NULL, NULL, 0}};

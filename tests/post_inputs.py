@@ -71,3 +71,19 @@ def region_universe_literal(bait, oe, s, chr_of):
     rows = sorted(rows, key=lambda t: t[0][0])                                      # setkey(baitID), stable
     out = [r for r, c in rows if c is not None and on_map(r[0]) and chr_of[r[0]] == c]   # chr == i.chr (NA drops)
     return np.array(out, dtype=np.int32).reshape(-1, 3)
+
+
+def golden_regions_as_ru(golden):
+    """The 24 863 regions of the reference's own chr19 run as CSR-ordered RU rows: a region is the contiguous
+    otherEndID range [minOE, maxOE] of its bait (chicdiff.R:353-367, :1703-1705) on the full chr19 restriction map
+    (tests/golden/chr19_design.npz).  Returns ru_bait, ru_oe, region_ptr, id_min, midsum (= start + end per ID)."""
+    d = np.load(os.path.join(HERE, "golden", "chr19_design.npz"))
+    ids = d["rmap_id"].astype(np.int64)
+    assert np.array_equal(ids, np.arange(ids[0], ids[0] + len(ids)))  # dense, ascending: table index = ID - id_min
+    lo, hi = golden["minOE"].astype(np.int64), golden["maxOE"].astype(np.int64)
+    F = hi - lo + 1
+    ptr = np.concatenate([[0], np.cumsum(F)]).astype(np.int64)
+    ru_oe = (np.repeat(lo, F) + (np.arange(ptr[-1]) - np.repeat(ptr[:-1], F))).astype(np.int32)
+    ru_bait = np.repeat(golden["baitID"], F).astype(np.int32)
+    midsum = d["rmap_start"].astype(np.int64) + d["rmap_end"].astype(np.int64)
+    return ru_bait, ru_oe, ptr, int(ids[0]), midsum

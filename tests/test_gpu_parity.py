@@ -1655,3 +1655,92 @@ def test_soak_changing_shapes_no_leak_and_run_to_run_identity(ctx):
         if it == 20:
             free_mid = free
     assert free_mid - free < 64 * 2 ** 20, (free_mid, free)
+
+
+@pytest.mark.parametrize("with_chinput", [True, False])
+def test_chicdiffPipeline_mirror_from_peak_matrix_to_weighted_padj(ctx, oracle, golden, tmp_path, with_chinput):
+    """chicdiffPipeline() (chicdiff.R:301-347) through the host mirrors with the device path behind every stage, given the
+    reference's own settings list UNCHANGED except for its file entries (tests/golden/chr19_settings.json: device = "png",
+    theta = NULL -> theta grid, 2 v 2): peak matrix -> region universe -> control universe -> getFullRegionData (both
+    universes from one read of each Chicago table / chinput file; `with_chinput = False`: the Reduce(merge) branch of
+    chicdiff.R:774-807) -> DESeq2Wrap x 2 -> IHWcorrection -> the 25-column result table.  Every block is compared with
+    the oracle run on the same inputs."""
+    import pandas as pd
+    import torch
+    from chicdiff_amd import pipeline, settings as st
+    from pipeline_inputs import make_experiment, quantile_ihw, read_chicago_pickle
+    settings, truth = make_experiment(tmp_path, npeaks=2500, with_chinput=with_chinput)
+    assert settings["device"] == ["png"] and "hipDevice" not in settings and settings["theta"] is None
+    s = st.asChicdiffSettings(settings)
+    rng = np.random.default_rng(11)
+    # stage by stage first (what chicdiffPipeline calls), each against the oracle
+    RU = pipeline.getRegionUniverse(settings, ctx)
+    rmap = pd.read_csv(s["rmapfile"], sep=r"\s+", header=None, quotechar='"')
+    id_min, nid = truth["id_min"], truth["nid"]
+    chr_of = np.full(id_min + nid, -1, dtype=np.int32)
+    chr_of[rmap[3].to_numpy()] = 0
+    ptr_ref, rb_ref, rr_ref, ro_ref = oracle.region_universe(truth["peak_bait"], truth["peak_oe"], 5, chr_of)
+    assert np.array_equal(RU["region_ptr"].cpu().numpy(), ptr_ref) and np.array_equal(RU["csr_otherEndID"].cpu().numpy(), ro_ref)
+    assert np.array_equal(RU["csr_baitID"].cpu().numpy(), rb_ref)
+    RUc = pipeline.getControlRegionUniverse(settings, RU, ctx, rng=rng)
+    nC = RUc["region_ptr"].numel() - 1
+    assert 0.9 * len(truth["peak_bait"]) <= nC <= len(truth["peak_bait"]) and (np.diff(RUc["region_ptr"].cpu().numpy()) > 0).all()
+    cb, co = RUc["csr_baitID"].cpu().numpy(), RUc["csr_otherEndID"].cpu().numpy()
+    assert np.isin(cb, np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chr19_design.npz"))["bait_id"]).all()
+    assert (np.abs(co.astype(np.int64) - cb) >= 2).all()                       # never the bait or its neighbours (.expandAvoidBait)
+    frd = pipeline.getFullRegionData(settings, RU, RUc, ctx=ctx, read_chicago=read_chicago_pickle)
+    assert len(frd) == 3 and not frd[0]["is_control"] and frd[1]["is_control"]
+    assert list(frd[2].columns) == ["baitID", "otherEndID", "Nav", "Bav", "score", "oeID_mid", "condition"]   # countput, chicdiff.R:754-768
+    S = 4
+    flags = np.zeros(id_min + nid, np.uint8)
+    flags[np.unique(np.concatenate([rb_ref, cb]))] = 1
+    if with_chinput:
+        tabs = [oracle.count_table(b, o, N, flags) for b, o, N in truth["chinput"]]
+    else:
+        tabs = [oracle.count_table(x["baitID"].to_numpy(), x["otherEndID"].to_numpy(), x["N"].to_numpy(), flags) for x in truth["xs"]]
+    bg = pipeline.background_tables(truth["xs"], id_min, nid)
+    N_ref = {}
+    for blk, (ub, uo, uptr) in zip(frd[:2], [(rb_ref, ro_ref, ptr_ref), (cb, co, RUc["region_ptr"].cpu().numpy())]):
+        if with_chinput:
+            Nf = np.stack([oracle.count_join(ub, uo, k, v) for k, v in tabs], 1)
+        else:
+            Nf = oracle.count_join_inner(ub, uo, tabs)
+            plain = np.stack([oracle.count_join(ub, uo, k, v) for k, v in tabs], 1)
+            assert (plain != Nf).any() and ((Nf > 0).all(1) == (Nf > 0).any(1)).all()   # the inner merge drops pairs a replicate lacks
+        assert np.array_equal(blk["fragN"].cpu().numpy().T, Nf) and Nf.sum() > 0
+        _, _, FM = oracle.fragment_background(ub, uo, id_min, truth["midsum"], bg["sj"], bg["si"], bg["tblb"], bg["tlb"], bg["T"], bg["distfun"])
+        assert np.allclose(blk["fragFullMean"].cpu().numpy(), FM, rtol=1e-13, equal_nan=True)
+        av = oracle.region_avdist(ub, uo, uptr, id_min, truth["midsum"], np.zeros(nid, np.int32))
+        assert np.array_equal(blk["avDist"].cpu().numpy(), av) and not np.isnan(av).any()
+        N_ref[id(blk)] = (oracle.window_sums(Nf, FM.T, uptr), av)
+    # the driver itself, same seed for the control draws
+    out = pipeline.chicdiffPipeline(settings, ctx=ctx, read_chicago=read_chicago_pickle, ihw=quantile_ihw(), rng=np.random.default_rng(11))
+    assert list(out.columns) == [str(c) for c in golden["__column_order__"]]    # the reference's own 25 columns, in its order
+    theta = out.attrs["theta"]
+    assert theta in s["theta_grid"]
+    out_r = out.sort_values("regionID").reset_index(drop=True)
+    n = len(truth["peak_bait"])
+    assert np.array_equal(out_r["regionID"].to_numpy(), np.arange(1, n + 1)) and np.array_equal(out_r["baitID"].to_numpy(), truth["peak_bait"])
+    (N_w, FM_w), av = N_ref[id(frd[0])]
+    assert np.array_equal(out_r["avDist"].to_numpy(), av)
+    group = np.array([0, 0, 1, 1])                                                # CD4 < Mono: alphabetical levels
+    sf = oracle.size_factors(N_w)
+    devs = [oracle.nbglm_fit(N_w, oracle.offsets(FM_w, sf, t), np.zeros(S, dtype=np.int32))["sumDeviance"] for t in s["theta_grid"]]
+    assert s["theta_grid"][int(np.argmin(devs))] == theta
+    ref = oracle.nbglm_fit(N_w, oracle.offsets(FM_w, sf, theta), group)
+    live = (ref["allZero"] == 0) & (ref["betaConv"] == 1)
+    check_close("pipeline mirror pvalue", out_r["pvalue"].to_numpy(), ref["pvalue"], live, 1e-6, frac=0.998, noise_rows=2)
+    check_close("pipeline mirror lfc", out_r["log2FoldChange"].to_numpy(), ref["log2FoldChange"], live & (np.abs(ref["log2FoldChange"]) > 1e-2), 1e-6,
+                frac=0.998, noise_rows=2)
+    # IHW side: the control fit's covariate trains the stand-in ihw(); the application reproduces the oracle's columns
+    ctl = pipeline.DESeq2Wrap(settings, RUc, frd[1], suffix="Control", theta=theta, ctx=ctx)
+    df, w = quantile_ihw()(ctl["pvalue"].to_numpy(), np.abs(N_ref[id(frd[1])][1]), 0.05)
+    look = pipeline.dist_lookup(df, w)
+    from chicdiff_amd import post
+    g_ref, w_ref, wp_ref, wpadj_ref = oracle.ihw_apply(av, out_r["pvalue"].to_numpy(), post.ihw_breaks(look["minLogDist"], look["maxLogDist"]), look["avWeights"])
+    assert np.array_equal(out_r["group"].to_numpy(), np.where(g_ref == np.iinfo(np.int32).min, -1, g_ref))
+    assert np.allclose(out_r["weighted_padj"].to_numpy(), wpadj_ref, rtol=1e-12, equal_nan=True)
+    assert np.allclose(out_r["weight"].to_numpy(), w_ref, rtol=1e-13, equal_nan=True) and (np.diff(out["group"].to_numpy()) >= 0).all()
+    assert os.path.exists(s["outprefix"] + "_results.csv") and os.path.exists(s["outprefix"] + "_countput.csv")
+    print(f"pipeline mirror (chinput={with_chinput}): {n} regions, {nC} control regions, theta {theta}, "
+          f"weighted padj < 0.05: {int((out['weighted_padj'] < 0.05).sum())}")

@@ -75,7 +75,8 @@ def test_every_dot_call_is_registered_with_matching_arity():
     for must in ("chicdiff_hip_open", "chicdiff_hip_window_sums", "chicdiff_hip_size_factors", "chicdiff_hip_theta_grid",
                  "chicdiff_hip_wald_test", "chicdiff_hip_fit", "chicdiff_hip_release", "chicdiff_hip_chinput_table",
                  "chicdiff_hip_count_join", "chicdiff_hip_fragment_background", "chicdiff_hip_alloc", "chicdiff_hip_region_universe",
-                 "chicdiff_hip_ihw_apply"):
+                 "chicdiff_hip_ihw_apply", "chicdiff_hip_bait_flags", "chicdiff_hip_count_table", "chicdiff_hip_count_join_inner",
+                 "chicdiff_hip_region_avdist", "chicdiff_hip_download", "chicdiff_hip_upload"):
         assert must in seen, must
 
 
@@ -89,7 +90,8 @@ def test_shim_uses_only_declared_library_entry_points():
     for must in ("chicdiff_hip_window_sums_dev", "chicdiff_hip_size_factors_dev", "chicdiff_hip_offsets_dev", "chicdiff_hip_theta_grid_dev",
                  "chicdiff_hip_wald_test_dev", "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_cooks_filter_dev",
                  "chicdiff_hip_independent_filtering_dev", "chicdiff_hip_chinput_read", "chicdiff_hip_chinput_table_dev",
-                 "chicdiff_hip_count_join_dev", "chicdiff_hip_fragment_background_dev"):
+                 "chicdiff_hip_count_join_dev", "chicdiff_hip_fragment_background_dev", "chicdiff_hip_count_table_dev",
+                 "chicdiff_hip_count_join_inner_dev", "chicdiff_hip_region_avdist_dev"):
         assert must in used, must
 
 
@@ -104,3 +106,10 @@ def test_r_wrapper_defines_the_reference_signature_and_messages():
                  'Mixing parameter theta set to 0, equivalent to norm = \\"fullmean\\". The norm method has been reset accordingly.'):
         assert text in r, text
     assert "unseeded" not in r and "session RNG" not in r
+    # the stages either side keep the reference's signatures too (chicdiff.R:1460, :1956), so chicdiffPipeline() (:301-347)
+    # reaches the device path without a change of its own
+    g = open(RSRC[2]).read()
+    assert re.search(r'^getFullRegionData <- function\(chicdiff\.settings, RU, RUcontrol, suffix = ""\)', g, re.M)
+    p = open(RSRC[3]).read()
+    assert re.search(r"^IHWcorrection <- function\(chicdiff\.settings, DESeqOut, FullRegionData, DESeqOutControl, FullControlRegionData,\s*countput, DiagPlot = TRUE, diffbaitPlot = TRUE, suffix = \"\"\)", p, re.M)
+    assert re.search(r'^getRegionUniverse <- function\(chicdiff\.settings, suffix = ""\)', p, re.M)
