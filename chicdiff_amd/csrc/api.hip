@@ -532,6 +532,13 @@ static int check_counts_group(chicdiff_hip_ctx *c, int64_t n, int32_t S, const i
     return CHICDIFF_OK;
 }
 
+// opts the caller filled in: fitType must be one of DESeq2's three (a NA_integer_ from R arrives as INT_MIN)
+static int check_opts(chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *opts) {
+    if (opts && (opts->fitType < 0 || opts->fitType > 2))
+        return fail(c, CHICDIFF_E_INVALID, "opts.fitType = %d: 0 (parametric), 1 (mean) or 2 (local) expected", opts->fitType);
+    return CHICDIFF_OK;
+}
+
 // Sharded fits: an argument error on ONE rank (e.g. an empty shard when n < world size) must not leave its peers blocked
 // in the first collective.  Every rank therefore contributes its local verdict to one sum-all-reduce before the fit
 // starts, and all return together.  (Single process: the local verdict.)
@@ -867,7 +874,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_wald_intercept(d_counts, d_nf, d, w, o, out, st);
     }
     launch_dev_sum_finish(d, w, st);
-    if ((rc = do_allreduce(c, sums_of(w), 4))) return rc;  // deviance sum, non-converged rows, all-zero rows, ranks whose trend kernel timed out
+    if ((rc = do_allreduce(c, sums_of(w), 5))) return rc;  // deviance sum, non-converged rows, all-zero rows, ranks whose trend kernel timed out, ranks with a negative / NA count
     // copy the per-row workspace columns the caller asked for
     const size_t nb = sizeof(double) * (size_t)d.n, ib = sizeof(int32_t) * (size_t)d.n;
 #define CPY(dst, src, bytes) \
@@ -877,12 +884,16 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     CPY(dispGeneIter, w.geneIter, ib); CPY(dispIter, w.mapIter, ib); CPY(dispOutlier, w.outlier, ib);
     CPY(allZero, w.allZero, ib);
 #undef CPY
-    double hs[4];
+    double hs[5];
     HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(hs, sums_of(w), sizeof hs, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
-    if (c->h_sc->neg_counts) return fail(c, CHICDIFF_E_INVALID, "counts contain a negative value or NA_integer_");
+    // hs[4] is all-reduced like the other sums: a negative / NA count on ANY rank has entered everybody's size factors, trend and
+    // prior, so every rank refuses the fit together (and none goes on to the retry below, whose collectives the others would miss)
+    if (hs[4] > 0)
+        return fail(c, CHICDIFF_E_INVALID, c->h_sc->neg_counts ? "counts contain a negative value or NA_integer_"
+                                                               : "counts contain a negative value or NA_integer_ (on another rank of the sharded fit)");
     if (c->h_sc->failed == 3 || hs[3] > 0) {  // (hs[3]: some rank of a sharded fit — every rank takes this branch together)
         // the persistent trend kernel's workgroups were not all resident within the barrier's patience (a GPU shared
         // with other work): fit again with one launch per IRLS pass, and stay with that for this context
@@ -923,6 +934,7 @@ int chicdiff_hip_nbglm_fit_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
     if (!c) return CHICDIFF_E_INVALID;
     FitDims d;
     int rc = (!d_counts || !d_nf) ? fail(c, CHICDIFF_E_INVALID, "counts / nf pointer is NULL") : check_counts_group(c, n, S, group, d);
+    if (!rc) rc = check_opts(c, opts);
     if ((rc = shard_consensus(c, rc))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
@@ -1118,6 +1130,7 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
     if (!c) return CHICDIFF_E_INVALID;
     FitDims d;
     int rc = !d_counts ? fail(c, CHICDIFF_E_INVALID, "counts pointer is NULL") : check_counts_group(c, n, S, group, d);
+    if (!rc) rc = check_opts(c, opts);
     if ((rc = shard_consensus(c, rc))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
@@ -1198,6 +1211,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
     int rc = (!d_counts || !d_fullMean || !sf_host || !thetas || !deviances_host || ntheta < 1)
                  ? fail(c, CHICDIFF_E_INVALID, "theta_grid: bad arguments")
                  : check_counts_group(c, n, S, nullptr, d);  // design ~ 1  ("sic!", chicdiff.R:1629-1631)
+    if (!rc) rc = check_opts(c, opts);
     if ((rc = shard_consensus(c, rc))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
@@ -1208,8 +1222,27 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
     // (every rank must issue its collectives in the same order).
     const size_t ws_per_lane = sizeof(double) * (size_t)n * (22 + S) + (64u << 20);
     int lanes = c->allreduce ? 1 : (ntheta < c->opt_grid_lanes ? ntheta : c->opt_grid_lanes);
-    while (lanes > 1 && ws_per_lane * lanes > ((size_t)96 << 30)) lanes--;  // keep the grid's workspaces under 96 GB
+    if (lanes > 1) {
+        // the lanes' workspaces must fit what the device has free NOW (a shared GPU, the caller's own tensors, a smaller
+        // part); lanes that already hold a workspace of this size cost nothing more
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        int have = 0;
+        for (chicdiff_hip_ctx *l : c->lanes) have += (l->cap_n >= n && l->cap_S >= S) ? 1 : 0;
+        while (lanes > 1 && lanes > have && (double)ws_per_lane * (lanes - have) > 0.9 * (double)free_b) lanes--;
+    }
+    while (lanes > 1 && (int)c->lanes.size() < lanes) {
+        chicdiff_hip_ctx *l = nullptr;
+        if (chicdiff_hip_create(&l, c->device)) { lanes = 1; break; }
+        c->lanes.push_back(l);
+    }
+    for (int k = 0; k < lanes && lanes > 1; k++)
+        if (ensure_workspace(c->lanes[k], n, S)) lanes = 1;  // no room after all: free the lanes, fit one theta after the other
     if (lanes <= 1) {
+        if (!c->allreduce && !c->lanes.empty()) {
+            for (chicdiff_hip_ctx *l : c->lanes) chicdiff_hip_destroy(l);
+            c->lanes.clear();
+        }
         if ((rc = ensure_workspace(c, n, S))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
         for (int t = 0; t < ntheta; t++) {
@@ -1223,11 +1256,6 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         }
         timing_collect(c);
         return CHICDIFF_OK;
-    }
-    while ((int)c->lanes.size() < lanes) {
-        chicdiff_hip_ctx *l = nullptr;
-        if ((rc = chicdiff_hip_create(&l, c->device))) return fail(c, rc, "theta_grid: %s", chicdiff_hip_last_error(nullptr));
-        c->lanes.push_back(l);
     }
     hipEvent_t ready;  // the inputs are produced on the caller's stream
     HIPCHK(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));

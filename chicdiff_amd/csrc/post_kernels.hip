@@ -470,7 +470,7 @@ __global__ void if_cuts_kernel(const uint64_t *__restrict__ sorted, int64_t n, d
     const double h = (double)(n - 1) * theta;
     const int64_t lo = (int64_t)floor(h), hi = lo + 1 < n ? lo + 1 : n - 1;
     const double frac = h - (double)lo, xlo = value_of(sorted[lo]), xhi = value_of(sorted[hi]);
-    st->cut[k] = xlo + frac * (xhi - xlo);
+    st->cut[k] = (frac > 0.0 && xhi != xlo) ? (1.0 - frac) * xlo + frac * xhi : xlo;  // quantile.default(type = 7): qs[i] <- (1 - h) * qs[i] + h * x[hi[i]]
     st->info.theta[k] = k == kIfN - 1 ? upper : theta;
 }
 // T = number of cutoffs <= baseMean (cutoffs ascending): the row passes the filters 0 .. T-1

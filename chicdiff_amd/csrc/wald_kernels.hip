@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void wald_intercept_kernel(const int32_t *__re
             (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-// partials (kRedBlocks x 3) -> sums[0..3): deviance sum, non-converged rows, all-zero rows
+// partials (kRedBlocks x 3) -> sums[0..5): deviance sum, non-converged rows, all-zero rows, trend-barrier timeout, negative counts
 __global__ void dev_sum_kernel(FitWork w) {
     __shared__ double red[256];
     double *sums = w.partials + (size_t)kRedBlocks * 72;
@@ -515,7 +515,10 @@ __global__ void dev_sum_kernel(FitWork w) {
     }
     // a rank whose persistent trend kernel lost its grid barrier (sharded fits with the gathered trend): summed over the
     // ranks with the three above, so that every rank learns of it and all of them refit the same way
-    if (threadIdx.x == 0) sums[3] = w.sc->failed == 3 ? 1.0 : 0.0;
+    if (threadIdx.x == 0) {
+        sums[3] = w.sc->failed == 3 ? 1.0 : 0.0;
+        sums[4] = w.sc->neg_counts ? 1.0 : 0.0;  // a rank that saw a negative / NA count: every rank must refuse the fit (api.hip)
+    }
 }
 
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts, hipStream_t st) {

@@ -136,7 +136,8 @@ def quantile7(x, probs):
     h = (n - 1) * np.asarray(probs, float)
     lo = np.floor(h).astype(int)
     hi = np.minimum(lo + 1, n - 1)
-    return xs[lo] + (h - lo) * (xs[hi] - xs[lo])
+    f = h - lo
+    return np.where((f > 0) & (xs[hi] != xs[lo]), (1.0 - f) * xs[lo] + f * xs[hi], xs[lo])   # qs[i] <- (1 - h) * qs[i] + h * x[hi[i]]
 
 
 def cooks_filter(pvalue, maxCooks, cooksArgmax, counts_of_rows, group, cutoff=None):

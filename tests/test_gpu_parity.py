@@ -707,6 +707,18 @@ def _two_rank_worker(rank, world, port, n, S, q):
             except hip.ChicdiffHipError as e:
                 msgs.append(str(e))
         assert all(("NULL" in m or "<= n" in m) if rank == 1 else ("rejected their arguments" in m) for m in msgs), msgs
+        # a negative / NA count on ONE rank has gone into everybody's size factors, trend and prior by the time it is seen:
+        # every rank must refuse the fit (round 2: the peers reported success on corrupted statistics)
+        bad = dk.clone()
+        if rank == 1:
+            bad[2, 5] = -2147483648   # NA_integer_
+        nf1 = c.offsets(dF, np.ones(S), 0.5)
+        for call in (lambda: c.nbglm_fit(bad, nf1, d["group"]), lambda: c.nbglm_fit(bad, nf1, d["group"], opts=hip.default_opts(fitType=7))):
+            try:
+                call()
+                raise AssertionError(f"rank {rank}: a fit with a negative count on rank 1 reported success")
+            except hip.ChicdiffHipError as e:
+                assert ("negative value or NA_integer_" in str(e)) or ("fitType" in str(e)) or ("rejected their arguments" in str(e)), str(e)
         out2, _ = c.wald_test(dk, dF, d["group"], theta=0.5)  # and the context still works afterwards
         assert all(c.torch.equal(out[k], out2[k]) or c.torch.allclose(out[k], out2[k], equal_nan=True, rtol=0, atol=0) for k in out)
         # the trend with one all-reduce per IRLS pass (the path before the rows were gathered; still the fallback when the
