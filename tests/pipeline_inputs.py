@@ -87,11 +87,15 @@ def make_experiment(tmp, seed=7, npeaks=2500, with_chinput=True):
     group = np.array([0, 0, 1, 1])
     for j, nm in enumerate(names):
         # observed pairs: every bait sees a window of other ends around it, dense enough that control regions carry counts
-        ob = np.repeat(baits, 140)
-        oo = ob + rng.integers(-70, 71, len(ob))
+        if with_chinput:
+            ob = np.repeat(baits, 140)
+            oo = ob + rng.integers(-70, 71, len(ob))
+        else:   # without chinputs a pair must be in EVERY replicate's table to count (Reduce(merge)): cover the whole window
+            ob = np.repeat(baits, 141)
+            oo = ob + np.tile(np.arange(-70, 71), len(baits))
         okp = (oo >= ids[0]) & (oo <= ids[-1]) & (oo != ob)
         key = np.unique((ob[okp] << 32) | oo[okp])
-        key = key[rng.random(len(key)) < 0.8]
+        key = key[rng.random(len(key)) < (0.8 if with_chinput else 0.99)]   # (without chinputs a pair must be in EVERY table to count: keep regions non-empty)
         ob, oo = key >> 32, key & 0xFFFFFFFF
         dd = mid[oo - id_min] - mid[ob - id_min]
         mu = 40.0 * depth[j] / (1.0 + np.abs(dd) / 2e4)

@@ -1756,3 +1756,26 @@ def test_chicdiffPipeline_mirror_from_peak_matrix_to_weighted_padj(ctx, oracle, 
     assert os.path.exists(s["outprefix"] + "_results.csv") and os.path.exists(s["outprefix"] + "_countput.csv")
     print(f"pipeline mirror (chinput={with_chinput}): {n} regions, {nC} control regions, theta {theta}, "
           f"weighted padj < 0.05: {int((out['weighted_padj'] < 0.05).sum())}")
+
+
+def test_region_avdist_on_device_reproduces_golden_avDist(ctx, oracle, golden, tmp_path):
+    """chicdiff_hip_region_avdist_dev on the regions of the reference's own chr19 run and the reference's restriction map:
+    the avDist column of the reference's result table (chicdiff.R:1965-1967), exactly, all 24 863 rows; trans rows give NA,
+    fragments off the map are dropped, as the oracle has it.  Plus the header-only chinput file (an empty key table, N = 0)."""
+    import torch
+    from post_inputs import golden_regions_as_ru
+    ru_bait, ru_oe, ptr, id_min, midsum = golden_regions_as_ru(golden)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(ctx.device)
+    av = ctx.region_avdist(t(ru_bait), t(ru_oe), t(ptr), id_min, t(midsum)).cpu().numpy()
+    assert np.array_equal(av, golden["avDist"])
+    rng = np.random.default_rng(3)
+    chr_codes = np.where(rng.random(len(midsum)) < 0.01, 1, 0).astype(np.int32)
+    chr_codes[rng.integers(0, len(midsum), 40)] = -1
+    av2 = ctx.region_avdist(t(ru_bait), t(ru_oe), t(ptr), id_min, t(midsum), t(chr_codes)).cpu().numpy()
+    ref2 = oracle.region_avdist(ru_bait, ru_oe, ptr, id_min, midsum, chr_codes)
+    assert np.array_equal(av2, ref2, equal_nan=True) and 0 < np.isnan(ref2).sum() < len(ref2)
+    empty = tmp_path / "empty.chinput"
+    empty.write_text("baitID\totherEndID\tN\totherEndLen\tdistSign\n")
+    keys, vals, nrows = ctx.read_chinput(empty, None)
+    assert nrows == 0 and keys.numel() == 0
+    assert int(ctx.count_join(t(ru_bait[:1000]), t(ru_oe[:1000]), keys, vals).abs().sum()) == 0
