@@ -42,7 +42,7 @@ struct chicdiff_hip_ctx {
     int device = 0;
     bool no_persistent_trend = false;  // set after a grid-barrier timeout (see fit_dev_impl)
     // tuning / test options (chicdiff_hip_set_option); the defaults are what the benchmarks run
-    int opt_spread = 1, opt_min_waves = 2, opt_select_rounds = 0, opt_trend_multilaunch = 0;
+    int opt_spread = 1, opt_min_waves = 2, opt_select_rounds = 0, opt_trend_multilaunch = 0, opt_schedule = 1, opt_deal = 0;
     int opt_trend_gather = 1;  // sharded fits: gather the rows of the trend on every rank (two collectives) instead of one all-reduce per IRLS pass
     char *tg_buf = nullptr;    // ... the gathered rows (grow-only)
     size_t tg_bytes = 0;
@@ -149,6 +149,8 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     const std::string k(name);
     if (k == "line_search_spread" && (value == 0 || value == 1)) c->opt_spread = (int)value;
     else if (k == "line_search_min_waves" && value >= 2 && value <= 4) c->opt_min_waves = (int)value;
+    else if (k == "line_search_schedule" && (value == 0 || value == 1)) c->opt_schedule = (int)value;
+    else if (k == "line_search_deal" && value >= 0 && value <= 64) c->opt_deal = (int)value;
     else if (k == "local_trend_substitute" && (value == 0 || value == 1)) c->opt_no_local_substitute = value ? 0 : 1;
     else if (k == "sharded_trend_gather" && (value == 0 || value == 1)) c->opt_trend_gather = (int)value;
     else if (k == "theta_grid_concurrency" && value >= 1 && value <= 16) c->opt_grid_lanes = (int)value;
@@ -389,7 +391,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
         c->ws = nullptr;
     }
     const size_t nd = align256(sizeof(double) * (size_t)n), ni = align256(sizeof(int32_t) * (size_t)n);
-    const size_t n_double_arrays = 15, n_int_arrays = 7;
+    const size_t n_double_arrays = 15, n_int_arrays = 8;
     const size_t partials = align256(sizeof(double) * ((size_t)kRedBlocks * 72 + 128));
     const size_t hist = align256(sizeof(double) * (size_t)kMaxS * 2 * kSelBins);
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
@@ -406,6 +408,8 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     takeD(w.crow); takeD(w.dispGene); takeD(w.dispFit); takeD(w.dispMAP); takeD(w.disp); takeD(w.beta0); takeD(w.beta1);
     takeD(w.resid);
     takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter); takeI(w.optimConv);
+    takeI(w.order);
+    { int32_t *q; takeI(q); w.cls = (uint8_t *)q; }
     w.partials = (double *)p; p += partials;
     w.hist = (double *)p; p += hist;
     w.hist_local = (double *)p; p += hist;
@@ -576,6 +580,8 @@ static Opts make_opts(const chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *in, 
     r.fit_type = o.fitType;
     r.spread = c->opt_spread;
     r.min_waves = c->opt_min_waves;
+    r.schedule = c->opt_schedule;
+    r.deal = c->opt_deal;
     return r;
 }
 
@@ -1266,6 +1272,8 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         chicdiff_hip_ctx *l = c->lanes[k];
         l->opt_spread = c->opt_spread;
         l->opt_min_waves = c->opt_min_waves;
+        l->opt_schedule = c->opt_schedule;
+        l->opt_deal = c->opt_deal;
         l->opt_no_local_substitute = c->opt_no_local_substitute;
         l->opt_trend_gather = c->opt_trend_gather;
         l->opt_select_rounds = c->opt_select_rounds;

@@ -22,6 +22,8 @@ struct FitWork {
     double *baseMean, *baseVar, *gm0, *gm1, *rough, *binit0, *binit1, *crow;
     double *dispGene, *dispFit, *dispMAP, *disp, *beta0, *beta1, *resid;
     int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter, *optimConv;
+    int32_t *order;               // schedule of the gene-wise line search: row indices, likely-long rows first (disp_kernels.hip)
+    uint8_t *cls;                 // ... and the class each row was put in (255 = all-zero row: not scheduled)
     double *partials;             // kRedBlocks x 72 doubles
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
     double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut
@@ -40,6 +42,8 @@ struct Opts {
     // tuning (chicdiff_hip_set_option): not part of the algorithm, results do not depend on them
     int32_t spread = 1;     // line search: samples-across-lanes evaluation for straggler waves (0 = row per lane only)
     int32_t min_waves = 2;  // line search: waves per SIMD the kernel variant is built for
+    int32_t schedule = 1;   // gene-wise line search: visit the rows likely-long first (0 = natural order through the queue)
+    int32_t deal = 0;       // ... entries per group of its static deal (0 = chosen from the number of entries per wave)
 };
 
 // ---- launchers (defined in the .hip files; all enqueue on `st` and never synchronise) -------
@@ -47,6 +51,7 @@ void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, 
 void launch_prep_finish(FitDims d, FitWork w, hipStream_t st);          // partials -> colsum,nnz
 void launch_xim(FitDims d, FitWork w, hipStream_t st);                  // colsum -> xim
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
+void launch_order_build(FitDims d, FitWork w, int classesA, hipStream_t st);  // w.cls -> w.order (schedule of a row-queue kernel)
 void launch_disp_map(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st);  // single rank: whole trend fit, one launch
 int trend_persistent_blocks();  // workgroups that must be co-resident (grid barrier): needs that many CUs

@@ -163,19 +163,124 @@ void launch_xim(FitDims d, FitWork w, hipStream_t st) { xim_kernel<<<1, 64, 0, s
 //   gene-wise (A2.3-2.4): alpha_init = clamp(min(roughDisp, momentsDisp)); rough[] <- alpha_init, resid[] <- log
 //   MAP (A4): dispFit, prior mean log(dispFit), start log(dispGeneEst > 0.1 dispFit ? dispGeneEst : dispFit),
 //             outlier flag log(dispGeneEst) > log(dispFit) + outlierSD * sqrt(varLogDispEsts)
+// ---- schedule of the gene-wise line search --------------------------------------------------------------------------
+// DESeq2's line search moves by kappa * dlp with kappa <= 1 shrinking by 0.8 every five accepted steps, so a row whose
+// likelihood is flat in log(alpha) — alpha * mu << 1, the near-Poisson corner — creeps for all 100 iterations and then
+// walks the 40 grid points: 2.7 % of the rows of the benchmark matrix take >= 50 iterations and hold 27 % of all ticks.
+// Which rows those are can be told beforehand: alpha_init * (smaller group mean) ranks them (400 k synthetic rows: the
+// lowest 8 % of the scores hold 82 % of the rows with >= 50 iterations, the lowest 23 % hold 99.2 %, the lowest 54 %
+// 99.95 %; rows that start at minDisp are never long).  A row dequeued late that needs 100 + 40 serial ticks IS the tail
+// of the launch (0.5 ms of 2.0 ms at 2 M rows, 0.55 of 0.72 ms at 250 k), so the rows are visited in score order:
+//   classes 0, 1 (score < 0.1, 0.32: 8 % of the rows, 82 % of the long ones) -> "A": dealt out statically, in groups of
+//       eight consecutive schedule entries round-robin over the waves, so every wave starts its share of the likely-long
+//       rows at once and — when rows are few (a rank's share of a sharded fit) — is left with a handful of them, which is
+//       what the samples-across-lanes evaluation wants (250 k x 8: 0.74 ms against 0.87 ms with the queue alone);
+//   classes 2..5 (score < 1, 3.2, 10; the rest and the minDisp starts) -> "B": the dynamic queue, in class order, after A.
+// Measured at 2 M x 8 (disp_gene incl. the two order_* launches): natural order 2.08-2.11 ms, class order through the
+// queue alone 1.92, A = classes 0-1 1.88-1.90, A = 0-2 1.90-1.95, A = 0-3 1.94-2.05, everything dealt statically 2.33-2.39:
+// the drain shrinks from 0.48 to 0.14 ms, but its ticks move into the bulk (143 -> 167 per wave), which is bound by fp64
+// issue — the launch cannot beat (all ticks) / (waves x lanes) ~ 1.7 ms.  At 250 k rows the launch stays at the latency of one
+// long row (~ 105 serial ticks at 3.6-4 us in the samples-across-lanes layout): 0.79 -> 0.74 ms.
+// Within a class rows keep their natural order (neighbouring lanes read neighbouring rows).  Results never depend on
+// the schedule (tests/test_gpu_parity.py::test_line_search_layouts_agree_bit_for_bit runs both).
+constexpr int kSchedClasses = 6, kSchedClassesA = 2, kSchedDeal = 8, kSchedBlocks = 1024;
+__device__ __forceinline__ int sched_class(double a0, double gmin, double minDisp) {
+    if (!(a0 > 1.5 * minDisp)) return 5;
+    const double s = a0 * gmin;
+    return s < 0.1 ? 0 : (s < 0.316 ? 1 : (s < 1.0 ? 2 : (s < 3.16 ? 3 : (s < 10.0 ? 4 : 5))));
+}
+// per-block class counts over contiguous tiles of rows: hist[class][block]
+__global__ __launch_bounds__(256) void order_hist_kernel(const uint8_t *__restrict__ cls, int64_t n, int64_t tile, unsigned int *hist) {
+    __shared__ unsigned int s_cnt[kSchedClasses];
+    if (threadIdx.x < kSchedClasses) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+    unsigned int mine[kSchedClasses] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int c = cls[i];
+#pragma unroll
+        for (int k = 0; k < kSchedClasses; k++) mine[k] += (c == k);
+    }
+#pragma unroll
+    for (int k = 0; k < kSchedClasses; k++) {
+        unsigned int v = mine[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < kSchedClasses) hist[threadIdx.x * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
+}
+// class-major exclusive scan of hist (every block recomputes the offsets it needs: 6 x 1024 entries from L2), then a
+// stable scatter of the block's rows: order[] = class 0 rows in row order, class 1 rows, ...
+__global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t *__restrict__ cls, int64_t n, int64_t tile,
+                                                            const unsigned int *__restrict__ hist, int32_t *__restrict__ order,
+                                                            FitScalars *sc, int classesA) {
+    __shared__ unsigned long long s_red[4];
+    __shared__ unsigned long long s_base[kSchedClasses + 1];
+    __shared__ unsigned int s_wcnt[4][kSchedClasses];
+    const int nblk = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // s_base[c] = number of schedule entries before this block's class-c rows; s_base[6] (block 0 only): totals
+    for (int c = 0; c <= kSchedClasses + 1; c++) {
+        // c <= 5: prefix up to (c, this block); c == 6: start of class kSchedClassesA (= |A|); c == 7: everything
+        const int target = c < kSchedClasses ? c * nblk + (int)blockIdx.x : (c == kSchedClasses ? classesA * nblk : kSchedClasses * nblk);
+        if (c >= kSchedClasses && blockIdx.x != 0) break;
+        unsigned long long part = 0;
+        for (int e = threadIdx.x; e < target; e += 256) part += hist[e];
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+        if (lane == 0) s_red[wave] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+            if (c < kSchedClasses) s_base[c] = tot;
+            else if (c == kSchedClasses) sc->ord_na = (int64_t)tot;
+            else sc->ord_n = (int64_t)tot;
+        }
+        __syncthreads();
+    }
+    const int64_t lo = (int64_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+    for (int64_t i0 = lo; i0 < hi; i0 += 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const int c = i < hi ? cls[i] : 255;
+        unsigned int rank = 0;
+#pragma unroll
+        for (int k = 0; k < kSchedClasses; k++) {
+            const unsigned long long m = __ballot(c == k);
+            if (c == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wcnt[wave][k] = __popcll(m);
+        }
+        __syncthreads();
+        if (c < kSchedClasses) {
+            unsigned int before = 0;
+            for (int w2 = 0; w2 < wave; w2++) before += s_wcnt[w2][c];
+            order[s_base[c] + before + rank] = (int32_t)i;
+        }
+        __syncthreads();
+        if (threadIdx.x < kSchedClasses) s_base[threadIdx.x] += s_wcnt[0][threadIdx.x] + s_wcnt[1][threadIdx.x] + s_wcnt[2][threadIdx.x] + s_wcnt[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
 template <bool MAP>
 __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Opts o) {
     const FitScalars *sc = w.sc;
     const double xim = sc->xim, c0 = sc->coefs[0], c1 = sc->coefs[1];
     const double out_thr = MAP ? o.outlierSD * sqrt(sc->varLogDispEsts) : 0.0;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
-        if (w.allZero[i]) continue;
+        if (w.allZero[i]) {
+            if (!MAP) {  // not scheduled at all (order_*): the line search never sees the row
+                w.cls[i] = 255;
+                w.dispGene[i] = NAN;
+                w.geneIter[i] = 0;
+            }
+            continue;
+        }
         const double bm = w.baseMean[i];
         if (!MAP) {
             const double moments = (w.baseVar[i] - xim * bm) / (bm * bm);
             const double a0 = fmin(fmax(o.minDisp, fmin(w.rough[i], moments)), o.maxDisp);
             w.rough[i] = a0;
             w.resid[i] = log(a0);
+            w.cls[i] = (uint8_t)sched_class(a0, d.p == 2 ? fmin(w.gm0[i], w.gm1[i]) : w.gm0[i], o.minDisp);
         } else {
             const double dg = w.dispGene[i], df = sc->trend_local ? w.dispFit[i] : c0 + c1 / bm;
             const double ldf = log(df);
@@ -198,6 +303,8 @@ struct DispArgs {
     Opts o;
     unsigned long long *stamps;  // CHICDIFF_DIAG builds only (make DIAG=1): per wave timestamps and tick counts
     int spread;                  // 0 = row-per-lane evaluation only (option "line_search_spread", for the bit-identity test)
+    const int32_t *order;        // gene-wise launch: the schedule (order_*); NULL = rows 0..n-1 through the queue (MAP, option "line_search_schedule" 0)
+    int deal;                    // entries per group of the static deal (0 = by the number of entries per wave)
 };
 #ifdef CHICDIFF_DIAG
 #define DIAG(...) __VA_ARGS__
@@ -432,6 +539,19 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     int is_outlier = 0;
     bool queue_empty = false;
     unsigned long long chunk_next = 0, chunk_end = 0;
+    // schedule (gene-wise launch): positions [0, nA) of order[] are dealt out statically — group g of kSchedDeal entries
+    // belongs to wave g mod W — the positions [nA, nTot) go through the queue; without a schedule the queue covers rows 0..n-1
+    const int32_t *__restrict__ order = MAP ? nullptr : A.order;
+    const unsigned long long nA = order ? (unsigned long long)sc->ord_na : 0ull;
+    const unsigned long long nTot = order ? (unsigned long long)sc->ord_n : (unsigned long long)n;
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+    const unsigned long long mywave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave;
+    unsigned long long a_k = 0;
+    bool a_done = nA == 0;
+    // entries per group of the deal: eight while every wave gets several groups (neighbouring rows, neighbouring lanes), down to
+    // one when rows are few, so that the likely-long rows spread evenly over the waves
+    unsigned long long deal = A.deal > 0 ? (unsigned long long)A.deal : nA / (4ull * nwaves);
+    deal = deal < 1 ? 1 : (deal > (unsigned long long)kSchedDeal ? (unsigned long long)kSchedDeal : deal);
     DIAG(const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;)
     DIAG(bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
          if (A.stamps && lane == 0) A.stamps[gwave * kStampSlots + 0] = __builtin_amdgcn_s_memrealtime();)
@@ -439,7 +559,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     for (;;) {
         // ---- refill: lanes without a row pull the next ones from the queue -----------------
 #pragma unroll 1
-        for (int attempt = 0; attempt < 4; attempt++) {
+        for (int attempt = 0; attempt < (MAP ? 4 : 10); attempt++) {
             const unsigned long long needmask = __ballot(phase == PH_NEED);
             if (!needmask) break;
             // rows come from a wave-private chunk: one atomic on the global head per kChunk rows
@@ -449,15 +569,26 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     if (phase == PH_NEED) phase = PH_DONE;
                     break;
                 }
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(queue, (unsigned long long)kChunk);
-                b = __shfl(b, 0);
-                if (b >= (unsigned long long)n) {
-                    queue_empty = true;
-                    continue;
+                if (!a_done) {  // this wave's next group of the static deal
+                    const unsigned long long start = (a_k * nwaves + mywave) * deal;
+                    a_k++;
+                    if (start >= nA) {
+                        a_done = true;
+                        continue;
+                    }
+                    chunk_next = start;
+                    chunk_end = start + deal < nA ? start + deal : nA;
+                } else {
+                    unsigned long long b = 0;
+                    if (lane == 0) b = atomicAdd(queue, (unsigned long long)kChunk);
+                    b = __shfl(b, 0) + nA;
+                    if (b >= nTot) {
+                        queue_empty = true;
+                        continue;
+                    }
+                    chunk_next = b;
+                    chunk_end = b + kChunk < nTot ? b + kChunk : nTot;
                 }
-                chunk_next = b;
-                chunk_end = b + kChunk < (unsigned long long)n ? b + kChunk : (unsigned long long)n;
             }
             const int cnt = __popcll(needmask);
             const unsigned long long base = chunk_next;
@@ -466,7 +597,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             chunk_next += (unsigned long long)take;
             if (phase == PH_NEED) {
                 const int rank = __popcll(needmask & ((1ull << lane) - 1ull));
-                const int64_t r = (int64_t)base + rank;
+                const int64_t r = rank >= take ? 0 : (order ? (int64_t)order[base + rank] : (int64_t)base + rank);
                 if (rank >= take) {
                     // chunk ran out: stay in PH_NEED, the next attempt opens a new chunk
                 } else if (A.w.allZero[r]) {
@@ -709,11 +840,24 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     })
 }
 
+// w.cls[] -> w.order[], sc->ord_na (entries of classes < classesA), sc->ord_n; w.hist is idle between the selects
+void launch_order_build(FitDims d, FitWork w, int classesA, hipStream_t st) {
+    int64_t nblk = (d.n + 255) / 256;
+    if (nblk > kSchedBlocks) nblk = kSchedBlocks;
+    const int64_t tile = ((d.n + nblk - 1) / nblk + 255) / 256 * 256;
+    nblk = (d.n + tile - 1) / tile;
+    unsigned int *hist = reinterpret_cast<unsigned int *>(w.hist);
+    order_hist_kernel<<<(unsigned)nblk, 256, 0, st>>>(w.cls, d.n, tile, hist);
+    order_scatter_kernel<<<(unsigned)nblk, 256, 0, st>>>(w.cls, d.n, tile, hist, w.order, w.sc, classesA);
+}
+
 static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                         hipStream_t st) {
     if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o);
     else disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o);
-    DispArgs A{counts, nf, d, w, o, nullptr, o.spread};
+    const bool sched = !map && o.schedule;
+    if (sched) launch_order_build(d, w, kSchedClassesA, st);  // the gene-wise launch visits the rows likely-long first
+    DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, o.deal};
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks
     int threads = 128;

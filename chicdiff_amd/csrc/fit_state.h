@@ -50,6 +50,9 @@ struct FitScalars {
     double sel_value[kMaxS * 2]; // selected order statistics
     uint32_t sel_cnt[kMaxS * 2]; // single-rank shortcut: candidates left after two rounds, per (column, slot)
     int32_t sel_fast_done, _pad2; // 1 = the shortcut resolved every order statistic of the running select
+    // schedule of the gene-wise line search (disp_kernels.hip: order_*): rows of order[0, ord_na) are dealt out statically,
+    // rows of order[ord_na, ord_n) through the queue; all-zero rows are in neither
+    int64_t ord_na, ord_n;
 };
 
 // order-preserving map double -> uint64 (NaN never passed in)

@@ -69,6 +69,9 @@ int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, 
 /* Tuning / test options; results never depend on them, the defaults are what bench.py measures.
  *   "line_search_spread"        1 (default) | 0: evaluate straggler rows with their samples spread across lanes
  *   "line_search_min_waves"     2 (default) .. 4: waves per SIMD the line-search kernel variant is built for
+ *   "line_search_schedule"      1 (default) | 0: the gene-wise line search visits the rows likely to need DESeq2's full 100
+ *                               iterations first (score alpha_init * smaller group mean); 0 = natural row order
+ *   "line_search_deal"          0 (default: chosen from the rows per wave), 1 .. 64: schedule entries per group of the static deal
  *   "theta_grid_concurrency"    5 (default), 1 .. 16: fits of the theta grid in flight at once (single rank only)
  *   "host_copy_threads"         12 (default), 1 .. 64: host threads staging caller buffers in chicdiff_hip_nbglm_fit
  *   "select_all_rounds"         0 (default) | 1: exact medians by histogram rounds only (no candidate-sort shortcut)

@@ -807,10 +807,16 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
         c = run()
     finally:
         ctx.set_option("line_search_spread", 1)
+    ctx.set_option("line_search_schedule", 0)  # natural row order through the queue instead of likely-long rows first
+    try:
+        e = run()
+    finally:
+        ctx.set_option("line_search_schedule", 1)
     assert (a["dispGeneIter"] >= 100).sum() > 10  # the stragglers this is about are present
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), f"{k}: two runs differ"
         assert np.array_equal(a[k], c[k], equal_nan=True), f"{k}: layouts differ in {np.sum(~((a[k] == c[k]) | (np.isnan(a[k]) & np.isnan(c[k]))))} rows"
+        assert np.array_equal(a[k], e[k], equal_nan=True), f"{k}: schedules differ in {np.sum(~((a[k] == e[k]) | (np.isnan(a[k]) & np.isnan(e[k]))))} rows"
 
 
 def test_bh_on_device(ctx, oracle):
