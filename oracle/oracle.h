@@ -38,6 +38,8 @@ typedef struct {
     int32_t noLocalSubstitute; /* 1: a failed parametric fit is reported (ORACLE_ST_TREND_FAILED) and the coefficients reached are kept */
     double varLogDispEsts; /* NaN = estimate (mad^2 of the log residuals); else as given: lets a SLICE of a larger fit be checked with
                               all three global scalars (trend, prior variance, this) pinned to the whole fit's */
+    double xim;            /* NaN = estimate (mean_j 1 / colMeans(nf)_j, momentsDispEstimate); else as given — the fourth global scalar: it
+                              enters every row's start value alpha_init = min(roughDisp, momentsDisp), hence where the search stops */
 } oracle_nbglm_opts;
 
 void oracle_nbglm_default_opts(oracle_nbglm_opts *o);
@@ -85,6 +87,11 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
 int oracle_arbitrate_disp(const int32_t *counts, const double *nf, int64_t n, int32_t S, const int32_t *group,
                           const int64_t *rows, int64_t nrows, int32_t stage, const double *dispInit, const double *dispGene,
                           const double *dispFit, double dispPriorVar, const oracle_nbglm_opts *opts, double *out);
+
+/* One row's IRLS iterates and conv_test values, without the stopping rule (the referee for rows whose two sides stop after a
+ * different number of steps; see nbglm_oracle.c). */
+int oracle_irls_trace(const int32_t *counts, const double *nf, int64_t n, int32_t S, const int32_t *group, int64_t row,
+                      double alpha, int32_t steps, double *b0_out, double *b1_out, double *conv_out);
 
 /* pieces exported for unit tests ------------------------------------------------------------- */
 double oracle_log_posterior(double log_alpha, const double *y, const double *mu, const int32_t *group,

@@ -35,7 +35,7 @@ class Opts(C.Structure):
                 ("maxit", C.c_int32), ("betaMaxit", C.c_int32), ("betaTol", C.c_double),
                 ("minmu", C.c_double), ("outlierSD", C.c_double), ("dispPriorVar", C.c_double),
                 ("nthreads", C.c_int32), ("_pad", C.c_int32), ("trendCoef", C.c_double * 2), ("fitType", C.c_int32),
-                ("noLocalSubstitute", C.c_int32), ("varLogDispEsts", C.c_double)]
+                ("noLocalSubstitute", C.c_int32), ("varLogDispEsts", C.c_double), ("xim", C.c_double)]
 
 
 _PD, _PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)
@@ -103,6 +103,7 @@ def lib():
         L.oracle_region_avdist.argtypes = [_PI, _PI, C.POINTER(C.c_int64), C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _PI, _PD]
         L.oracle_count_join_inner.argtypes = [_PI, _PI, C.c_int64, C.c_int32, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(_PI),
                                               C.POINTER(C.c_int64), _PI]
+        L.oracle_irls_trace.argtypes = [_PI, _PD, C.c_int64, C.c_int32, _PI, C.c_int64, C.c_double, C.c_int32, _PD, _PD, _PD]
         L.oracle_region_universe.argtypes = [_PI, _PI, C.c_int64, C.c_int32, _PI, C.c_int32, P64, _PI, _PI, _PI]
         _lib = L
     return _lib
@@ -154,6 +155,19 @@ def arbitrate_disp(counts, nf, group, rows, fit, stage="gene") -> np.ndarray:
     if rc:
         raise RuntimeError(f"oracle_arbitrate_disp rc={rc}")
     return out
+
+
+def irls_trace(counts, nf, group, row, alpha, steps=12):
+    """One row's IRLS iterates without the stopping rule: (lfc on the log2 scale per step, conv_test per step)."""
+    k = _cm(counts, np.int32)
+    f = _cm(nf, np.float64)
+    n, S = k.shape
+    g = np.ascontiguousarray(group, dtype=np.int32)
+    b0, b1, cv = np.empty(steps), np.empty(steps), np.empty(steps)
+    rc = lib().oracle_irls_trace(_pi(k), _pd(f), n, S, _pi(g), int(row), float(alpha), steps, _pd(b0), _pd(b1), _pd(cv))
+    if rc:
+        raise RuntimeError(f"oracle_irls_trace rc={rc}")
+    return b1 / np.log(2.0), cv
 
 
 def size_factors(counts) -> np.ndarray:

@@ -552,6 +552,86 @@ def test_fragment_background(ctx, oracle):
     assert np.allclose(F.cpu().numpy(), Fr, rtol=1e-13, equal_nan=True)
 
 
+FULL_WANT = ["log2FoldChange", "pvalue", "stat", "dispersion", "dispGeneEst", "dispMAP", "dispFit", "dispOutlier", "dispIter", "betaConv", "betaIter"]
+
+
+def assert_rows_explained(tag, oracle, d, group, got, ref, dispPriorVar, maxit=100, gene_listed=None):
+    """Full-size comparison of two fits that share their global scalars (trend, prior variance): EVERY non-all-zero row
+    must agree — dispersion to 1e-6, log2FoldChange to 1e-6 * max(|lfc|, 1e-2), p to 1e-6 * max(1, z^2) (a relative change
+    eps of the Wald statistic z changes a tail p-value by ~ z^2 eps) — or be on the list this function builds, and every
+    listed row has a referee that shows the difference to be a stopping decision inside rounding noise:
+      gene : gene-wise line search ended elsewhere       -> binary128 re-run (oracle_arbitrate_disp, stage 0) sides with one side
+      map  : MAP line search ended elsewhere              -> binary128 re-run (stage 1) sides with one side
+      irls : the IRLS stopped one step apart              -> conv_test at the disputed step is within 1e-3 of betaTol, and each
+                                                             side's estimate is the trace's iterate at its own step count
+    No blanket allowance: returns the list (written to gpurun_out/ for profiles/)."""
+    n = len(ref["allZero"])
+    live = ref["allZero"] == 0
+    listed = []
+    # gene-wise stage (the caller may have arbitrated these rows already)
+    gene_off = np.flatnonzero(live & ((ref["dispGeneEst"] > 1e-6) | (got["dispGeneEst"] > 1e-6)) & (rel(got["dispGeneEst"], ref["dispGeneEst"]) > 1e-6))
+    if gene_listed is None:
+        arb = oracle.arbitrate_disp(d["counts"], d["nf"], group, gene_off, ref) if len(gene_off) else np.empty(0)
+        eg, eo = rel(got["dispGeneEst"][gene_off], arb), rel(ref["dispGeneEst"][gene_off], arb)
+        assert int(((eg > 1e-6) & (eo > 1e-6)).sum()) <= 2, (tag, "gene-wise rows neither side gets right")
+        listed += [dict(row=int(i), kind="gene", gpu=float(got["dispGeneEst"][i]), oracle=float(ref["dispGeneEst"][i]), referee=float(a))
+                   for i, a in zip(gene_off, arb)]
+    else:
+        assert set(gene_off.tolist()) <= set(gene_listed), (tag, "gene-wise rows off that the caller did not arbitrate")
+    in_gene = np.zeros(n, dtype=bool)
+    in_gene[gene_off] = True
+    if gene_listed is not None:
+        in_gene[np.asarray(sorted(gene_listed), dtype=np.int64)] = True
+    assert len(gene_off) <= 3e-5 * live.sum(), (tag, len(gene_off))
+    # MAP stage, rows whose gene-wise estimates agree
+    assert np.allclose(got["dispFit"][live], ref["dispFit"][live], rtol=1e-12), tag   # same trend on both sides
+    map_off = np.flatnonzero(live & ~in_gene & (rel(got["dispMAP"], ref["dispMAP"]) > 1e-6))
+    if len(map_off):
+        arb = oracle.arbitrate_disp(d["counts"], d["nf"], group, map_off,
+                                    dict(dispGeneEst=ref["dispGeneEst"], dispFit=ref["dispFit"], dispPriorVar=dispPriorVar), stage="map")
+        eg, eo = rel(got["dispMAP"][map_off], arb), rel(ref["dispMAP"][map_off], arb)
+        assert np.all((eg <= 1e-6) | (eo <= 1e-6)), (tag, "MAP rows neither side gets right", map_off[(eg > 1e-6) & (eo > 1e-6)])
+        listed += [dict(row=int(i), kind="map", gpu=float(got["dispMAP"][i]), oracle=float(ref["dispMAP"][i]), referee=float(a),
+                        iters=[int(got["dispIter"][i]), int(ref["dispIter"][i])]) for i, a in zip(map_off, arb)]
+    assert len(map_off) <= 1e-5 * live.sum() + 2, (tag, len(map_off))
+    disp_listed = in_gene.copy()
+    disp_listed[map_off] = True
+    rd = rel(got["dispersion"], ref["dispersion"])
+    assert not np.any(live & ~disp_listed & (rd > 1e-6)), (tag, "dispersion off on unlisted rows", np.flatnonzero(live & ~disp_listed & (rd > 1e-6))[:10])
+    assert np.array_equal(got["dispOutlier"][live & ~disp_listed], ref["dispOutlier"][live & ~disp_listed]), tag
+    # Wald stage
+    optim = live & ((got["betaIter"] >= maxit) | (ref["betaIter"] >= maxit))
+    flip = np.flatnonzero(live & ~disp_listed & ~optim & (got["betaIter"] != ref["betaIter"]))
+    for i in flip:
+        kg, ko = int(got["betaIter"][i]), int(ref["betaIter"][i])
+        lfc, cv = oracle.irls_trace(d["counts"], d["nf"], group, i, ref["dispersion"][i], steps=max(kg, ko) + 1)
+        t = min(kg, ko)
+        assert abs(kg - ko) == 1 and abs(cv[t - 1] / 1e-8 - 1.0) < 1e-3, (tag, "IRLS steps differ but conv_test is not at the tolerance", int(i), kg, ko, cv[:t + 1])
+        assert abs(got["log2FoldChange"][i] - lfc[kg - 1]) <= 1e-9 * max(abs(lfc[kg - 1]), 1e-2) and abs(ref["log2FoldChange"][i] - lfc[ko - 1]) <= 1e-9 * max(abs(lfc[ko - 1]), 1e-2), (tag, int(i))
+        listed.append(dict(row=int(i), kind="irls", steps=[kg, ko], conv_test_at_disputed_step=float(cv[t - 1]), gpu=float(got["log2FoldChange"][i]),
+                           oracle=float(ref["log2FoldChange"][i])))
+    assert len(flip) <= 5e-6 * live.sum() + 2, (tag, len(flip))
+    wald_listed = disp_listed.copy()
+    wald_listed[flip] = True
+    chk = live & ~wald_listed
+    assert np.array_equal(got["betaConv"][chk], ref["betaConv"][chk]), tag
+    dl = np.abs(got["log2FoldChange"] - ref["log2FoldChange"])
+    bad = chk & ~(dl <= 1e-6 * np.maximum(np.abs(ref["log2FoldChange"]), 1e-2))
+    assert not bad.any(), (tag, "log2FoldChange off on unlisted rows", np.flatnonzero(bad)[:10], dl[bad][:10])
+    z2 = np.maximum(1.0, ref["stat"] ** 2)
+    badp = chk & ~(rel(got["pvalue"], ref["pvalue"]) <= 1e-6 * z2)
+    assert not badp.any(), (tag, "pvalue off on unlisted rows", np.flatnonzero(badp)[:10])
+    n_optim = int((chk & optim).sum())   # rows through the optim fallback are held to the same bounds (not masked)
+    kinds = {k: sum(1 for x in listed if x["kind"] == k) for k in ("gene", "map", "irls")}
+    print(f"{tag}: {int(live.sum())} rows, every one within bounds except {len(listed)} refereed rows {kinds}; {n_optim} optim-fallback rows inside the bounds; "
+          f"max rel dispersion {rd[chk].max():.2e}, lfc {(dl[chk] / np.maximum(np.abs(ref['log2FoldChange'][chk]), 1e-2)).max():.2e}, "
+          f"p/(z^2) {(rel(got['pvalue'], ref['pvalue'])[chk] / z2[chk]).max():.2e}")
+    PARITY_LOG.append(dict(test="assert_rows_explained", column=tag, rows=int(live.sum()), tol=1e-6, max_rel=float(rd[chk].max()), rows_off=len(listed),
+                           frac_within=1.0 - len(listed) / max(int(live.sum()), 1), required_frac=1.0, loose=None, rows_beyond_loose=0,
+                           noise_rows_allowed=0, refereed=kinds))
+    return listed, wald_listed
+
+
 def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     """BASELINE.json configs[2] (2 M x 8, 4v4) at full size, every row against the oracle (run on the host
     cores), plus a size-independent property (row permutation).
@@ -576,7 +656,7 @@ def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     n, S = 2_000_000, 8
     d = synth.make(n, S)
     dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64)
-    want = ["log2FoldChange", "pvalue", "dispersion", "dispGeneEst"]
+    want = FULL_WANT
     out, sc = ctx.nbglm_fit(dk, dn, d["group"], want=want)
     got = {k: v.cpu().numpy() for k, v in out.items()}
     threads = min(16, os.cpu_count() or 1)
@@ -614,27 +694,36 @@ def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     c_arb, it_arb, rc = oracle.parametric_dispersion_fit(ref["baseMean"][use], dg[use])
     print("trend: arbitrated", c_arb, "GPU", sc["trendCoef"], "oracle", ref["trendCoef"])
     assert rc == 0 and np.allclose(c_arb, sc["trendCoef"], rtol=2e-5) and np.allclose(c_arb, ref["trendCoef"], rtol=2e-5)
-    # (3a) the oracle under the GPU's trend against the GPU's free fit
+    # (3a) the oracle under the GPU's trend against the GPU's free fit: every row, no blanket allowance
     ref_g = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], nthreads=threads, trendCoef=sc["trendCoef"])
-    keep = nz.copy()
-    keep[bad] = False  # listed above; their MAP start value / outlier flag follow each side's own gene-wise estimate
     assert np.isclose(sc["varLogDispEsts"], ref_g["varLogDispEsts"], rtol=1e-5)
-    check_close("dispersion(2M, free fit | trend)", got["dispersion"], ref_g["dispersion"], keep, 1e-6)
-    check_close("lfc(2M, free fit | trend)", got["log2FoldChange"], ref_g["log2FoldChange"], keep & big, 1e-6)
-    check_close("pvalue(2M, free fit | trend)", got["pvalue"], ref_g["pvalue"], keep, 1e-6)
-    # the two free fits against each other: what the 6th-digit trend shift does to every row — plus the few rows
-    # (<= 3 per 100 000) sitting within that shift of the outlier threshold log(dispFit) + 2 sd, which flip between
-    # their gene-wise and their MAP estimate
-    check_close("dispersion(2M, free vs free)", got["dispersion"], ref["dispersion"], keep, 2e-5, 0.999, noise_rows=60)
-    check_close("pvalue(2M, free vs free)", got["pvalue"], ref["pvalue"], keep, 2e-4, 0.999, noise_rows=60)
+    listed_a, wl_a = assert_rows_explained("2M x 8, GPU free fit vs oracle under the GPU's trend", oracle, d, d["group"], got, ref_g, ref_g["dispPriorVar"],
+                                           gene_listed=[int(i) for i in bad])
     # (3b) the GPU under the oracle's global scalars against the oracle's free fit
     opts = hip.default_opts(trendCoef=ref["trendCoef"], dispPriorVar=ref["dispPriorVar"])
     out2, sc2 = ctx.nbglm_fit(dk, dn, d["group"], want=want, opts=opts)
     got2 = {k: v.cpu().numpy() for k, v in out2.items()}
     assert np.array_equal(sc2["trendCoef"], ref["trendCoef"]) and sc2["dispPriorVar"] == ref["dispPriorVar"]
-    check_close("dispersion(2M, pinned)", got2["dispersion"], ref["dispersion"], keep, 1e-6)
-    check_close("lfc(2M, pinned)", got2["log2FoldChange"], ref["log2FoldChange"], keep & big, 1e-6)
-    check_close("pvalue(2M, pinned)", got2["pvalue"], ref["pvalue"], keep, 1e-6)
+    listed_b, wl_b = assert_rows_explained("2M x 8, GPU under the oracle's scalars vs oracle free fit", oracle, d, d["group"], got2, ref, ref["dispPriorVar"],
+                                           gene_listed=[int(i) for i in bad])
+    # The two FREE fits against each other = (3a) + what the 6th-digit trend shift does to the oracle itself (ref_g vs ref: the
+    # same code, the same rounding, trend coefficients 2e-5 apart).  Nothing to allow here: every row is either refereed above
+    # or within 1e-6 of the oracle under the same trend; what remains is the algorithm's own sensitivity, reported as such —
+    # a row whose MAP search stops one step earlier under a prior mean shifted by 2e-6 lands up to a few per cent away.
+    live = ref["allZero"] == 0
+    rs = rel(ref_g["dispersion"], ref["dispersion"])
+    shift_rows = np.flatnonzero(live & (rs > 1e-3))
+    rf = rel(got["dispersion"], ref["dispersion"])
+    far = np.flatnonzero(live & (rf > 1e-3))
+    assert set(far.tolist()) <= set(shift_rows.tolist()) | set(np.flatnonzero(wl_a).tolist()), "free vs free: a row beyond 1e-3 that neither the trend shift nor a referee explains"
+    assert np.array_equal(got["dispOutlier"][live & ~wl_a], ref_g["dispOutlier"][live & ~wl_a])
+    print(f"free vs free: dispersion beyond 2e-5 on {int((live & (rf > 2e-5)).sum())} rows, beyond 1e-3 on {len(far)}; the oracle against ITSELF under the GPU's "
+          f"trend coefficients (rel. shift {np.max(rel(sc['trendCoef'], ref['trendCoef'])):.1e}): beyond 2e-5 on {int((live & (rs > 2e-5)).sum())} rows, beyond 1e-3 on {len(shift_rows)}")
+    assert len(shift_rows) <= 2e-5 * live.sum()   # (a property of DESeq2's stopping rule under a perturbed prior, not of the GPU path)
+    json.dump(dict(n=n, S=S, same_trend_gpu_vs_oracle=listed_a, pinned_scalars_gpu_vs_oracle=listed_b,
+                   trend_shift_rows=[dict(row=int(i), oracle_own_trend=float(ref["dispersion"][i]), oracle_gpu_trend=float(ref_g["dispersion"][i]),
+                                          gpu=float(got["dispersion"][i]), map_iters=[int(ref["dispIter"][i]), int(ref_g["dispIter"][i])]) for i in shift_rows]),
+              open("gpurun_out/refereed_rows_2Mx8.json", "w"), indent=1)
     # (4) permuting the rows permutes the results (order-free sums, exact medians)
     perm = torch.randperm(n, device=ctx.device, generator=torch.Generator(device=ctx.device).manual_seed(0))
     p1 = out["pvalue"][perm].cpu().numpy()
@@ -659,10 +748,14 @@ def test_full_size_C2_200k_x4_2v2_against_oracle(ctx, oracle):
     print("dispPriorVar", sc["dispPriorVar"], ref["dispPriorVar"], "trend", sc["trendCoef"], ref["trendCoef"])
     assert sc["dispPriorVar"] == ref["dispPriorVar"]
     assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6) and sc["trendOuterIter"] == ref["trendOuterIter"]
+    # every row, optim-fallback rows included: within bounds or refereed.  The two fits are free, but their global scalars
+    # coincide (prior variance exactly — it is the argmin over a grid — and the trend to 1e-6), so the same-trend rule applies
+    # after handing the oracle the GPU's coefficients
+    ref_g = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], nthreads=min(16, os.cpu_count() or 1), trendCoef=sc["trendCoef"])
+    assert ref_g["dispPriorVar"] == sc["dispPriorVar"]
+    assert_rows_explained("C2 (200 000 x 4, 2v2), GPU free fit vs oracle under the GPU's trend", oracle, d, d["group"], got, ref_g, sc["dispPriorVar"])
     nz = (ref["allZero"] == 0) & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
-    check_close("dispersion(C2)", got["dispersion"], ref["dispersion"], nz, 1e-6)
-    check_close("lfc(C2)", got["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-2), 1e-6)
-    check_close("pvalue(C2)", got["pvalue"], ref["pvalue"], nz, 1e-6)
+    check_close("dispersion(C2, free vs free)", got["dispersion"], ref["dispersion"], nz, 1e-5, 0.9999)
     assert np.all(np.isnan(got["maxCooks"]))  # no group with >= 3 replicates
     # a heterogeneous 2v2 matrix of the same size: the prior variance lands above DESeq2's 0.25 floor
     from test_oracle import heterogeneous_counts
@@ -1569,7 +1662,8 @@ def test_full_size_C5_20M_x16_pipeline_properties_and_slice_parity(ctx, oracle):
         dk[:, lo:lo + m] = torch.poisson(lam, generator=g).to(torch.int32)
         dfm[:, lo:lo + m] = r * (mu[None, :] / S)  # region-level FullMean
         del mu, alpha, lfc, r, mean, lam
-    want = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue", "maxCooks", "cooksArgmax", "allZero", "betaConv"]
+    want = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue", "maxCooks", "cooksArgmax", "allZero", "betaConv", "betaIter",
+            "dispGeneEst", "dispMAP", "dispFit", "dispOutlier", "dispIter"]
     out, sc = ctx.wald_test(dk, dfm, group, theta=0.5, want=want)
     print("C5 scalars", {k: sc[k] for k in ("trendCoef", "varLogDispEsts", "dispPriorVar", "nAllZero", "status")})
     assert not (sc["status"] & 1) and not (sc["status"] & 2)
@@ -1613,17 +1707,20 @@ def test_full_size_C5_20M_x16_pipeline_properties_and_slice_parity(ctx, oracle):
     lo, hi = 7_000_000, 7_200_000
     d_nf = ctx.offsets(dfm, sc["sizeFactors"], 0.5)
     cs, nfs = dk[:, lo:hi].T.cpu().numpy(), d_nf[:, lo:hi].T.cpu().numpy()
-    del d_nf
+    # the fourth global scalar, xim = mean_j 1 / colMeans(nf)_j over the non-all-zero rows (it enters every start value)
+    colmeans = (d_nf * (out["allZero"] == 0)).sum(1) / float(n - sc["nAllZero"])
+    xim = float((1.0 / colmeans).mean())
     ref = oracle.nbglm_fit(cs, nfs, group, nthreads=min(16, os.cpu_count() or 1), trendCoef=sc["trendCoef"], dispPriorVar=sc["dispPriorVar"],
-                           varLogDispEsts=sc["varLogDispEsts"])
-    sl = {k: out[k][lo:hi].cpu().numpy() for k in ("baseMean", "dispersion", "log2FoldChange", "lfcSE", "maxCooks", "betaConv")}
-    praw = p_raw[lo:hi].cpu().numpy()
-    nz = (ref["allZero"] == 0) & (ref["betaConv"] == 1) & (sl["betaConv"] == 1)
+                           varLogDispEsts=sc["varLogDispEsts"], xim=xim)
+    del d_nf, colmeans
+    sl = {k: out[k][lo:hi].cpu().numpy() for k in want if k != "pvalue"}
+    sl["pvalue"] = p_raw[lo:hi].cpu().numpy()
+    # every row of the slice, optim-fallback rows included: within bounds or refereed (binary128 line search, IRLS trace)
+    listed, wl = assert_rows_explained("C5 slice (200 000 of 20 M x 16), scalars pinned to the whole fit's", oracle, dict(counts=cs, nf=nfs), group, sl, ref,
+                                       sc["dispPriorVar"])
+    nz = (ref["allZero"] == 0) & ~wl
     check_close("baseMean(C5 slice)", sl["baseMean"], ref["baseMean"], nz, 1e-13, 1.0)
-    check_close("dispersion(C5 slice)", sl["dispersion"], ref["dispersion"], nz, 1e-6)
-    check_close("lfc(C5 slice)", sl["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-2), 1e-6)
-    check_close("pvalue(C5 slice)", praw, ref["pvalue"], nz, 1e-6)
-    check_close("maxCooks(C5 slice)", sl["maxCooks"], ref["maxCooks"], nz & (ref["maxCooks"] > 1e-12), 1e-5)
+    check_close("maxCooks(C5 slice)", sl["maxCooks"], ref["maxCooks"], nz & (ref["maxCooks"] > 1e-12), 1e-5, 1.0)
     # row permutation
     del av, ihw, w, wp
     perm = torch.randperm(n, device=dev, generator=g)
