@@ -396,7 +396,8 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     const size_t hist = align256(sizeof(double) * (size_t)kMaxS * 2 * kSelBins);
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
     const size_t selcnt = align256(sizeof(double) * (size_t)kSelMaxWorld * kMaxS * 2);
-    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + 2 * hist + selcnt + align256(sizeof(FitScalars)) + 256 + 1024 + nfbytes;
+    const size_t rowpack = align256((size_t)row_stride(S) * (size_t)n);
+    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + 2 * hist + selcnt + align256(sizeof(FitScalars)) + 256 + 1024 + nfbytes + rowpack;
     hipError_t e = hipMalloc(&c->ws, total);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "workspace of %zu bytes: %s", total, hipGetErrorString(e));
     c->ws_bytes = total;
@@ -418,7 +419,8 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     w.logfact = c->d_logfact;
     w.queue = (unsigned long long *)p; p += 256;
     w.barrier = (unsigned int *)p; p += 1024;
-    c->d_nf_tmp = (double *)p;
+    c->d_nf_tmp = (double *)p; p += nfbytes;
+    w.rowpack = p;
     c->cap_n = n;
     c->cap_S = S;
     return CHICDIFF_OK;
@@ -440,7 +442,36 @@ static int ensure_aux(chicdiff_hip_ctx *c, size_t bytes) {
 
 static int do_allreduce(chicdiff_hip_ctx *c, double *dev, int64_t count) {
     if (!c->allreduce) return CHICDIFF_OK;  // a callback registered with world_size 1 is still called (tests)
-    if (c->allreduce(c->allreduce_user, dev, count) != 0) return fail(c, CHICDIFF_E_COMM, "all-reduce callback failed");
+    // with timing on, every collective gets an event pair of its own, whatever scope it sits in: "allreduce" in
+    // chicdiff_hip_kernel_times = number of collectives of the call and their summed duration on the stream (that time is ALSO
+    // inside the enclosing scope's figure — size_factors, trend_fit, mad_select — so it is a breakdown, not an extra term)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int idx = -1;
+    if (c->timing) {
+        for (size_t i = 0; i < c->timers.size(); i++)
+            if (c->timers[i].name == "allreduce") idx = (int)i;
+        if (idx < 0) {
+            KTimer t;
+            t.name = "allreduce";
+            c->timers.push_back(t);
+            idx = (int)c->timers.size() - 1;
+        }
+        auto take = [&]() {
+            hipEvent_t e = nullptr;
+            if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); } else (void)hipEventCreate(&e);
+            return e;
+        };
+        e0 = take();
+        e1 = take();
+        (void)hipEventRecord(e0, c->stream);
+    }
+    const int rc = c->allreduce(c->allreduce_user, dev, count);
+    if (idx >= 0) {
+        (void)hipEventRecord(e1, c->stream);
+        c->pending.push_back({idx, e0});
+        c->pending.push_back({idx, e1});
+    }
+    if (rc != 0) return fail(c, CHICDIFF_E_COMM, "all-reduce callback failed");
     return CHICDIFF_OK;
 }
 
@@ -1226,7 +1257,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
     // opt_grid_lanes at once, each driven by its own host thread: one fit's straggler tail and its latency-bound
     // global steps (trend barriers, selects) overlap with the other fits' line searches.  Sharded: one after the other
     // (every rank must issue its collectives in the same order).
-    const size_t ws_per_lane = sizeof(double) * (size_t)n * (22 + S) + (64u << 20);
+    const size_t ws_per_lane = sizeof(double) * (size_t)n * (22 + S) + (size_t)row_stride(S) * (size_t)n + (64u << 20);
     int lanes = c->allreduce ? 1 : (ntheta < c->opt_grid_lanes ? ntheta : c->opt_grid_lanes);
     if (lanes > 1) {
         // the lanes' workspaces must fit what the device has free NOW (a shared GPU, the caller's own tensors, a smaller
@@ -1272,7 +1303,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         chicdiff_hip_ctx *l = c->lanes[k];
         l->opt_spread = c->opt_spread;
         l->opt_min_waves = c->opt_min_waves;
-        l->opt_schedule = c->opt_schedule;
+        l->opt_schedule = c->opt_schedule ? 2 : 0;  // concurrent fits: class order through the queue, nothing dealt out statically
         l->opt_deal = c->opt_deal;
         l->opt_no_local_substitute = c->opt_no_local_substitute;
         l->opt_trend_gather = c->opt_trend_gather;

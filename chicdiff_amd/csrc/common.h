@@ -24,6 +24,9 @@ struct FitWork {
     int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter, *optimConv;
     int32_t *order;               // schedule of the gene-wise line search: row indices, likely-long rows first (disp_kernels.hip)
     uint8_t *cls;                 // ... and the class each row was put in (255 = all-zero row: not scheduled)
+    char *rowpack;                // row-major copy of the fit's inputs, row i at rowpack + i * row_stride(S): nf[S] doubles, then counts[S]
+                                  // int32 (written by prep): the row-queue kernels visit rows out of order, and a row that is 12 S
+                                  // contiguous bytes costs one or two cache lines instead of 2 S
     double *partials;             // kRedBlocks x 72 doubles
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
     double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut
@@ -34,6 +37,8 @@ struct FitWork {
     const double *logfact;        // log(k!) for k < kLogFactN
 };
 constexpr int kLogFactN = 1024;
+// bytes between rows of FitWork::rowpack: 12 S rounded up so that a row never straddles more 128-byte lines than it must
+__host__ __device__ inline int64_t row_stride(int S) { return S * 12 <= 64 ? 64 : ((int64_t)S * 12 + 127) / 128 * 128; }
 
 struct Opts {
     double minDisp, dispTol, kappa0, betaTol, minmu, outlierSD, dispPriorVarIn, maxDisp, trendIn[2];
@@ -42,9 +47,31 @@ struct Opts {
     // tuning (chicdiff_hip_set_option): not part of the algorithm, results do not depend on them
     int32_t spread = 1;     // line search: samples-across-lanes evaluation for straggler waves (0 = row per lane only)
     int32_t min_waves = 2;  // line search: waves per SIMD the kernel variant is built for
-    int32_t schedule = 1;   // gene-wise line search: visit the rows likely-long first (0 = natural order through the queue)
+    int32_t schedule = 1;   // gene-wise line search / IRLS: visit the rows likely-long first (0 = natural order; 2 = class order through the queue only)
     int32_t deal = 0;       // ... entries per group of its static deal (0 = chosen from the number of entries per wave)
 };
+
+// one row of FitWork::rowpack -> the wave's LDS slice ([sample][lane]); 16-byte loads when S is a multiple of four
+__device__ __forceinline__ void load_row(const char *rowpack, int64_t r, int S, double *s_nf, int *s_y, int lane) {
+    const char *row = rowpack + r * row_stride(S);
+    if ((S & 3) == 0) {
+        const double2 *pf = reinterpret_cast<const double2 *>(row);
+        const int4 *py = reinterpret_cast<const int4 *>(row + 8 * S);
+        for (int j = 0; j < S; j += 4) {
+            const double2 a = pf[j >> 1], b = pf[(j >> 1) + 1];
+            const int4 y = py[j >> 2];
+            s_nf[j * 64 + lane] = a.x; s_nf[(j + 1) * 64 + lane] = a.y; s_nf[(j + 2) * 64 + lane] = b.x; s_nf[(j + 3) * 64 + lane] = b.y;
+            s_y[j * 64 + lane] = y.x; s_y[(j + 1) * 64 + lane] = y.y; s_y[(j + 2) * 64 + lane] = y.z; s_y[(j + 3) * 64 + lane] = y.w;
+        }
+    } else {
+        const double *pf = reinterpret_cast<const double *>(row);
+        const int *py = reinterpret_cast<const int *>(row + 8 * S);
+        for (int j = 0; j < S; j++) {
+            s_nf[j * 64 + lane] = pf[j];
+            s_y[j * 64 + lane] = py[j];
+        }
+    }
+}
 
 // ---- launchers (defined in the .hip files; all enqueue on `st` and never synchronise) -------
 void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);

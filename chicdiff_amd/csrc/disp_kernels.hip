@@ -41,44 +41,70 @@ __device__ __forceinline__ void prep_store(FitDims d, FitWork w, int64_t i, doub
     w.allZero[i] = (tot == 0);
 }
 
-// S <= 16: the row's q_j live in registers — one read of counts and offsets, one division per sample
+// S <= 16: the row's q_j live in registers — one read of counts and offsets, one division per sample.  The same pass writes
+// FitWork::rowpack, the row-major copy the row-queue kernels read (a row = 12 S contiguous bytes): the block's 256 rows go
+// through an LDS tile (row pitch + 1 dword: conflict-free both ways) and leave as one contiguous run of 16-byte stores.
+// (Measured, 2 M x 8: with every thread storing its own row straight to global memory — 16 partial-line stores per row — the
+// pass took 0.47 ms instead of 0.12; through the tile it is 0.19 ms, and the three row-queue kernels gain 0.46 ms.)
 __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__ counts,
                                                      const double *__restrict__ nf, FitDims d, FitWork w) {
+    extern __shared__ uint32_t s_tile[];  // T rows x (stride / 4 + 1) dwords, T = blockDim.x (256, or 128 when a row is longer than 128 bytes)
+    const int T = blockDim.x;
     const int64_t n = d.n;
     const int S = d.S;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double q[16];
-        double s = 0, g0 = 0, g1 = 0;
-        int64_t tot = 0;
-        int32_t sign = 0;
+    const int64_t stride = row_stride(S);
+    const int ldw = (int)(stride / 4) + 1, qpr = (int)(stride / 16);  // tile pitch in dwords; 16-byte chunks per row
+    const int tid = threadIdx.x;
+    for (int64_t base = (int64_t)blockIdx.x * T; base < n; base += (int64_t)gridDim.x * T) {
+        const int64_t i = base + tid;
+        const int nrows = n - base < T ? (int)(n - base) : T;
+        if (i < n) {
+            double q[16];
+            double s = 0, g0 = 0, g1 = 0;
+            int64_t tot = 0;
+            int32_t sign = 0;
+            uint32_t *row = s_tile + tid * ldw;
+            for (int k = 3 * S; k < (int)(stride / 4); k++) row[k] = 0;  // the pad behind the row
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            q[j] = 0;
-            if (j < S) {
-                const int32_t k = counts[(int64_t)j * n + i];
-                sign |= k;
-                q[j] = (double)k / nf[(int64_t)j * n + i];
-                tot += k;
-                s += q[j];
-                if ((d.gmask >> j) & 1) g1 += q[j]; else g0 += q[j];
+            for (int j = 0; j < 16; j++) {
+                q[j] = 0;
+                if (j < S) {
+                    const int32_t k = counts[(int64_t)j * n + i];
+                    const double f = nf[(int64_t)j * n + i];
+                    row[2 * j] = (uint32_t)__double2loint(f);
+                    row[2 * j + 1] = (uint32_t)__double2hiint(f);
+                    row[2 * S + j] = (uint32_t)k;
+                    sign |= k;
+                    q[j] = (double)k / f;
+                    tot += k;
+                    s += q[j];
+                    if ((d.gmask >> j) & 1) g1 += q[j]; else g0 += q[j];
+                }
             }
+            const double bm = s / S;
+            g0 /= d.nA;
+            if (d.p == 2) g1 /= d.nB;
+            const double m0 = fmax(1.0, g0), m1 = fmax(1.0, g1);
+            const double i0 = 1.0 / (m0 * m0), i1 = 1.0 / (m1 * m1);  // two divisions per row instead of one per sample
+            double v = 0, est = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (j < S) {
+                    v += (q[j] - bm) * (q[j] - bm);
+                    const bool g = (d.gmask >> j) & 1;
+                    const double mj = g ? m1 : m0;
+                    est += ((q[j] - mj) * (q[j] - mj) - mj) * (g ? i1 : i0);
+                }
+            prep_store(d, w, i, s, g0, g1, v, est, tot);
+            if (sign < 0) w.sc->neg_counts = 1;  // NA_integer_ / negative count: the fit is refused (include/chicdiff_hip.h)
         }
-        const double bm = s / S;
-        g0 /= d.nA;
-        if (d.p == 2) g1 /= d.nB;
-        const double m0 = fmax(1.0, g0), m1 = fmax(1.0, g1);
-        const double i0 = 1.0 / (m0 * m0), i1 = 1.0 / (m1 * m1);  // two divisions per row instead of one per sample
-        double v = 0, est = 0;
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            if (j < S) {
-                v += (q[j] - bm) * (q[j] - bm);
-                const bool g = (d.gmask >> j) & 1;
-                const double mj = g ? m1 : m0;
-                est += ((q[j] - mj) * (q[j] - mj) - mj) * (g ? i1 : i0);
-            }
-        prep_store(d, w, i, s, g0, g1, v, est, tot);
-        if (sign < 0) w.sc->neg_counts = 1;  // NA_integer_ / negative count: the fit is refused (include/chicdiff_hip.h)
+        __syncthreads();
+        uint4 *dst = reinterpret_cast<uint4 *>(w.rowpack + base * stride);
+        for (int c = tid; c < nrows * qpr; c += T) {
+            const uint32_t *src = s_tile + (c / qpr) * ldw + (c % qpr) * 4;
+            dst[c] = make_uint4(src[0], src[1], src[2], src[3]);
+        }
+        __syncthreads();
     }
 }
 
@@ -89,9 +115,13 @@ __global__ __launch_bounds__(256) void prep_kernel(const int32_t *__restrict__ c
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double s = 0, g0 = 0, g1 = 0;
         int64_t tot = 0;
+        double *rp_nf = reinterpret_cast<double *>(w.rowpack + i * row_stride(S));
+        int32_t *rp_y = reinterpret_cast<int32_t *>(rp_nf + S);
         for (int j = 0; j < S; j++) {
             const int32_t k = counts[(int64_t)j * n + i];
             if (k < 0) w.sc->neg_counts = 1;
+            rp_nf[j] = nf[(int64_t)j * n + i];
+            rp_y[j] = k;
             const double q = (double)k / nf[(int64_t)j * n + i];
             tot += k;
             s += q;
@@ -150,7 +180,10 @@ __global__ void xim_kernel(FitDims d, FitWork w) {
 
 constexpr int kColsumBlocks = 512;  // per column; (S+1) x 512 partials fit the 1024 x 72 partials buffer for S <= 64
 void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts, hipStream_t st) {
-    if (d.S <= 16) prep16_kernel<<<768, 256, 0, st>>>(counts, nf, d, w);  // one resident round: 149 VGPRs = 3 workgroups per CU
+    if (d.S <= 16) {  // one resident round: 149 VGPRs = 3 workgroups of 256 per CU; the LDS tile stays under 34 KB
+        const int T = row_stride(d.S) > 128 ? 128 : 256;
+        prep16_kernel<<<768 * (256 / T), T, (size_t)T * (row_stride(d.S) + 4), st>>>(counts, nf, d, w);
+    }
     else prep_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
     colsum_kernel<<<dim3(kColsumBlocks, d.S + 1), 256, 0, st>>>(nf, d, w);
 }
@@ -613,10 +646,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     }
                 } else {
                     row = r;
-                    for (int j = 0; j < S; j++) {
-                        s_nf[j * 64 + lane] = A.nf[(int64_t)j * n + r];
-                        s_y[j * 64 + lane] = A.counts[(int64_t)j * n + r];
-                    }
+                    load_row(A.w.rowpack, r, S, s_nf, s_y, lane);
                     gm0 = A.w.gm0[r];
                     gm1 = A.w.gm1[r];
                     if (!MAP) {  // start values come from disp_init_kernel
@@ -856,7 +886,10 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o);
     else disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o);
     const bool sched = !map && o.schedule;
-    if (sched) launch_order_build(d, w, kSchedClassesA, st);  // the gene-wise launch visits the rows likely-long first
+    // the gene-wise launch visits the rows likely-long first; schedule 2 (a fit that shares the GPU with other fits: the theta
+    // grid's lanes) keeps the class order but deals nothing out statically — its waves are not all resident at once, and a wave
+    // that starts late must not be the owner of likely-long rows
+    if (sched) launch_order_build(d, w, o.schedule == 2 ? 0 : kSchedClassesA, st);
     DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, o.deal};
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks
@@ -866,7 +899,16 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     // persistent grid: enough waves to fill 256 CUs; rows are pulled from the queue
     int64_t waves_needed = (d.n + 63) / 64;
     int64_t blocks = (waves_needed + threads / 64 - 1) / (threads / 64);
-    const int64_t max_blocks = 256 * (int64_t)(160 * 1024 / (lds > 0 ? lds : 1) < 8 ? 160 * 1024 / lds : 8);
+    // never more waves than are resident at once — by LDS, and by registers (the kernel is built for `min_waves` per SIMD): a
+    // wave that starts only when another has left finds the queue empty at best, and at worst owns dealt-out rows that then
+    // start late (S = 4: LDS would allow 10 waves per CU, the registers allow 8; 200 k x 4 went from 0.57 to 0.72 ms)
+    const int waves_per_block = threads / 64;
+    int64_t blocks_per_cu = (int64_t)(160 * 1024 / (lds > 0 ? lds : 1));
+    const int64_t by_regs = (int64_t)(4 * (o.min_waves >= 2 && o.min_waves <= 4 ? o.min_waves : 2)) / waves_per_block;
+    if (blocks_per_cu > by_regs) blocks_per_cu = by_regs;
+    if (blocks_per_cu > 8) blocks_per_cu = 8;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    const int64_t max_blocks = 256 * blocks_per_cu;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
 #ifdef CHICDIFF_DIAG

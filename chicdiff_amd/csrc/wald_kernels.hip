@@ -199,10 +199,9 @@ __global__ __launch_bounds__(256, 4) void wald_irls_kernel(WaldArgs A) {
                 } else {
                     row = r;
                     int iyA = 0, iyB = 0;
+                    load_row(A.w.rowpack, r, S, s_nf, s_y, lane);
                     for (int j = 0; j < S; j++) {
-                        const int yi = A.counts[(int64_t)j * n + r];
-                        s_nf[j * 64 + lane] = A.nf[(int64_t)j * n + r];
-                        s_y[j * 64 + lane] = yi;
+                        const int yi = s_y[j * 64 + lane];
                         if ((gmask >> j) & 1) iyB += yi; else iyA += yi;
                     }
                     syA = (double)iyA;

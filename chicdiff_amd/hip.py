@@ -428,11 +428,13 @@ class HipContext:
         self._check(self.lib.chicdiff_hip_region_universe_count_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), n, int(RUexpand),
                                                                     d_chr_of.data_ptr(), maxfrag, ptr.data_ptr(), mn.data_ptr(),
                                                                     mx.data_ptr(), C.byref(total)))
+        self.last_region_universe_ms = self.kernel_times().get("region_universe", (0.0, 0))[0]  # (count + scan; the fill is added below)
         rb, rr, ro = (torch.empty(max(total.value, 1), dtype=torch.int32, device=self.device)[: total.value] for _ in range(3))
         if total.value:
             self._check(self.lib.chicdiff_hip_region_universe_fill_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), n, int(RUexpand),
                                                                        d_chr_of.data_ptr(), maxfrag, ptr.data_ptr(), rb.data_ptr(),
                                                                        rr.data_ptr(), ro.data_ptr()))
+            self.last_region_universe_ms += self.kernel_times().get("region_universe", (0.0, 0))[0]
         return dict(region_ptr=ptr, minOE=mn, maxOE=mx, baitID=rb, regionID=rr, otherEndID=ro)
 
     # -- a6 + a7 ----------------------------------------------------------------------------

@@ -10,6 +10,9 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 d = synth.make(n, S)
 print('n', n, 'S', S)
 ctx = hip.HipContext(0)
+for kv in sys.argv[3:]:  # option=value pairs of chicdiff_hip_set_option
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
 dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64)
 ctx.nbglm_fit(dk, dn, d["group"])
 raw = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64)
