@@ -24,9 +24,9 @@ struct FitWork {
     int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter, *optimConv;
     int32_t *order;               // schedule of the gene-wise line search: row indices, likely-long rows first (disp_kernels.hip)
     uint8_t *cls;                 // ... and the class each row was put in (255 = all-zero row: not scheduled)
-    char *rowpack;                // row-major copy of the fit's inputs, row i at rowpack + i * row_stride(S): nf[S] doubles, then counts[S]
-                                  // int32 (written by prep): the row-queue kernels visit rows out of order, and a row that is 12 S
-                                  // contiguous bytes costs one or two cache lines instead of 2 S
+    char *rowpack;                // row-major copy of the fit's inputs, row i at rowpack + i * row_stride(S): a 32-byte header (kRowHdr), nf[S]
+                                  // doubles, counts[S] int32 (written by prep): the row-queue kernels visit rows out of order, and a row that
+                                  // is 32 + 12 S contiguous bytes costs one or two cache lines instead of 2 S + 4
     double *partials;             // kRedBlocks x 72 doubles
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
     double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut
@@ -38,7 +38,14 @@ struct FitWork {
 };
 constexpr int kLogFactN = 1024;
 // bytes between rows of FitWork::rowpack: 12 S rounded up so that a row never straddles more 128-byte lines than it must
-__host__ __device__ inline int64_t row_stride(int S) { return S * 12 <= 64 ? 64 : ((int64_t)S * 12 + 127) / 128 * 128; }
+constexpr int kRowHdr = 32;  // four doubles in front of every row: what the kernel that visits the rows next needs besides the data —
+                             // gene-wise search: group mean A, group mean B, alpha_init, log alpha_init; MAP search: the means, start
+                             // value, prior mean; IRLS: alpha, row constant of the deviance, the two start values
+__host__ __device__ inline int64_t row_stride(int S) {
+    const int64_t bytes = kRowHdr + (int64_t)S * 12;
+    return bytes <= 64 ? 64 : (bytes + 127) / 128 * 128;
+}
+__device__ __forceinline__ double *row_hdr(char *rowpack, int64_t r, int S) { return reinterpret_cast<double *>(rowpack + r * row_stride(S)); }
 
 struct Opts {
     double minDisp, dispTol, kappa0, betaTol, minmu, outlierSD, dispPriorVarIn, maxDisp, trendIn[2];
@@ -52,8 +59,13 @@ struct Opts {
 };
 
 // one row of FitWork::rowpack -> the wave's LDS slice ([sample][lane]); 16-byte loads when S is a multiple of four
-__device__ __forceinline__ void load_row(const char *rowpack, int64_t r, int S, double *s_nf, int *s_y, int lane) {
+__device__ __forceinline__ void load_row(const char *rowpack, int64_t r, int S, double *s_nf, int *s_y, int lane, double (&hdr)[4]) {
     const char *row = rowpack + r * row_stride(S);
+    {
+        const double2 h0 = reinterpret_cast<const double2 *>(row)[0], h1 = reinterpret_cast<const double2 *>(row)[1];
+        hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
+    }
+    row += kRowHdr;
     if ((S & 3) == 0) {
         const double2 *pf = reinterpret_cast<const double2 *>(row);
         const int4 *py = reinterpret_cast<const int4 *>(row + 8 * S);

@@ -64,16 +64,17 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
             int64_t tot = 0;
             int32_t sign = 0;
             uint32_t *row = s_tile + tid * ldw;
-            for (int k = 3 * S; k < (int)(stride / 4); k++) row[k] = 0;  // the pad behind the row
+            for (int k = 0; k < 8; k++) row[k] = 0;                           // the header (filled in by the kernels' init passes)
+            for (int k = 8 + 3 * S; k < (int)(stride / 4); k++) row[k] = 0;  // the pad behind the row
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 q[j] = 0;
                 if (j < S) {
                     const int32_t k = counts[(int64_t)j * n + i];
                     const double f = nf[(int64_t)j * n + i];
-                    row[2 * j] = (uint32_t)__double2loint(f);
-                    row[2 * j + 1] = (uint32_t)__double2hiint(f);
-                    row[2 * S + j] = (uint32_t)k;
+                    row[8 + 2 * j] = (uint32_t)__double2loint(f);
+                    row[8 + 2 * j + 1] = (uint32_t)__double2hiint(f);
+                    row[8 + 2 * S + j] = (uint32_t)k;
                     sign |= k;
                     q[j] = (double)k / f;
                     tot += k;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const int32_t *__restrict__ c
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double s = 0, g0 = 0, g1 = 0;
         int64_t tot = 0;
-        double *rp_nf = reinterpret_cast<double *>(w.rowpack + i * row_stride(S));
+        double *rp_nf = reinterpret_cast<double *>(w.rowpack + i * row_stride(S) + kRowHdr);
         int32_t *rp_y = reinterpret_cast<int32_t *>(rp_nf + S);
         for (int j = 0; j < S; j++) {
             const int32_t k = counts[(int64_t)j * n + i];
@@ -311,15 +312,16 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
         if (!MAP) {
             const double moments = (w.baseVar[i] - xim * bm) / (bm * bm);
             const double a0 = fmin(fmax(o.minDisp, fmin(w.rough[i], moments)), o.maxDisp);
-            w.rough[i] = a0;
-            w.resid[i] = log(a0);
-            w.cls[i] = (uint8_t)sched_class(a0, d.p == 2 ? fmin(w.gm0[i], w.gm1[i]) : w.gm0[i], o.minDisp);
+            const double g0 = w.gm0[i], g1 = w.gm1[i];
+            double2 *h = reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, d.S));  // what the search reads with the row
+            h[0] = make_double2(g0, g1);
+            h[1] = make_double2(a0, log(a0));
+            w.cls[i] = (uint8_t)sched_class(a0, d.p == 2 ? fmin(g0, g1) : g0, o.minDisp);
         } else {
             const double dg = w.dispGene[i], df = sc->trend_local ? w.dispFit[i] : c0 + c1 / bm;
             const double ldf = log(df);
             w.dispFit[i] = df;
-            w.resid[i] = ldf;
-            w.rough[i] = dg > 0.1 * df ? log(dg) : ldf;
+            reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, d.S))[1] = make_double2(dg > 0.1 * df ? log(dg) : ldf, ldf);  // start value, prior mean
             w.outlier[i] = log(dg) > ldf + out_thr;
         }
     }
@@ -338,6 +340,7 @@ struct DispArgs {
     int spread;                  // 0 = row-per-lane evaluation only (option "line_search_spread", for the bit-identity test)
     const int32_t *order;        // gene-wise launch: the schedule (order_*); NULL = rows 0..n-1 through the queue (MAP, option "line_search_schedule" 0)
     int deal;                    // entries per group of the static deal (0 = by the number of entries per wave)
+    int prefetch;                // 1 = warm the cache lines of the rows handed out next
 };
 #ifdef CHICDIFF_DIAG
 #define DIAG(...) __VA_ARGS__
@@ -581,6 +584,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     const unsigned long long mywave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave;
     unsigned long long a_k = 0;
     bool a_done = nA == 0;
+    unsigned int pf_val = 0, pf_acc = 0;
     // entries per group of the deal: eight while every wave gets several groups (neighbouring rows, neighbouring lanes), down to
     // one when rows are few, so that the likely-long rows spread evenly over the waves
     unsigned long long deal = A.deal > 0 ? (unsigned long long)A.deal : nA / (4ull * nwaves);
@@ -646,16 +650,17 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     }
                 } else {
                     row = r;
-                    load_row(A.w.rowpack, r, S, s_nf, s_y, lane);
-                    gm0 = A.w.gm0[r];
-                    gm1 = A.w.gm1[r];
+                    double hdr[4];
+                    load_row(A.w.rowpack, r, S, s_nf, s_y, lane, hdr);
+                    gm0 = hdr[0];
+                    gm1 = hdr[1];
                     if (!MAP) {  // start values come from disp_init_kernel
-                        a0 = A.w.rough[r];
-                        a = A.w.resid[r];
+                        a0 = hdr[2];
+                        a = hdr[3];
                     } else {
+                        a = hdr[2];
+                        prior_mean = hdr[3];
                         dgene = A.w.dispGene[r];
-                        prior_mean = A.w.resid[r];
-                        a = A.w.rough[r];
                         is_outlier = A.w.outlier[r];
                     }
                     phase = PH_INIT;
@@ -663,6 +668,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
         }
         if (__ballot(phase != PH_DONE) == 0ull) break;
+        // warm the lines of the rows this wave hands out next (its private chunk continues at chunk_next): the load is consumed one
+        // tick later (pf_acc), long after it has landed, so the next refill finds its rows in the cache instead of in HBM
+        pf_acc ^= pf_val;
+        pf_val = 0;
+        if (A.prefetch && chunk_next + lane < chunk_end) {
+            const int64_t rn = order ? (int64_t)order[chunk_next + lane] : (int64_t)(chunk_next + lane);
+            pf_val = *reinterpret_cast<const unsigned int *>(A.w.rowpack + rn * row_stride(S));
+        }
         DIAG(if (A.stamps && queue_empty && !stamped) {
             stamped = true;
             const int live = __popcll(__ballot(phase != PH_DONE && phase != PH_NEED));
@@ -858,6 +871,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             phase = PH_NEED;
         }
     }
+    if (A.prefetch == 0x7fffffff) A.w.queue[8 + (pf_acc & 7)] = pf_acc;  // (never: keeps the warming loads alive)
     DIAG(if (A.stamps && lane == 0) {
         A.stamps[gwave * kStampSlots + 2] = __builtin_amdgcn_s_memrealtime();
         A.stamps[gwave * kStampSlots + 4] = tk_row;
@@ -890,7 +904,7 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     // grid's lanes) keeps the class order but deals nothing out statically — its waves are not all resident at once, and a wave
     // that starts late must not be the owner of likely-long rows
     if (sched) launch_order_build(d, w, o.schedule == 2 ? 0 : kSchedClassesA, st);
-    DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, o.deal};
+    DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, o.deal, 1};
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks
     int threads = 128;

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
         w.binit0[i] = lA;
         w.binit1[i] = lB - lA;
         w.crow[i] = c;
-        w.rough[i] = cst;  // (the line-search start values are no longer needed)
+        double2 *h = reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, S));  // what the IRLS reads with the row
+        h[0] = make_double2(alpha, c + cst);
+        h[1] = make_double2(lA, lB - lA);
     }
 }
 
@@ -141,7 +143,12 @@ struct WaldArgs {
 
 // IRLS.  Tick k evaluates at beta_k: deviance(beta_k) for the convergence test and the
 // weighted sums that give beta_{k+1}.  DESeq2's loop index t equals k-1.
-__global__ __launch_bounds__(256, 4) void wald_irls_kernel(WaldArgs A) {
+// Three waves per SIMD: at four (128 VGPRs) the kernel spills 44 VGPRs to scratch and, once the row header is read with the row, is
+// slower (0.50 ms at 2 M x 8 against 0.43 at three and 0.44 at two; 250 k x 8: 0.25 / 0.25 / 0.23).
+#ifndef WALD_MINW
+#define WALD_MINW 3
+#endif
+__global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
     extern __shared__ double smem[];
     __shared__ LogEntry s_logtab[64];
     log_table_to_lds(s_logtab);
@@ -199,18 +206,19 @@ __global__ __launch_bounds__(256, 4) void wald_irls_kernel(WaldArgs A) {
                 } else {
                     row = r;
                     int iyA = 0, iyB = 0;
-                    load_row(A.w.rowpack, r, S, s_nf, s_y, lane);
+                    double hdr[4];
+                    load_row(A.w.rowpack, r, S, s_nf, s_y, lane, hdr);
                     for (int j = 0; j < S; j++) {
                         const int yi = s_y[j * 64 + lane];
                         if ((gmask >> j) & 1) iyB += yi; else iyA += yi;
                     }
                     syA = (double)iyA;
                     syB = (double)iyB;
-                    alpha = A.w.disp[r];
+                    alpha = hdr[0];
                     size = 1.0 / alpha;
-                    crow = A.w.crow[r] + A.w.rough[r];  // + sum_j y_j (log alpha + log nf_j), from wald_prep
-                    b0 = A.w.binit0[r];
-                    b1 = A.w.binit1[r];
+                    crow = hdr[1];  // row constant + sum_j y_j (log alpha + log nf_j), from wald_prep
+                    b0 = hdr[2];
+                    b1 = hdr[3];
                     k = 0;
                     dev_old = 0;
                     need = false;
