@@ -292,12 +292,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_hbm_kernels:
         # what an R caller sees: chicdiff_hip_nbglm_fit on HOST buffers (INTEGER(counts), REAL(nf) in, six columns out) — staging
         # through pinned slices + PCIe both ways included.  Reported beside `value`, never as `value`.
-        nf_host = ctx.offsets(dfm, sc["sizeFactors"], args.theta).T.cpu().numpy()
-        ctx.nbglm_fit_host(d["counts"], nf_host, group, want=want)
+        nf_host = np.asfortranarray(ctx.offsets(dfm, sc["sizeFactors"], args.theta).T.cpu().numpy())   # column-major, as R holds them
+        k_host = np.asfortranarray(d["counts"].astype(np.int32))
+        ctx.nbglm_fit_host(k_host, nf_host, group, want=want)
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
-            ctx.nbglm_fit_host(d["counts"], nf_host, group, want=want)
+            ctx.nbglm_fit_host(k_host, nf_host, group, want=want)
             ts.append((time.perf_counter() - t0) * 1e3)
         hm = float(np.median(ts))
         result["host_buffer_entry"] = {"ms": round(hm, 3), "interactions_per_s": round(n / hm * 1e3, 1),

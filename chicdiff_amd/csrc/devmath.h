@@ -75,8 +75,9 @@ __device__ __forceinline__ void log_table_to_lds(LogEntry *s_tab) {
 __device__ __forceinline__ double tlog(double x, const LogEntry *tab) {
     const unsigned long long ix = (unsigned long long)__double_as_longlong(x);
     const unsigned long long tmp = ix - 0x3FE6000000000000ull;
-    const int i = (int)(tmp >> 46) & 63;
-    const int k = (int)((long long)tmp >> 52);
+    const int hi = (int)(unsigned int)(tmp >> 32);  // the exponent lives in the high word: keep k a 32-bit quantity (as a 64-bit
+    const int i = (hi >> 14) & 63;                  // shift the compiler converts it to double as an int64: two cvt, ldexp, add)
+    const int k = hi >> 20;
     const double z = __longlong_as_double((long long)(ix - (tmp & 0xFFF0000000000000ull)));
     const LogEntry e = tab[i];
     const double r = fma(z, e.invc, -1.0);
@@ -108,19 +109,21 @@ __device__ __forceinline__ double flog1p_from(double u, double t, double rt) {
 //   digamma(z) = log z - 1/(2z) - dg_tail(1/z^2)
 __device__ __forceinline__ void stirling(double z, double lz, double zi, double &lg, double &dg) {
     const double z2 = zi * zi;
+    // the two Horner chains are written interleaved: each step depends on the one two lines up, so a wave always has an
+    // independent fp64 instruction to issue (as two separate chains the compiler emitted them back to back, with wait states)
     double s = fma3(z2, 1.0 / 156.0, -691.0 / 360360.0);
-    s = fma3(z2, s, 1.0 / 1188.0);
-    s = fma3(z2, s, -1.0 / 1680.0);
-    s = fma3(z2, s, 1.0 / 1260.0);
-    s = fma3(z2, s, -1.0 / 360.0);
-    s = fma3(z2, s, 1.0 / 12.0);
-    lg = fma(z - 0.5, lz, -z) + 0.91893853320467274178 + s * zi;
     double t = fma3(z2, 1.0 / 12.0, -691.0 / 32760.0);
+    s = fma3(z2, s, 1.0 / 1188.0);
     t = fma3(z2, t, 1.0 / 132.0);
+    s = fma3(z2, s, -1.0 / 1680.0);
     t = fma3(z2, t, -1.0 / 240.0);
+    s = fma3(z2, s, 1.0 / 1260.0);
     t = fma3(z2, t, 1.0 / 252.0);
+    s = fma3(z2, s, -1.0 / 360.0);
     t = fma3(z2, t, -1.0 / 120.0);
+    s = fma3(z2, s, 1.0 / 12.0);
     t = fma3(z2, t, 1.0 / 12.0);
+    lg = fma(z - 0.5, lz, -z) + 0.91893853320467274178 + s * zi;
     dg = fma(-0.5, zi, lz) - t * z2;
 }
 
