@@ -31,6 +31,24 @@ namespace cd {
 // prep: per-row moments of the normalised counts (getBaseMeansAndVariances, roughDispEstimate,
 // linearModelMu group means).  One thread per row, sample-major loads are coalesced.
 // per-row statistics from the normalised counts q_j = k_j / nf_j (shared by both variants)
+// double-double accumulation (error-free TwoSum): the column sums of nf decide xim, xim enters every row's start value, and a
+// start value one ulp away moves a noise-decided row elsewhere (and through the trend every row's 8th digit).  Summed this way the
+// result is the correctly rounded exact sum whatever the order, so a permuted matrix gives the permuted results bit for bit
+// (test_full_size_2Mx8_...: trend to 1e-12) although the sums now ride on prep's tiles instead of a pass of their own.
+struct DD { double hi, lo; };
+__device__ __forceinline__ void dd_add(DD &a, double x) {
+    const double s = a.hi + x, bb = s - a.hi;
+    a.lo += (a.hi - (s - bb)) + (x - bb);
+    a.hi = s;
+}
+__device__ __forceinline__ void dd_add(DD &a, const DD &b) {
+    dd_add(a, b.hi);
+    a.lo += b.lo;
+    const double s = a.hi + a.lo;  // renormalise
+    a.lo = a.lo - (s - a.hi);
+    a.hi = s;
+}
+
 __device__ __forceinline__ void prep_store(FitDims d, FitWork w, int64_t i, double s, double g0, double g1, double v,
                                            double est, int64_t tot) {
     w.baseMean[i] = s / d.S;
@@ -49,12 +67,18 @@ __device__ __forceinline__ void prep_store(FitDims d, FitWork w, int64_t i, doub
 __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__ counts,
                                                      const double *__restrict__ nf, FitDims d, FitWork w) {
     extern __shared__ uint32_t s_tile[];  // T rows x (stride / 4 + 1) dwords, T = blockDim.x (256, or 128 when a row is longer than 128 bytes)
+    __shared__ DD s_part[256];            // column sums of the tile by row group: [group][column]
+    __shared__ unsigned char s_live[256]; // row of the tile is not all zero
     const int T = blockDim.x;
     const int64_t n = d.n;
     const int S = d.S;
     const int64_t stride = row_stride(S);
     const int ldw = (int)(stride / 4) + 1, qpr = (int)(stride / 16);  // tile pitch in dwords; 16-byte chunks per row
     const int tid = threadIdx.x;
+    // column sums of nf over the non-all-zero rows + their number (momentsDispEstimate's xim): the tile holds the values anyway.
+    // Thread (group g, column c) adds the rows g, g + G, ... of column c; thread c then adds the G group sums in order: fixed order
+    const int ncol = S + 1, G = T / ncol, cg = tid / ncol, cc = tid % ncol;
+    DD colacc{0.0, 0.0};  // threads 0..S: this block's sum of column tid (column S counts the rows)
     for (int64_t base = (int64_t)blockIdx.x * T; base < n; base += (int64_t)gridDim.x * T) {
         const int64_t i = base + tid;
         const int nrows = n - base < T ? (int)(n - base) : T;
@@ -64,7 +88,7 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
             int64_t tot = 0;
             int32_t sign = 0;
             uint32_t *row = s_tile + tid * ldw;
-            for (int k = 0; k < 8; k++) row[k] = 0;                           // the header (filled in by the kernels' init passes)
+            for (int k = 4; k < 8; k++) row[k] = 0;                           // second half of the header (start values: the kernels' init passes)
             for (int k = 8 + 3 * S; k < (int)(stride / 4); k++) row[k] = 0;  // the pad behind the row
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -85,6 +109,11 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
             const double bm = s / S;
             g0 /= d.nA;
             if (d.p == 2) g1 /= d.nB;
+            row[0] = (uint32_t)__double2loint(g0);  // first half of the header: the group means
+            row[1] = (uint32_t)__double2hiint(g0);
+            row[2] = (uint32_t)__double2loint(g1);
+            row[3] = (uint32_t)__double2hiint(g1);
+            s_live[tid] = tot != 0;
             const double m0 = fmax(1.0, g0), m1 = fmax(1.0, g1);
             const double i0 = 1.0 / (m0 * m0), i1 = 1.0 / (m1 * m1);  // two divisions per row instead of one per sample
             double v = 0, est = 0;
@@ -105,7 +134,23 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
             const uint32_t *src = s_tile + (c / qpr) * ldw + (c % qpr) * 4;
             dst[c] = make_uint4(src[0], src[1], src[2], src[3]);
         }
+        if (cg < G) {
+            DD a{0.0, 0.0};
+            for (int r = cg; r < nrows; r += G)
+                if (s_live[r]) {
+                    const uint32_t *src = s_tile + r * ldw + 8 + 2 * cc;
+                    dd_add(a, cc < S ? __hiloint2double((int)src[1], (int)src[0]) : 1.0);
+                }
+            s_part[cg * ncol + cc] = a;
+        }
         __syncthreads();
+        if (tid < ncol)
+            for (int g = 0; g < G; g++) dd_add(colacc, s_part[g * ncol + tid]);
+        __syncthreads();
+    }
+    if (tid < ncol) {
+        w.partials[((int64_t)tid * gridDim.x + blockIdx.x) * 2] = colacc.hi;
+        w.partials[((int64_t)tid * gridDim.x + blockIdx.x) * 2 + 1] = colacc.lo;
     }
 }
 
@@ -131,6 +176,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const int32_t *__restrict__ c
         const double bm = s / S;
         g0 /= d.nA;
         if (d.p == 2) g1 /= d.nB;
+        reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, S))[0] = make_double2(g0, g1);  // first half of the row's header
         const double m0 = fmax(1.0, g0), m1 = fmax(1.0, g1);
         double v = 0, est = 0;
         for (int j = 0; j < S; j++) {
@@ -161,12 +207,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const double *__restrict__ 
     if (threadIdx.x == 0) w.partials[(int64_t)j * gridDim.x + blockIdx.x] = red[0];
 }
 
-// one wave per column: strided fixed-order sum of the block partials, then a shuffle tree
-__global__ void colsum_finish_kernel(FitDims d, FitWork w, int nblk) {
+// one wave per column: strided fixed-order sum of the block partials, then a shuffle tree; dd: the partials are double-double pairs
+__global__ void colsum_finish_kernel(FitDims d, FitWork w, int nblk, int dd) {
     const int j = blockIdx.x, lane = threadIdx.x;
     double s = 0;
-    for (int b = lane; b < nblk; b += 64) s += w.partials[(int64_t)j * nblk + b];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (dd) {
+        DD a{0.0, 0.0};
+        for (int b = lane; b < nblk; b += 64) dd_add(a, DD{w.partials[((int64_t)j * nblk + b) * 2], w.partials[((int64_t)j * nblk + b) * 2 + 1]});
+        for (int off = 32; off > 0; off >>= 1) dd_add(a, DD{__shfl_down(a.hi, off), __shfl_down(a.lo, off)});
+        s = a.hi + a.lo;
+    } else {
+        for (int b = lane; b < nblk; b += 64) s += w.partials[(int64_t)j * nblk + b];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    }
     if (lane == 0) {
         if (j < d.S) w.sc->colsum[j] = s; else w.sc->nnz = s;
     }
@@ -180,15 +233,19 @@ __global__ void xim_kernel(FitDims d, FitWork w) {
 }
 
 constexpr int kColsumBlocks = 512;  // per column; (S+1) x 512 partials fit the 1024 x 72 partials buffer for S <= 64
+static int prep16_blocks(int S) { return row_stride(S) > 128 ? 1536 : 768; }  // (S + 1) x 1536 partials fit as well
 void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts, hipStream_t st) {
-    if (d.S <= 16) {  // one resident round: 149 VGPRs = 3 workgroups of 256 per CU; the LDS tile stays under 34 KB
+    if (d.S <= 16) {  // one resident round: 3 workgroups of 256 per CU; the LDS tile stays under 34 KB; the column sums ride along
         const int T = row_stride(d.S) > 128 ? 128 : 256;
-        prep16_kernel<<<768 * (256 / T), T, (size_t)T * (row_stride(d.S) + 4), st>>>(counts, nf, d, w);
+        prep16_kernel<<<prep16_blocks(d.S), T, (size_t)T * (row_stride(d.S) + 4), st>>>(counts, nf, d, w);
+    } else {
+        prep_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
+        colsum_kernel<<<dim3(kColsumBlocks, d.S + 1), 256, 0, st>>>(nf, d, w);
     }
-    else prep_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
-    colsum_kernel<<<dim3(kColsumBlocks, d.S + 1), 256, 0, st>>>(nf, d, w);
 }
-void launch_prep_finish(FitDims d, FitWork w, hipStream_t st) { colsum_finish_kernel<<<d.S + 1, 64, 0, st>>>(d, w, kColsumBlocks); }
+void launch_prep_finish(FitDims d, FitWork w, hipStream_t st) {
+    colsum_finish_kernel<<<d.S + 1, 64, 0, st>>>(d, w, d.S <= 16 ? prep16_blocks(d.S) : kColsumBlocks, d.S <= 16);
+}
 void launch_xim(FitDims d, FitWork w, hipStream_t st) { xim_kernel<<<1, 64, 0, st>>>(d, w); }
 
 // ------------------------------------------------------------------------------------------
@@ -313,9 +370,7 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
             const double moments = (w.baseVar[i] - xim * bm) / (bm * bm);
             const double a0 = fmin(fmax(o.minDisp, fmin(w.rough[i], moments)), o.maxDisp);
             const double g0 = w.gm0[i], g1 = w.gm1[i];
-            double2 *h = reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, d.S));  // what the search reads with the row
-            h[0] = make_double2(g0, g1);
-            h[1] = make_double2(a0, log(a0));
+            reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, d.S))[1] = make_double2(a0, log(a0));  // what the search reads with the row (the means are there since prep)
             w.cls[i] = (uint8_t)sched_class(a0, d.p == 2 ? fmin(g0, g1) : g0, o.minDisp);
         } else {
             const double dg = w.dispGene[i], df = sc->trend_local ? w.dispFit[i] : c0 + c1 / bm;
