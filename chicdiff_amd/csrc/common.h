@@ -90,7 +90,7 @@ void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, 
 void launch_prep_finish(FitDims d, FitWork w, hipStream_t st);          // partials -> colsum,nnz
 void launch_xim(FitDims d, FitWork w, hipStream_t st);                  // colsum -> xim
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
-void launch_order_build(FitDims d, FitWork w, int classesA, hipStream_t st);  // w.cls -> w.order (schedule of a row-queue kernel)
+void launch_order_build(FitDims d, FitWork w, int classesA, bool have_hist, hipStream_t st);  // w.cls -> w.order (schedule of a row-queue kernel)
 void launch_disp_map(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st);  // single rank: whole trend fit, one launch
 int trend_persistent_blocks();  // workgroups that must be co-resident (grid barrier): needs that many CUs

@@ -280,18 +280,11 @@ __device__ __forceinline__ int sched_class(double a0, double gmin, double minDis
     const double s = a0 * gmin;
     return s < 0.1 ? 0 : (s < 0.316 ? 1 : (s < 1.0 ? 2 : (s < 3.16 ? 3 : (s < 10.0 ? 4 : 5))));
 }
-// per-block class counts over contiguous tiles of rows: hist[class][block]
-__global__ __launch_bounds__(256) void order_hist_kernel(const uint8_t *__restrict__ cls, int64_t n, int64_t tile, unsigned int *hist) {
+// per-thread class counts -> hist[class][block] (wave shuffles, then one LDS add per wave and class)
+__device__ __forceinline__ void order_hist_store(const unsigned int (&mine)[kSchedClasses], unsigned int *hist) {
     __shared__ unsigned int s_cnt[kSchedClasses];
     if (threadIdx.x < kSchedClasses) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
-    unsigned int mine[kSchedClasses] = {0, 0, 0, 0, 0, 0};
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const int c = cls[i];
-#pragma unroll
-        for (int k = 0; k < kSchedClasses; k++) mine[k] += (c == k);
-    }
 #pragma unroll
     for (int k = 0; k < kSchedClasses; k++) {
         unsigned int v = mine[k];
@@ -300,6 +293,17 @@ __global__ __launch_bounds__(256) void order_hist_kernel(const uint8_t *__restri
     }
     __syncthreads();
     if (threadIdx.x < kSchedClasses) hist[threadIdx.x * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
+}
+// per-block class counts over contiguous tiles of rows: hist[class][block]
+__global__ __launch_bounds__(256) void order_hist_kernel(const uint8_t *__restrict__ cls, int64_t n, int64_t tile, unsigned int *hist) {
+    const int64_t lo = (int64_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+    unsigned int mine[kSchedClasses] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int c = cls[i];
+#pragma unroll
+        for (int k = 0; k < kSchedClasses; k++) mine[k] += (c == k);
+    }
+    order_hist_store(mine, hist);
 }
 // class-major exclusive scan of hist (every block recomputes the offsets it needs: 6 x 1024 entries from L2), then a
 // stable scatter of the block's rows: order[] = class 0 rows in row order, class 1 rows, ...
@@ -351,12 +355,18 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t *__res
     }
 }
 
+// tile > 0 (gene-wise launch with the schedule on): block b owns rows [b tile, (b + 1) tile) and leaves its class counts in
+// hist (the first half of order_*); tile == 0: rows grid-strided
 template <bool MAP>
-__global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Opts o) {
+__global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Opts o, int64_t tile, unsigned int *hist) {
     const FitScalars *sc = w.sc;
     const double xim = sc->xim, c0 = sc->coefs[0], c1 = sc->coefs[1];
     const double out_thr = MAP ? o.outlierSD * sqrt(sc->varLogDispEsts) : 0.0;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+    unsigned int mine[kSchedClasses] = {0, 0, 0, 0, 0, 0};
+    const int64_t lo = tile > 0 ? (int64_t)blockIdx.x * tile : (int64_t)blockIdx.x * 256;
+    const int64_t hi = tile > 0 ? (lo + tile < d.n ? lo + tile : d.n) : d.n;
+    const int64_t step = tile > 0 ? 256 : (int64_t)gridDim.x * 256;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += step) {
         if (w.allZero[i]) {
             if (!MAP) {  // not scheduled at all (order_*): the line search never sees the row
                 w.cls[i] = 255;
@@ -371,7 +381,10 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
             const double a0 = fmin(fmax(o.minDisp, fmin(w.rough[i], moments)), o.maxDisp);
             const double g0 = w.gm0[i], g1 = w.gm1[i];
             reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, d.S))[1] = make_double2(a0, log(a0));  // what the search reads with the row (the means are there since prep)
-            w.cls[i] = (uint8_t)sched_class(a0, d.p == 2 ? fmin(g0, g1) : g0, o.minDisp);
+            const int c = sched_class(a0, d.p == 2 ? fmin(g0, g1) : g0, o.minDisp);
+            w.cls[i] = (uint8_t)c;
+#pragma unroll
+            for (int k = 0; k < kSchedClasses; k++) mine[k] += (c == k);
         } else {
             const double dg = w.dispGene[i], df = sc->trend_local ? w.dispFit[i] : c0 + c1 / bm;
             const double ldf = log(df);
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
             w.outlier[i] = log(dg) > ldf + out_thr;
         }
     }
+    if (!MAP && tile > 0) order_hist_store(mine, hist);
 }
 
 constexpr int kChunk = 64;   // rows a wave takes from the global queue per atomic
@@ -940,25 +954,35 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
 }
 
 // w.cls[] -> w.order[], sc->ord_na (entries of classes < classesA), sc->ord_n; w.hist is idle between the selects
-void launch_order_build(FitDims d, FitWork w, int classesA, hipStream_t st) {
-    int64_t nblk = (d.n + 255) / 256;
+void order_tiles(int64_t n, int64_t &nblk, int64_t &tile) {
+    nblk = (n + 255) / 256;
     if (nblk > kSchedBlocks) nblk = kSchedBlocks;
-    const int64_t tile = ((d.n + nblk - 1) / nblk + 255) / 256 * 256;
-    nblk = (d.n + tile - 1) / tile;
+    tile = ((n + nblk - 1) / nblk + 255) / 256 * 256;
+    nblk = (n + tile - 1) / tile;
+}
+// have_hist: the class counts per tile are in w.hist already (left there by the kernel that wrote w.cls)
+void launch_order_build(FitDims d, FitWork w, int classesA, bool have_hist, hipStream_t st) {
+    int64_t nblk, tile;
+    order_tiles(d.n, nblk, tile);
     unsigned int *hist = reinterpret_cast<unsigned int *>(w.hist);
-    order_hist_kernel<<<(unsigned)nblk, 256, 0, st>>>(w.cls, d.n, tile, hist);
+    if (!have_hist) order_hist_kernel<<<(unsigned)nblk, 256, 0, st>>>(w.cls, d.n, tile, hist);
     order_scatter_kernel<<<(unsigned)nblk, 256, 0, st>>>(w.cls, d.n, tile, hist, w.order, w.sc, classesA);
 }
 
 static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                         hipStream_t st) {
-    if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o);
-    else disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o);
     const bool sched = !map && o.schedule;
+    if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o, 0, nullptr);
+    else if (!sched) disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o, 0, nullptr);
+    else {
+        int64_t nblk, tile;
+        order_tiles(d.n, nblk, tile);
+        disp_init_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(d, w, o, tile, reinterpret_cast<unsigned int *>(w.hist));
+    }
     // the gene-wise launch visits the rows likely-long first; schedule 2 (a fit that shares the GPU with other fits: the theta
     // grid's lanes) keeps the class order but deals nothing out statically — its waves are not all resident at once, and a wave
     // that starts late must not be the owner of likely-long rows
-    if (sched) launch_order_build(d, w, o.schedule == 2 ? 0 : kSchedClassesA, st);
+    if (sched) launch_order_build(d, w, o.schedule == 2 ? 0 : kSchedClassesA, true, st);
     DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, o.deal, 1};
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks

@@ -548,7 +548,7 @@ __global__ void dev_sum_kernel(FitWork w) {
 
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
     wald_prep_kernel<<<1536, 256, 0, st>>>(counts, nf, d, w, o.schedule);  // one resident round: 80 VGPRs = 6 workgroups per CU
-    if (o.schedule) launch_order_build(d, w, 0, st);
+    if (o.schedule) launch_order_build(d, w, 0, false, st);
 }
 void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
     WaldArgs A{counts, nf, d, w, o, 64, o.schedule ? w.order : nullptr};
