@@ -46,6 +46,13 @@ struct chicdiff_hip_ctx {
     int opt_trend_gather = 1;  // sharded fits: gather the rows of the trend on every rank (two collectives) instead of one all-reduce per IRLS pass
     char *tg_buf = nullptr;    // ... the gathered rows (grow-only)
     size_t tg_bytes = 0;
+    double shard_n[kSelMaxWorld] = {0};  // rows of every rank's shard, exchanged with the argument verdicts at the start of a sharded call
+    bool shard_n_valid = false;
+    // set by gathered_trend for the rest of the fit: the whole fit's (baseMean, dispGeneEst) rows are on this rank
+    int64_t tg_total = 0;
+    double *tg_x = nullptr, *tg_y = nullptr, *tg_resid = nullptr;
+    int32_t *tg_flags = nullptr;
+    int32_t *h_flag = nullptr;  // pinned: sel_overflow of the size-factor select (read with the call's last synchronisation)
     int opt_no_local_substitute = 0;  // 1: a failed parametric trend is reported (CHICDIFF_ST_TREND_FAILED), not replaced by the local fit
     // host-buffer entry point: device arena + pinned staging, both grow-only (no allocation per call once warm)
     char *io_dev = nullptr, *io_pin = nullptr;
@@ -174,8 +181,8 @@ int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
     c->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_sc, sizeof(FitScalars))) != hipSuccess ||
-        (e = hipHostMalloc((void **)&c->h_sf, sizeof(double) * kMaxS)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_sf, sizeof(double) * (kMaxS + 1))) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->h_sf, sizeof(double) * (kMaxS + 1))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_sf, sizeof(double) * (kMaxS + 1 + kSelMaxWorld))) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_logfact, sizeof(double) * kLogFactN)) != hipSuccess) {
         fail(nullptr, CHICDIFF_E_HIP, "context setup: %s", hipGetErrorString(e));
         delete c;
@@ -484,8 +491,10 @@ struct HipBackend {
     Opts o;
     SelArgs sa;  // key source of the running select
     int err = 0;
-    int world() const { return c->allreduce ? (c->world > 1 ? c->world : 2) : 1; }  // callback set => sharded protocol
-    int allreduce(double *buf, int64_t n) { return do_allreduce(c, buf, n); }
+    bool local = false;  // a sharded fit whose rows are all on this rank for this step (MAD over the gathered trend rows): single-rank path
+    bool sharded() const { return c->allreduce && !local; }
+    int world() const { return sharded() ? (c->world > 1 ? c->world : 2) : 1; }  // callback set => sharded protocol
+    int allreduce(double *buf, int64_t n) { return sharded() ? do_allreduce(c, buf, n) : 0; }
     double *sums() { return c->w.partials; }  // sharded: the per-block partials themselves are all-reduced (one launch fewer per pass)
     int64_t sums_len() const { return (int64_t)trend_blocks() * kTrendSums; }
     double *hist() { return c->w.hist; }
@@ -515,7 +524,7 @@ struct HipBackend {
         launch_sel_step(sa, c->w, c->stream);
     }
     bool sel_shortcut(const SelSpec &) {
-        if (c->allreduce || c->opt_select_rounds) return false;  // sharded: candidates live on other ranks too
+        if (sharded() || c->opt_select_rounds) return false;  // sharded: candidates live on other ranks too
         Scope t(c, "select_shortcut");
         sa.shift = 40;
         launch_sel_shortcut(sa, c->w, c->stream);
@@ -538,11 +547,15 @@ struct HipBackend {
         launch_sel_gather_place(sa, c->w, c->world, c->rank, c->stream);
     }
     void sel_gather_finish(const SelSpec &) { launch_sel_gather_finish(sa, c->w, c->world, c->rank, c->stream); }
+    // no look at the device: a list that did not fit sets FitScalars::sel_overflow, which the host sees at the call's last
+    // synchronisation and answers with a refit over every histogram round (every rank takes the same decision)
+    bool sel_gather_done() { return true; }
 };
 
 // exact medians by radix select; results land in w.sc (see sel_finish_kernel)
-static int run_select(chicdiff_hip_ctx *c, SelArgs a) {
+static int run_select(chicdiff_hip_ctx *c, SelArgs a, bool local = false) {
     HipBackend be{c, FitDims{}, Opts{}, a};
+    be.local = local;
     SelSpec spec{a.mode, a.ncol};
     const int rc = drive_select(be, spec);
     if (rc) return c->err[0] ? CHICDIFF_E_COMM : fail(c, CHICDIFF_E_COMM, "select: all-reduce failed");
@@ -577,20 +590,31 @@ static int check_opts(chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *opts) {
 // Sharded fits: an argument error on ONE rank (e.g. an empty shard when n < world size) must not leave its peers blocked
 // in the first collective.  Every rank therefore contributes its local verdict to one sum-all-reduce before the fit
 // starts, and all return together.  (Single process: the local verdict.)
-static int shard_consensus(chicdiff_hip_ctx *c, int local_rc) {
+static int shard_consensus(chicdiff_hip_ctx *c, int local_rc, int64_t n = 0) {
+    c->shard_n_valid = false;
     if (!c->allreduce) return local_rc;
     char keep[sizeof c->err];
     memcpy(keep, c->err, sizeof keep);
-    double flag = local_rc ? 1.0 : 0.0;
-    double *d_flag = c->d_sf + kMaxS;  // one spare double behind the size factors
+    // one all-reduce carries the verdict and — zero everywhere but in the rank's own slot — the shards' row counts, which the
+    // gathered trend needs (round 2 exchanged them with a collective and two host synchronisations of their own)
+    const int world = c->world > 0 ? c->world : 1, slots = world <= kSelMaxWorld ? 1 + world : 1;
+    double buf[1 + kSelMaxWorld] = {0};
+    buf[0] = local_rc ? 1.0 : 0.0;
+    if (slots > 1 && c->rank >= 0 && c->rank < world) buf[1 + c->rank] = local_rc ? 0.0 : (double)n;
+    double *d_flag = c->d_sf + kMaxS;  // spare doubles behind the size factors
     hipError_t e = hipSetDevice(c->device);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_flag, &flag, sizeof flag, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_flag, buf, sizeof(double) * slots, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_HIP, "shard consensus: %s", hipGetErrorString(e));
-    if (do_allreduce(c, d_flag, 1)) return CHICDIFF_E_COMM;
-    e = hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, c->stream);
+    if (do_allreduce(c, d_flag, slots)) return CHICDIFF_E_COMM;
+    e = hipMemcpyAsync(buf, d_flag, sizeof(double) * slots, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_HIP, "shard consensus: %s", hipGetErrorString(e));
+    const double flag = buf[0];
+    if (slots > 1) {
+        for (int r = 0; r < world; r++) c->shard_n[r] = buf[1 + r];
+        c->shard_n_valid = flag == 0.0 && n > 0;
+    }
     if (local_rc) {
         memcpy(c->err, keep, sizeof keep);
         return local_rc;
@@ -738,29 +762,38 @@ static int gathered_trend(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
     FitWork &w = c->w;
     const int world = c->world > 0 ? c->world : 1, rank = c->rank;
     std::vector<double> cnt((size_t)world, 0.0);
-    cnt[(size_t)rank] = (double)d.n;
-    double *d_cnt = w.hist;
-    HIPCHK(c, hipMemcpyAsync(d_cnt, cnt.data(), sizeof(double) * world, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));  // cnt lives on this frame
-    int rc = do_allreduce(c, d_cnt, world);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(double) * world, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    int rc;
+    if (c->shard_n_valid && world <= kSelMaxWorld && (int64_t)c->shard_n[rank] == d.n) {
+        for (int r = 0; r < world; r++) cnt[(size_t)r] = c->shard_n[r];  // exchanged with the argument verdicts: no collective, no host stop
+    } else {
+        cnt[(size_t)rank] = (double)d.n;
+        double *d_cnt = w.hist;
+        HIPCHK(c, hipMemcpyAsync(d_cnt, cnt.data(), sizeof(double) * world, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));  // cnt lives on this frame
+        if ((rc = do_allreduce(c, d_cnt, world))) return rc;
+        HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(double) * world, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     int64_t off = 0, total = 0;
     for (int r = 0; r < world; r++) {
         if (r < rank) off += (int64_t)cnt[(size_t)r];
         total += (int64_t)cnt[(size_t)r];
     }
     const size_t nd = align256(sizeof(double) * (size_t)total), ni = align256(sizeof(int32_t) * (size_t)total);
-    if (c->tg_bytes < 2 * nd + ni) {
-        if (c->tg_buf) HIPCHK(c, hipFree(c->tg_buf));
+    if (c->tg_bytes < 3 * nd + ni) {
+        if (c->tg_buf) { HIPCHK(c, hipStreamSynchronize(st)); HIPCHK(c, hipFree(c->tg_buf)); }
         c->tg_buf = nullptr;
         c->tg_bytes = 0;
-        HIPCHK(c, hipMalloc((void **)&c->tg_buf, 2 * nd + ni));
-        c->tg_bytes = 2 * nd + ni;
+        HIPCHK(c, hipMalloc((void **)&c->tg_buf, 3 * nd + ni));
+        c->tg_bytes = 3 * nd + ni;
     }
     double *xg = (double *)c->tg_buf, *yg = (double *)(c->tg_buf + nd);
     int32_t *flags = (int32_t *)(c->tg_buf + 2 * nd);
+    c->tg_total = total;
+    c->tg_x = xg;
+    c->tg_y = yg;
+    c->tg_flags = flags;
+    c->tg_resid = (double *)(c->tg_buf + 2 * nd + ni);
     HIPCHK(c, hipMemsetAsync(c->tg_buf, 0, 2 * nd + ni, st));
     launch_trend_gather(d, w, o, xg + off, yg + off, st);
     if ((rc = do_allreduce(c, xg, (int64_t)(2 * nd / sizeof(double))))) return rc;  // x and y are contiguous (padding included)
@@ -779,6 +812,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     int rc;
     hipStream_t st = c->stream;
     FitWork &w = c->w;
+    c->tg_total = 0;
     // the scalars, the queue heads and the barrier counters sit next to each other in the workspace: one fill
     HIPCHK(c, hipMemsetAsync(w.sc, 0, align256(sizeof(FitScalars)) + 256 + 1024, st));
     {
@@ -852,24 +886,37 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     }
     int status = 0;
     const bool prior_by_simulation = !(o.dispPriorVarIn == o.dispPriorVarIn) && d.S - d.p <= 3 && d.S > d.p;
-    // MAD of the log residuals
-    launch_dispfit_resid(d, w, o, st);
+    // MAD of the log residuals.  A sharded fit that gathered the trend's rows has every rank's (baseMean, dispGeneEst) on this
+    // rank already: the residuals of ALL rows are formed here and the two medians (and the residual histogram of the d.f. <= 3
+    // prior) are taken locally, single-rank path — no collective at all instead of eight (nine) latency-bound ones, and the
+    // same bits as the one-rank fit
+    const bool mad_local = c->allreduce && c->tg_total > 0;
+    FitDims dm = d;
+    FitWork wm = w;
+    if (mad_local) {
+        dm.n = c->tg_total;
+        wm.baseMean = c->tg_x;
+        wm.dispGene = c->tg_y;
+        wm.allZero = c->tg_flags;
+        wm.resid = c->tg_resid;
+    }
+    launch_dispfit_resid(dm, wm, o, st);
     SelArgs sa{};
-    sa.n = d.n;
+    sa.n = dm.n;
     sa.ncol = 1;
-    sa.resid = w.resid;
+    sa.resid = wm.resid;
     {
         Scope t(c, "mad_select");
         sa.mode = SEL_RESID;
-        if ((rc = run_select(c, sa))) return rc;
+        if ((rc = run_select(c, sa, mad_local))) return rc;
         sa.mode = SEL_ABSDEV;
-        if ((rc = run_select(c, sa))) return rc;
+        if ((rc = run_select(c, sa, mad_local))) return rc;
         if (prior_by_simulation) {
             // residual d.f. <= 3: DESeq2 matches the prior variance by simulation (prior_mc.h).  The 200 x 40 simulated
             // densities are constants (built once per process and d.f.); the matching itself runs on the device
             double *d_hist = sums_of(w) + 32;
-            launch_resid_hist(d, w, d_hist, st);
-            if ((rc = do_allreduce(c, d_hist, kPmcBins))) return rc;
+            launch_resid_hist(dm, wm, d_hist, st);
+            if (!mad_local && (rc = do_allreduce(c, d_hist, kPmcBins))) return rc;
             const int df = d.S - d.p;
             if (!c->d_pmc[df]) {  // built once per process, uploaded once per context
                 HIPCHK(c, hipMalloc((void **)&c->d_pmc[df], sizeof(PmcTable)));
@@ -931,6 +978,12 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     if (hs[4] > 0)
         return fail(c, CHICDIFF_E_INVALID, c->h_sc->neg_counts ? "counts contain a negative value or NA_integer_"
                                                                : "counts contain a negative value or NA_integer_ (on another rank of the sharded fit)");
+    if (c->h_sc->sel_overflow && !c->opt_select_rounds) {  // a sharded select's candidate list did not fit (every rank sees the same flag)
+        c->opt_select_rounds = 1;
+        rc = fit_dev_impl(c, d_counts, d_nf, d, o, d_out, scalars);
+        c->opt_select_rounds = 0;
+        return rc;
+    }
     if (c->h_sc->failed == 3 || hs[3] > 0) {  // (hs[3]: some rank of a sharded fit — every rank takes this branch together)
         // the persistent trend kernel's workgroups were not all resident within the barrier's patience (a GPU shared
         // with other work): fit again with one launch per IRLS pass, and stay with that for this context
@@ -972,7 +1025,7 @@ int chicdiff_hip_nbglm_fit_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
     FitDims d;
     int rc = (!d_counts || !d_nf) ? fail(c, CHICDIFF_E_INVALID, "counts / nf pointer is NULL") : check_counts_group(c, n, S, group, d);
     if (!rc) rc = check_opts(c, opts);
-    if ((rc = shard_consensus(c, rc))) return rc;
+    if ((rc = shard_consensus(c, rc, n))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);
@@ -1143,13 +1196,22 @@ static int size_factors_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, int64
 int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S, double *sf_host) {
     if (!c) return CHICDIFF_E_INVALID;
     int rc = (!d_counts || !sf_host || n < 1 || S < 1 || S > kMaxS) ? fail(c, CHICDIFF_E_INVALID, "size_factors: bad arguments") : CHICDIFF_OK;
-    if ((rc = shard_consensus(c, rc))) return rc;
+    if ((rc = shard_consensus(c, rc, n))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);
     if ((rc = size_factors_impl(c, d_counts, n, S))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_sc, c->w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_sc->sel_overflow && !c->opt_select_rounds) {  // a candidate list of the sharded select did not fit: every histogram round instead
+        c->opt_select_rounds = 1;
+        HIPCHK(c, hipMemsetAsync(&c->w.sc->sel_overflow, 0, sizeof(int32_t), c->stream));
+        rc = size_factors_impl(c, d_counts, n, S);
+        c->opt_select_rounds = 0;
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_sc, c->w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     timing_collect(c);
     for (int j = 0; j < S; j++) {
         if (c->h_sc->sel_count[j] <= 0)
@@ -1168,18 +1230,27 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
     FitDims d;
     int rc = !d_counts ? fail(c, CHICDIFF_E_INVALID, "counts pointer is NULL") : check_counts_group(c, n, S, group, d);
     if (!rc) rc = check_opts(c, opts);
-    if ((rc = shard_consensus(c, rc))) return rc;
+    if ((rc = shard_consensus(c, rc, n))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
     timing_reset(c);
-    if ((rc = size_factors_impl(c, d_counts, n, S))) return rc;
-    const int mix = theta == theta;
-    {
-        Scope t(c, "offsets");
-        launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, c->d_nf_tmp, c->stream);
+    int32_t *h_overflow = reinterpret_cast<int32_t *>(c->h_sf + kMaxS);  // pinned
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = size_factors_impl(c, d_counts, n, S))) break;
+        const int mix = theta == theta;
+        {
+            Scope t(c, "offsets");
+            launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, c->d_nf_tmp, c->stream);
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_sf, c->d_sf, sizeof(double) * S, hipMemcpyDeviceToHost, c->stream));  // pinned: no stall
+        HIPCHK(c, hipMemcpyAsync(h_overflow, &c->w.sc->sel_overflow, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));  // (the fit clears the scalars next)
+        rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(c, opts, S), d_out, scalars);  // ends with a stream sync
+        // the sharded size-factor select ran without a host look at its candidate lists: one that did not fit (massive ties) shows
+        // now, on every rank alike, and the call is repeated with every histogram round
+        if (rc || !*h_overflow || c->opt_select_rounds) break;
+        c->opt_select_rounds = 1;
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_sf, c->d_sf, sizeof(double) * S, hipMemcpyDeviceToHost, c->stream));  // pinned: no stall
-    rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(c, opts, S), d_out, scalars);  // ends with a stream sync
+    if (*h_overflow && c->opt_select_rounds) c->opt_select_rounds = 0;
     timing_collect(c);
     if (rc) return rc;
     for (int j = 0; j < S; j++) {
@@ -1249,7 +1320,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
                  ? fail(c, CHICDIFF_E_INVALID, "theta_grid: bad arguments")
                  : check_counts_group(c, n, S, nullptr, d);  // design ~ 1  ("sic!", chicdiff.R:1629-1631)
     if (!rc) rc = check_opts(c, opts);
-    if ((rc = shard_consensus(c, rc))) return rc;
+    if ((rc = shard_consensus(c, rc, n))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     timing_reset(c);
     const Opts o = make_opts(c, opts, S);

@@ -20,6 +20,7 @@
 //   void sel_gather_counts(const SelSpec&);     //   own row of the count buffer,
 //   void sel_gather_place(const SelSpec&);      //   own candidates at their offset in the zeroed hist() buffer,
 //   void sel_gather_finish(const SelSpec&);     //   sort + pick; sets sel_fast_done when every list fitted
+//   bool sel_gather_done();                     //   did they?  (may answer "yes" without looking, if an overflow is caught later)
 #pragma once
 #include "fit_state.h"
 
@@ -69,7 +70,7 @@ int drive_select(B &be, const SelSpec &a) {
             be.sel_gather_place(a);
             if (be.allreduce(be.hist(), (int64_t)a.ncol * 2 * kSelCap)) return -1;
             be.sel_gather_finish(a);
-            if (be.sync_scalars()->sel_fast_done) break;
+            if (be.sel_gather_done()) break;  // HIP backend: assumed (checked with the fit's final scalars: sel_overflow); test backend: looked up
         }
     }
     be.sel_finish(a);

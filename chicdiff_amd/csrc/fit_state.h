@@ -53,6 +53,9 @@ struct FitScalars {
     // schedule of the gene-wise line search (disp_kernels.hip: order_*): rows of order[0, ord_na) are dealt out statically,
     // rows of order[ord_na, ord_n) through the queue; all-zero rows are in neither
     int64_t ord_na, ord_n;
+    // sharded selects run optimistically (no host look at sel_fast_done): a candidate list that did not fit (massive ties)
+    // leaves this set, the host sees it with the fit's final scalars and refits with every histogram round
+    int32_t sel_overflow, _pad3;
 };
 
 // order-preserving map double -> uint64 (NaN never passed in)

@@ -233,12 +233,12 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
     }
 }
 // sharded fits: this rank's slice of the rows the trend is fitted to, written into the all-ranks arrays (zero elsewhere; the
-// sum-all-reduce that follows is then an all-gather).  y = NaN marks a row that does not take part.
+// sum-all-reduce that follows is then an all-gather).  y = NaN marks an all-zero row.
 __global__ __launch_bounds__(256) void trend_gather_kernel(FitDims d, FitWork w, double minDisp, double *xg, double *yg) {
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
         const double y = w.dispGene[i];
         xg[i] = w.baseMean[i];
-        yg[i] = (!w.allZero[i] && y > 100 * minDisp) ? y : NAN;
+        yg[i] = w.allZero[i] ? NAN : y;  // (the trend kernel applies useForFit itself; the MAD of the residuals wants y >= 100 minDisp)
     }
 }
 void launch_trend_gather(FitDims d, FitWork w, Opts o, double *xg, double *yg, hipStream_t st) {
@@ -745,7 +745,10 @@ __global__ __launch_bounds__(256) void sel_gfinish_kernel(SelArgs a, FitWork w, 
     __shared__ uint64_t s_k[kSelCap];
     FitScalars *sc = w.sc;
     const int nq = 2 * a.ncol;
-    if (!sel_gather_fits(w.selcnt, world, nq)) return;
+    if (!sel_gather_fits(w.selcnt, world, nq)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->sel_overflow = 1;  // the host refits with every histogram round (api.hip)
+        return;
+    }
     const int col = blockIdx.x;
     const uint64_t p0 = sc->sel_prefix[2 * col], p1 = sc->sel_prefix[2 * col + 1];
     uint64_t result[2] = {p0, p1};

@@ -109,6 +109,7 @@ struct CpuBackend {
     bool sel_shortcut(const SelSpec &) { return false; }
     // sharded shortcut (fit_state.h), plain-loop twin of the HIP kernels
     bool sel_can_gather() const { return world_ <= kSelMaxWorld && !no_gather; }
+    bool sel_gather_done() { return sync_scalars()->sel_fast_done != 0; }
     bool no_gather = false;
     double *sel_counts() { return cnt_.data(); }
     void sel_keep_local_hist(const SelSpec &a) { std::copy(hist_.begin(), hist_.begin() + (size_t)a.ncol * 2 * kSelBins, hist_local_.begin()); }

@@ -382,7 +382,7 @@ def test_allreduce_hook_on_device_single_rank(ctx, oracle):
         c2.set_process_group()
         out, sc1 = c2.nbglm_fit(dk, dn, d["group"])
         sf1 = c2.size_factors(dk)
-        assert c2._hook.error is None and c2._hook.calls > 12
+        assert c2._hook.error is None and c2._hook.calls >= 7  # consensus, nf column sums, the size-factor select (2 histogram rounds + counts + candidates), trend rows, final sums
         # (size factors, column sums, the trend's rows gathered in two collectives, four select rounds with their
         # candidate gathers, the final sums; with option sharded_trend_gather = 0 the trend alone makes ~20 calls)
         # medians and sums go through reordered partial sums: identical up to their rounding
@@ -785,7 +785,7 @@ def _two_rank_worker(rank, world, port, n, S, q):
         c.set_process_group(memory="device_via_host")
         dk, dF = c.to_device(d["counts"][lo:hi], np.int32), c.to_device(fm[lo:hi], np.float64)
         out, sc = c.wald_test(dk, dF, d["group"], theta=0.5)
-        assert c._hook.error is None and c._hook.calls > 12
+        assert c._hook.error is None and c._hook.calls >= 7
         # a shard one rank cannot fit (here: empty on rank 1, n < 1) must fail on EVERY rank, not hang the others in
         # their first collective
         msgs = []
