@@ -432,7 +432,7 @@ constexpr int kStampSlots = 12;  // start, queue-empty, exit (s_memrealtime), li
 //     with alpha <= 0.1 need no product;
 //     The nr+1 prefix products and harmonic sums are tabulated once per row and tick in LDS;
 //   * the products of all samples are multiplied up (mantissa/exponent) and logged ONCE per row.
-// mu_j = max(nf_j * groupmean_g, minmu) is rebuilt on the fly from LDS.
+// mu_j = max(nf_j * groupmean_g, minmu) sits in LDS (formed when the row is staged).
 struct RowConsts {  // what depends only on the evaluation point a = log(alpha)
     double a, alpha, r, lgS0, dgS0;
     int nr;
@@ -461,11 +461,12 @@ struct SampleVals {
     int pe;
 };
 // P = prod_{i<n}(r+i), H = sum_{i<n} 1/(r+i) for n = min(y, nr)
-__device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double nfj, int yi, bool g, double gm0, double gm1,
-                                                    double minmu, double P, double H, const LogEntry *lt) {
+// mu = max(nf_j * groupmean_g, minmu) does not change during a row's search: it is formed once, when the row is staged, and kept in
+// the LDS column in place of nf_j (round 3: five instructions per sample and tick less, two shuffled operands less per
+// samples-across-lanes tick; same product, same bits)
+__device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double mu, int yi, double P, double H, const LogEntry *lt) {
     SampleVals v;
     const double y = (double)yi;
-    const double mu = fmax(nfj * (g ? gm1 : gm0), minmu);
     const double ma = mu * c.alpha;
     const double t = 1.0 + ma;
     const double rt = rcp(t);
@@ -524,7 +525,7 @@ __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c,
 // Row-per-lane evaluation: all S samples of the row in LDS column `slot` (the lane's own row, or — grid burst —
 // another lane's), the prefix table in the lane's own column.
 __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int slot, int S, uint64_t gmask,
-                                           bool p2, double gm0, double gm1, double minmu, double a,
+                                           bool p2, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
                                            double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
     const RowConsts c = row_consts(a, lt);
@@ -547,7 +548,7 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
         const int yi = s_y[j * 64 + slot];
         const int n = yi < c.nr ? yi : c.nr;
         const bool g = (gmask >> j) & 1;
-        accumulate(acc, sample_values(c, s_nf[j * 64 + slot], yi, g, gm0, gm1, minmu, s_tab[n * 64 + lane], s_tab[(11 + n) * 64 + lane], lt), g);
+        accumulate(acc, sample_values(c, s_nf[j * 64 + slot], yi, s_tab[n * 64 + lane], s_tab[(11 + n) * 64 + lane], lt), g);
     }
     finish_point(acc, c, p2, use_prior, prior_mean, prior_isig, lp, dlp, lt);
 }
@@ -566,8 +567,8 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
 // (Measured and dropped: handing the stragglers to a second, densely packed launch — a wave's tick takes
 // ~5 us alone or with a neighbour on its SIMD, the tail is bound by the ~130 serial ticks, not by issue.)
 __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int *s_y, int lane, int S, int lg, uint64_t gmask,
-                                                  bool p2, double minmu, unsigned long long actmask, bool active, double a_eval,
-                                                  double gm0, double gm1, bool use_prior, double prior_mean, double prior_isig,
+                                                  bool p2, unsigned long long actmask, bool active, double a_eval,
+                                                  bool use_prior, double prior_mean, double prior_isig,
                                                   double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
     const int grp = lane >> lg, jj = lane & ((1 << lg) - 1);
     // owner of group g = the g-th live lane (wave-uniform walk over the set bits)
@@ -576,7 +577,6 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
         if (grp == nact) owner = __ffsll((long long)m) - 1;
     const bool has = grp < nact;
     const double a_o = __shfl(a_eval, owner);
-    const double gm0_o = __shfl(gm0, owner), gm1_o = __shfl(gm1, owner);
     const double pm_o = use_prior ? __shfl(prior_mean, owner) : 0.0;
     const RowConsts c = row_consts(a_o, lt);
     const bool mine = has && jj < S;
@@ -592,7 +592,7 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
             zz += 1.0;
         }
     }
-    const SampleVals v = sample_values(c, nfj, yi, (gmask >> jj) & 1, gm0_o, gm1_o, minmu, P, H, lt);
+    const SampleVals v = sample_values(c, nfj, yi, P, H, lt);
     Acc acc;
     const int base = grp << lg;
     for (int j = 0; j < S; j++) {
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
 
     int phase = PH_NEED, iter = 0, iacc = 0, gt = 0, gbi = 0;
     int64_t row = -1;
-    double a = 0, lp = 0, dlp = 0, kappa = 0, init_lp = 0, a0 = 0, gm0 = 0, gm1 = 0, prior_mean = 0;
+    double a = 0, lp = 0, dlp = 0, kappa = 0, init_lp = 0, a0 = 0, prior_mean = 0;
     double gbest = 0, ghat = 0, dgene = 0, a_new = 0, alpha_cur = 0;
     int is_outlier = 0;
     bool queue_empty = false;
@@ -721,8 +721,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     row = r;
                     double hdr[4];
                     load_row(A.w.rowpack, r, S, s_nf, s_y, lane, hdr);
-                    gm0 = hdr[0];
-                    gm1 = hdr[1];
+                    for (int j = 0; j < S; j++)  // nf_j -> mu_j, once per row
+                        s_nf[j * 64 + lane] = fmax(s_nf[j * 64 + lane] * (((gmask >> j) & 1) ? hdr[1] : hdr[0]), o.minmu);
                     if (!MAP) {  // start values come from disp_init_kernel
                         a0 = hdr[2];
                         a = hdr[3];
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         // ticks of a straggler become 2.  Same eval_point(), same first-maximum rule: identical bits.
         int burst_owner = -1, slot = lane, hk = 0, nhelp = 0;
         bool helper = false;
-        double gm0_e = gm0, gm1_e = gm1, pm_e = prior_mean;
+        double pm_e = prior_mean;
         if (queue_empty && A.spread) {
             const unsigned long long ingrid = __ballot(phase == PH_GRID1 || phase == PH_GRID2);
             const unsigned long long idle = __ballot(phase == PH_DONE);
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                 burst_owner = __ffsll((long long)ingrid) - 1;
                 const int ph_o = __shfl(phase, burst_owner), gt_o = __shfl(gt, burst_owner);
                 const double ghat_o = __shfl(ghat, burst_owner);
-                const double g0 = __shfl(gm0, burst_owner), g1 = __shfl(gm1, burst_owner), pmo = __shfl(prior_mean, burst_owner);
+                const double pmo = __shfl(prior_mean, burst_owner);
                 const int nidle = __popcll(idle);
                 nhelp = 19 - gt_o < nidle ? 19 - gt_o : nidle;  // points gt_o+1 .. gt_o+nhelp go to idle lanes
                 const int r = __popcll(idle & ((1ull << lane) - 1ull));
@@ -792,8 +792,6 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     helper = true;
                     hk = gt_o + r + 1;
                     slot = burst_owner;
-                    gm0_e = g0;
-                    gm1_e = g1;
                     pm_e = pmo;
                     a_eval = ph_o == PH_GRID1 ? ((hk == 19) ? ghi : glo + hk * gstep)
                                               : ((hk == 19) ? ghat_o + gstep : (ghat_o - gstep) + hk * (2.0 * gstep / 19.0));
@@ -819,10 +817,10 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
         })
         if (burst_owner < 0 && queue_empty && spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) {
-            eval_point_spread(s_nf, s_y, lane, S, spread_lg, gmask, p2, o.minmu, actmask, active, a_eval, gm0, gm1, MAP,
+            eval_point_spread(s_nf, s_y, lane, S, spread_lg, gmask, p2, actmask, active, a_eval, MAP,
                               prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab);
         } else if (active || helper) {
-            eval_point(s_nf, s_y, s_tab, lane, slot, S, gmask, p2, gm0_e, gm1_e, o.minmu, a_eval, MAP, pm_e, prior_isig, l_new,
+            eval_point(s_nf, s_y, s_tab, lane, slot, S, gmask, p2, a_eval, MAP, pm_e, prior_isig, l_new,
                        dl_new, alpha_new, s_logtab);
         }
         bool burst_done = false;  // this lane owns the burst: l_new / hk now describe the best of the 20 points
