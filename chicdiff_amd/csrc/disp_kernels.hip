@@ -566,7 +566,7 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
 // Gain at 2 M rows: 1 % of the gene-wise launch at S = 8, 4 % at S = 4, 10 % at S = 16.
 // (Measured and dropped: handing the stragglers to a second, densely packed launch — a wave's tick takes
 // ~5 us alone or with a neighbour on its SIMD, the tail is bound by the ~130 serial ticks, not by issue.)
-__device__ __forceinline__ void eval_point_spread(const double *s_nf, const int *s_y, int lane, int S, int lg, uint64_t gmask,
+__device__ __forceinline__ void eval_point_spread(const double *s_nf, const int *s_y, double *s_x, int lane, int S, int lg, uint64_t gmask,
                                                   bool p2, unsigned long long actmask, bool active, double a_eval,
                                                   bool use_prior, double prior_mean, double prior_isig,
                                                   double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
@@ -593,17 +593,36 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
         }
     }
     const SampleVals v = sample_values(c, nfj, yi, P, H, lt);
+    // the five values of every sample pass through the wave's prefix-table area (idle in this layout), [value][lane]: each lane
+    // then reads its group's S samples — four samples' loads in flight at a time, same address within a group (a broadcast),
+    // neighbouring banks across groups — and folds them in sample order.  (Round 2 fetched them with nine ds_bpermute per sample
+    // inside the fold loop: one LDS round trip per sample on the critical path of a tick that is all latency.)
+    s_x[lane] = v.wj;
+    s_x[64 + lane] = v.pm;
+    s_x[128 + lane] = v.tll;
+    s_x[192 + lane] = v.tsd;
+    reinterpret_cast<int *>(s_x + 256)[lane] = v.pe;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     Acc acc;
     const int base = grp << lg;
-    for (int j = 0; j < S; j++) {
-        SampleVals u;
-        u.wj = __shfl(v.wj, base + j);
-        u.pm = __shfl(v.pm, base + j);
-        u.tll = __shfl(v.tll, base + j);
-        u.tsd = __shfl(v.tsd, base + j);
-        u.pe = __shfl(v.pe, base + j);
-        accumulate(acc, u, (gmask >> j) & 1);
+    for (int j0 = 0; j0 < S; j0 += 4) {
+        SampleVals u[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int src = base + (j0 + t < S ? j0 + t : j0);
+            u[t].wj = s_x[src];
+            u[t].pm = s_x[64 + src];
+            u[t].tll = s_x[128 + src];
+            u[t].tsd = s_x[192 + src];
+            u[t].pe = reinterpret_cast<const int *>(s_x + 256)[src];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (j0 + t < S) accumulate(acc, u[t], (gmask >> (j0 + t)) & 1);
     }
+    __builtin_amdgcn_wave_barrier();  // (the area is written again only after every lane has read it)
     double lp_g, dlp_g;
     finish_point(acc, c, p2, use_prior, pm_o, prior_isig, lp_g, dlp_g, lt);
     // an active lane's group is its rank among the active lanes
@@ -817,7 +836,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
         })
         if (burst_owner < 0 && queue_empty && spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) {
-            eval_point_spread(s_nf, s_y, lane, S, spread_lg, gmask, p2, actmask, active, a_eval, MAP,
+            eval_point_spread(s_nf, s_y, s_tab, lane, S, spread_lg, gmask, p2, actmask, active, a_eval, MAP,
                               prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab);
         } else if (active || helper) {
             eval_point(s_nf, s_y, s_tab, lane, slot, S, gmask, p2, a_eval, MAP, pm_e, prior_isig, l_new,

@@ -139,6 +139,7 @@ struct WaldArgs {
     Opts o;
     int chunk;  // rows a wave takes from the global queue per atomic
     const int32_t *order;  // schedule (slow rows first, wald_prep_kernel + order_*), NULL = rows 0..n-1
+    int spread;            // 0 = row-per-lane ticks only (option "line_search_spread", for the bit-identity test)
 };
 
 // IRLS.  Tick k evaluates at beta_k: deviance(beta_k) for the convergence test and the
@@ -163,6 +164,8 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
     unsigned long long *queue = A.w.queue + 2;
     const int32_t *__restrict__ order = A.order;
     const unsigned long long nTot = order ? (unsigned long long)A.w.sc->ord_n : (unsigned long long)n;
+    int spread_lg = A.spread ? 1 : -1;  // log2(lanes per row) of the samples-across-lanes layout; -1 = never
+    while (spread_lg >= 0 && (1 << spread_lg) < S) spread_lg++;
 
     bool need = true, done = false, queue_empty = false;
     unsigned long long chunk_next = 0, chunk_end = 0;
@@ -226,14 +229,93 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
             }
         }
         if (__ballot(!done) == 0ull) break;
-        if (!need && !done) {  // lanes without a row sit this tick out; the wave as a whole goes on
+        const bool active = !need && !done;
+        const unsigned long long actmask = __ballot(active);
+        double wA = 0, wB = 0, uA = 0, uB = 0, Dl = 0, zcA = 0, zcB = 0, Dc = 0;
+        const bool spread_now = queue_empty && spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64;
+        if (spread_now) {
+            // Samples across lanes for the end of the launch (as disp_kernels.hip eval_point_spread): the rows still running are
+            // the ones that need 20-100 steps, a handful per wave, and a row-per-lane tick costs the same ~800 instructions for
+            // one busy lane as for 64.  The g-th live row is handled by lanes G g .. G g + G - 1 (G = 2^spread_lg >= S), one
+            // sample each; every lane of the group then folds the S samples' terms in sample order with the very operations of
+            // the loop below (same values, same order: same bits), and the lane that owns the row picks the sums up.
+            const int grp = lane >> spread_lg, jj = lane & ((1 << spread_lg) - 1);
+            int owner = 0, nact = 0;
+            for (unsigned long long m = actmask; m; m &= m - 1ull, nact++)
+                if (grp == nact) owner = __ffsll((long long)m) - 1;
+            const bool mine = grp < nact && jj < S;
+            const double b0o = __shfl(b0, owner), b1o = __shfl(b1, owner), alo = __shfl(alpha, owner), szo = __shfl(size, owner);
+            const double etaAo = b0o, etaBo = b0o + b1o;
+            const double E0 = exp(etaAo), E1 = exp(etaBo);
+            const double nfj = mine ? s_nf[jj * 64 + owner] : 1.0;
+            const double y = mine ? (double)s_y[jj * 64 + owner] : 0.0;
+            const bool g = (gmask >> jj) & 1;
+            const double raw = nfj * (g ? E1 : E0);
+            const bool floored = raw < o.minmu;
+            const double mu = floored ? o.minmu : raw;
+            const double ma = alo * mu;
+            const double t1 = 1.0 + ma;
+            const double rt = rcp(t1);
+            const double wj = mu * rt;
+            const double yr = y * rt;
+            const double sy = szo + y;
+            const double L = tlog1p_from(ma, t1, rt, s_logtab);
+            double de = 0.0;
+            if (floored) de = (tlog(o.minmu, s_logtab) - tlog(nfj, s_logtab)) - (g ? etaBo : etaAo);
+            const int fl = floored ? 1 : 0;
+            const int base = grp << spread_lg;
+            for (int j0 = 0; j0 < S; j0 += 4) {
+                double q_wj[4], q_yr[4], q_sy[4], q_L[4], q_de[4], q_y[4];
+                int q_fl[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {  // four samples' terms in flight at a time
+                    const int src = base + (j0 + t < S ? j0 + t : j0);
+                    q_wj[t] = __shfl(wj, src);
+                    q_yr[t] = __shfl(yr, src);
+                    q_sy[t] = __shfl(sy, src);
+                    q_L[t] = __shfl(L, src);
+                    q_fl[t] = __shfl(fl, src);
+                    q_de[t] = __shfl(de, src);
+                    q_y[t] = __shfl(y, src);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (j0 + t >= S) continue;
+                    const bool gj = (gmask >> (j0 + t)) & 1;
+                    const double gB = gj ? 1.0 : 0.0, gA = gj ? 0.0 : 1.0;
+                    wA = fma(q_wj[t], gA, wA);
+                    wB = fma(q_wj[t], gB, wB);
+                    uA = fma(q_yr[t], gA, uA);
+                    uB = fma(q_yr[t], gB, uB);
+                    Dl = fma(q_sy[t], q_L[t], Dl);
+                    if (q_fl[t]) {
+                        if (gj) zcB = fma(q_wj[t], q_de[t], zcB); else zcA = fma(q_wj[t], q_de[t], zcA);
+                        Dc = fma(-q_y[t], q_de[t], Dc);
+                    }
+                }
+            }
+            // an active lane's group is its rank among the active lanes
+            const int src = (active ? __popcll(actmask & ((1ull << lane) - 1ull)) : 0) << spread_lg;
+            wA = __shfl(wA, src);
+            wB = __shfl(wB, src);
+            uA = __shfl(uA, src);
+            uB = __shfl(uB, src);
+            Dl = __shfl(Dl, src);
+            zcA = __shfl(zcA, src);
+            zcB = __shfl(zcB, src);
+            Dc = __shfl(Dc, src);
+        }
+        if (active) {  // lanes without a row sit this tick out; the wave as a whole goes on
 
             // z_j = eta_j + (y_j - mu_j)/mu_j and w_j = mu_j/(1 + alpha mu_j) give w_j z_j = w_j (eta_j - 1) + y_j/(1 + alpha mu_j):
             // no 1/mu, and eta is the group's constant unless mu was floored at minmu (rare, handled in the branch)
             const double etaA = b0, etaB = b0 + b1;
-            const double E0 = exp(etaA), E1 = exp(etaB);
-            double wA = 0, wB = 0, uA = 0, uB = 0, Dl = 0, zcA = 0, zcB = 0, Dc = 0;
-            for (int j = 0; j < S; j++) {
+            double E0 = 0, E1 = 0;
+            if (!spread_now) {  // (wave-uniform)
+                E0 = exp(etaA);
+                E1 = exp(etaB);
+            }
+            for (int j = 0; j < (spread_now ? 0 : S); j++) {
                 const double nfj = s_nf[j * 64 + lane];
                 const double y = (double)s_y[j * 64 + lane];
                 const bool g = (gmask >> j) & 1;
@@ -551,7 +633,7 @@ void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWor
     if (o.schedule) launch_order_build(d, w, 0, false, st);
 }
 void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
-    WaldArgs A{counts, nf, d, w, o, 64, o.schedule ? w.order : nullptr};
+    WaldArgs A{counts, nf, d, w, o, 64, o.schedule ? w.order : nullptr, o.spread};
     const size_t lds_per_wave = (size_t)d.S * 64 * 12;
     int threads = 256;
     while (threads > 64 && lds_per_wave * (threads / 64) > 40 * 1024) threads >>= 1;

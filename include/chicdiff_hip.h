@@ -67,7 +67,7 @@ int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, 
                                int32_t world_size, int32_t rank);
 
 /* Tuning / test options; results never depend on them, the defaults are what bench.py measures.
- *   "line_search_spread"        1 (default) | 0: evaluate straggler rows with their samples spread across lanes
+ *   "line_search_spread"        1 (default) | 0: evaluate straggler rows (line searches and IRLS) with their samples spread across lanes
  *   "line_search_min_waves"     2 (default) .. 4: waves per SIMD the line-search kernel variant is built for
  *   "line_search_schedule"      1 (default) | 0: the gene-wise line search visits the rows likely to need DESeq2's full 100
  *                               iterations first (score alpha_init * smaller group mean); 0 = natural row order

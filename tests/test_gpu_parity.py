@@ -880,14 +880,14 @@ def test_two_ranks_sharing_one_gpu_match_single_rank(ctx):
 
 @pytest.mark.parametrize("n,S,group", [(300000, 8, None), (40000, 5, [0, 0, 1, 1, 1]), (30000, 16, None), (20000, 3, [0, 0, 0])])
 def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
-    """At the end of a launch the line-search kernels evaluate stragglers with the samples spread across lanes
-    (disp_kernels.hip: eval_point_spread).  Which ticks run in which layout depends on the schedule, so the two
-    layouts must agree to the last bit — and repeated runs must be identical."""
+    """At the end of a launch the line-search kernels and the IRLS evaluate stragglers with the samples spread across lanes
+    (disp_kernels.hip: eval_point_spread; wald_kernels.hip: the spread_now branch).  Which ticks run in which layout depends
+    on the schedule, so the two layouts must agree to the last bit — and repeated runs must be identical."""
     import os
     d = synth.make(n, S)
     group = np.asarray(d["group"] if group is None else group, dtype=np.int32)
     dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64)
-    want = ["dispGeneEst", "dispGeneIter", "dispMAP", "dispIter", "dispersion", "log2FoldChange", "lfcSE", "pvalue"]
+    want = ["dispGeneEst", "dispGeneIter", "dispMAP", "dispIter", "dispersion", "log2FoldChange", "lfcSE", "pvalue", "betaIter", "deviance"]
 
     def run():
         out, _ = ctx.nbglm_fit(dk, dn, group, want=want)
@@ -906,6 +906,8 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
     finally:
         ctx.set_option("line_search_schedule", 1)
     assert (a["dispGeneIter"] >= 100).sum() > 10  # the stragglers this is about are present
+    if n >= 300000:
+        assert (a["betaIter"] >= 20).sum() > 0  # ... and the IRLS's
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), f"{k}: two runs differ"
         assert np.array_equal(a[k], c[k], equal_nan=True), f"{k}: layouts differ in {np.sum(~((a[k] == c[k]) | (np.isnan(a[k]) & np.isnan(c[k]))))} rows"
