@@ -14,7 +14,8 @@ global statistics (size-factor medians, trend sums, MAD, deviance) go through RC
 torch.distributed.run`, spawned before this process touches a GPU); under an external
 torch.distributed.run (WORLD_SIZE set) it is a rank.  --scaling strong (default: BASELINE.json
 configs[3], "2 M x 8 sharded across 8 MI355X": --rows is the GLOBAL row count, rows/N per rank) or
-weak (--rows per rank).
+weak (--rows per rank); for N > 1 the other of the two is measured as well, after the first, and reported
+under "other_scaling" (same K and W; `value` is always the --scaling one).
 
 Prints ONE JSON line on rank 0.
 """
@@ -145,6 +146,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-kernels", action="store_true", help="skip the window-sum / offsets / count-join side measurement")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--one-mode", action="store_true", help="N > 1: skip the second measurement (the other of strong / weak scaling)")
     args = ap.parse_args()
 
     force_dist = os.environ.get("CHICDIFF_BENCH_FORCE_DIST") == "1"  # rehearse the N > 1 code path with a 1-rank group
@@ -186,12 +188,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     S = args.samples
-    if args.scaling == "strong":
-        lo, hi = shard_bounds(args.rows, world, rank)
-        n, n_global = hi - lo, args.rows
-    else:
-        lo, n, n_global = rank * args.rows, args.rows, world * args.rows
-    d = synth.make(n, S, start=lo)
     ctx = hip.HipContext(local_rank)
     collectives, comm_ranks = "none (single rank)", 1
     if dist is not None:
@@ -209,37 +205,50 @@ def main():
             ctx.set_process_group(memory="device_via_host" if share_gpu else "device")
             collectives = ("gloo through torch.distributed.all_reduce, device buffers staged through the host (one-GPU rehearsal)" if share_gpu
                            else "RCCL through torch.distributed.all_reduce (host callback)")
-    dk = ctx.to_device(d["counts"], np.int32)
-    dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)  # region-level FullMean (window sums)
-    group = d["group"]
     want = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue"]
-    outputs = {}
-
-    def step():
-        return ctx.wald_test(dk, dfm, group, theta=args.theta, want=want, outputs=outputs)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.enable_timing(True)
-    ktimes = {}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, sc = step()
-        for k, (ms, cnt) in ctx.kernel_times().items():
-            a = ktimes.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.enable_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(scaling):
+        """W warm-up steps, then exactly K timed steps between two barriers; the MAX over ranks."""
+        if scaling == "strong":
+            lo, hi = shard_bounds(args.rows, world, rank)
+            n, n_global = hi - lo, args.rows
+        else:
+            lo, n, n_global = rank * args.rows, args.rows, world * args.rows
+        d = synth.make(n, S, start=lo)
+        dk = ctx.to_device(d["counts"], np.int32)
+        dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)  # region-level FullMean (window sums)
+        group = d["group"]
+        outputs = {}
+
+        def step():
+            return ctx.wald_test(dk, dfm, group, theta=args.theta, want=want, outputs=outputs)
+
+        for _ in range(args.warmup):
+            step()
+        ctx.enable_timing(True)
+        ktimes = {}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _, sc = step()
+            for k, (ms, cnt) in ctx.kernel_times().items():
+                a = ktimes.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ctx.enable_timing(False)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return dict(elapsed=elapsed, n=n, n_global=n_global, ktimes=ktimes, sc=sc, d=d, dk=dk, dfm=dfm, group=group)
+
+    m = measure(args.scaling)
+    elapsed, n, n_global, ktimes, sc, d, dk, dfm, group = (m[k] for k in ("elapsed", "n", "n_global", "ktimes", "sc", "d", "dk", "dfm", "group"))
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_global / (elapsed / args.steps)
@@ -286,6 +295,15 @@ def main():
                                  if "allreduce" in ktimes else None),
         "fit_status": int(sc["status"]),
     }
+    if world > 1 and not args.one_mode:
+        # the other way of scaling, measured in the same run with the same K / W: `value` follows --scaling (default strong =
+        # BASELINE.json configs[3], 2 M rows in all); this is the same metric with the per-GPU work fixed instead
+        other = "weak" if args.scaling == "strong" else "strong"
+        del m, dk, dfm, d
+        mo = measure(other)
+        result["other_scaling"] = {"scaling": other, "value": round(mo["n_global"] / (mo["elapsed"] / args.steps), 1), "unit": "interactions/s",
+                                   "ms_per_step": round(mo["elapsed"] / args.steps * 1e3, 3), "rows_per_gpu": mo["n"], "global_rows": mo["n_global"],
+                                   "steps": args.steps, "warmup": args.warmup}
     if rank == 0 and world == 1 and not args.no_hbm_kernels:
         result["hbm_kernels"] = hbm_kernels(ctx, torch, n, S)
         result["theta_grid"] = theta_grid_time(ctx, torch, dk, dfm, S)
