@@ -113,3 +113,132 @@ def test_r_wrapper_defines_the_reference_signature_and_messages():
     p = open(RSRC[3]).read()
     assert re.search(r"^IHWcorrection <- function\(chicdiff\.settings, DESeqOut, FullRegionData, DESeqOutControl, FullControlRegionData,\s*countput, DiagPlot = TRUE, diffbaitPlot = TRUE, suffix = \"\"\)", p, re.M)
     assert re.search(r'^getRegionUniverse <- function\(chicdiff\.settings, suffix = ""\)', p, re.M)
+
+
+# ---- a lint of the R sources: what a typo would break ---------------------------------------------------------------
+# (text only — it resolves names and argument names, it does not evaluate anything)
+
+def _r_strip(src):
+    """comments out, string literals -> "" (so that brackets and names inside them do not count)"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == "#":
+            while i < n and src[i] != "\n":
+                i += 1
+        elif c in "\"'":
+            q = c
+            i += 1
+            while i < n and src[i] != q:
+                if src[i] == "\\":
+                    i += 1
+                i += 1
+            i += 1
+            out.append('""')
+        elif c == "`":
+            j = src.index("`", i + 1)
+            out.append(src[i:j + 1])
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def _r_args(s, open_paren):
+    """top-level arguments of the call whose "(" is at s[open_paren]; returns (list of argument texts, index after ")")"""
+    depth, cur, args, i = 0, "", [], open_paren
+    while i < len(s):
+        c = s[i]
+        if c in "([{":
+            depth += 1
+            if depth > 1:
+                cur += c
+        elif c in ")]}":
+            depth -= 1
+            if depth == 0:
+                args.append(cur)
+                return [a.strip() for a in args if a.strip()], i + 1
+            cur += c
+        elif c == "," and depth == 1:
+            args.append(cur)
+            cur = ""
+        else:
+            cur += c
+        i += 1
+    raise AssertionError("unbalanced call")
+
+
+_NAME = r"[A-Za-z.][A-Za-z0-9._]*"
+# base / stats / utils functions and control-flow words the host uses: a new name must be added here deliberately
+_BASE = set("""abs all any anyNA array as.character as.data.frame as.double as.integer attributes bitwAnd c cat cbind class dev.off
+emptyenv factor for function getOption head identical if inherits is.na is.nan is.null lapply length list log match matrix max mean
+merge message min names ncol new.env nrow numeric on.exit order paste paste0 plot rep return rowSums runif sample sapply saveRDS
+seq_along seq_len setdiff sort sprintf stderr stop stopifnot storage.mode structure sum suppressWarnings table unique unlist vector
+warning which while repeat switch tryCatch exp sqrt floor round is.numeric is.character nchar rev cumsum do.call Reduce Filter Map
+vapply mapply file.path basename readRDS load get exists environment invisible .Call""".split())
+_PKGS = {"data.table", "stats", "IHW", "cowplot", "ggplot2", "Chicago", "DESeq2", "utils", "methods"}
+_KEPT_REFERENCE = {".DESeq2WrapReference", ".getFullRegionDataReference", ".getRegionUniverseReference", ".IHWcorrectionReference"}
+
+
+def _r_host_sources():
+    return [p for p in RSRC if os.sep + "r" + os.sep in p]
+
+
+def test_r_sources_brackets_balance():
+    for path in RSRC:
+        s = _r_strip(open(path).read())
+        stack = []
+        pairs = {")": "(", "]": "[", "}": "{"}
+        for k, c in enumerate(s):
+            if c in "([{":
+                stack.append((c, s.count("\n", 0, k) + 1))
+            elif c in ")]}":
+                assert stack and stack[-1][0] == pairs[c], (path, "line", s.count("\n", 0, k) + 1, c)
+                stack.pop()
+        assert not stack, (path, stack[-3:])
+
+
+def test_every_function_the_r_host_calls_exists_and_takes_the_arguments_it_is_given():
+    """A name the host calls is one of: a function defined in r/R/ (or a parameter / local of the calling file), a function
+    the reference defines (tests/golden/reference_functions.json: names and formals from Chicdiff/R/chicdiff.R, made by
+    tools/make_reference_function_index.py), one of the four reference functions the installation keeps under a new
+    name (INTEGRATION.md), a pkg::name of a package the reference already imports, or a listed base function.  Named
+    arguments passed to the reference's or the host's own functions are formals of those functions."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_functions.json")))
+    texts = {p: _r_strip(open(p).read()) for p in _r_host_sources()}
+    own = {}
+    for p, s in texts.items():
+        for m in re.finditer(r"(" + _NAME + r")\s*(?:<-|=)\s*function\s*\(", s):
+            formals, _ = _r_args(s, m.end() - 1)
+            own[m.group(1)] = [re.split(r"\s*=", a, maxsplit=1)[0].strip() for a in formals]
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for kept in _KEPT_REFERENCE:
+        assert kept in integration, kept + " is called by the host but INTEGRATION.md does not say where it comes from"
+        ref[kept] = ref[kept[1:].replace("Reference", "")]  # .DESeq2WrapReference is the reference's DESeq2Wrap
+    checked = 0
+    for p, s in texts.items():
+        params = {a for f in own.values() for a in f}
+        for m in re.finditer(r"(?<![A-Za-z0-9._$@:])((?:" + _NAME + r"::)?" + _NAME + r")\s*\(", s):
+            name = m.group(1)
+            line = s.count("\n", 0, m.start()) + 1
+            if "::" in name:
+                assert name.split("::")[0] in _PKGS, (p, line, name)
+                continue
+            known = name in own or name in ref or name in _BASE or name in params
+            assert known, f"{os.path.basename(p)}:{line}: call of unknown function {name}()"
+            target = own.get(name) or (ref.get(name) if name in ref else None)
+            if target is None or "..." in target:
+                continue
+            args, _ = _r_args(s, m.end() - 1)
+            positional = 0
+            for a in args:
+                nm = re.match(r"(" + _NAME + r")\s*=(?!=)", a)
+                if nm:
+                    assert nm.group(1) in target, f"{os.path.basename(p)}:{line}: {name}() has no argument {nm.group(1)} (formals: {target})"
+                else:
+                    positional += 1
+            assert positional <= len(target), f"{os.path.basename(p)}:{line}: {name}() takes {len(target)} arguments"
+            checked += 1
+    assert checked > 25  # the lint did look at calls
