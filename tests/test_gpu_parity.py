@@ -933,6 +933,72 @@ def test_bh_on_device(ctx, oracle):
     assert np.all(np.isnan(allna))
 
 
+def test_bh_and_filtering_at_benchmark_sizes(ctx, oracle):
+    """p.adjust / results() at 0.4 M - 3.2 M rows (the sizes bench.py's hbm_kernels quotes): BH equal to the oracle to the bit
+    and independent filtering equal to the numpy restatement — uniform, spiked, sorted, reversed, constant, half-NA inputs,
+    massive ties, and inputs with structure at evenly spaced positions (written for the sample sort measured and dropped in
+    round 3, DESIGN.md §5: a sort that samples evenly spaced rows must not depend on what sits there)."""
+    import torch
+    import results_twin as results
+    rng = np.random.default_rng(5)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(ctx.device)
+
+    def bh_check(p, what):
+        got = ctx.bh_adjust(dev(p)).cpu().numpy()
+        ref = oracle.bh_adjust(p)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), what
+        ok = ~np.isnan(ref)
+        assert np.array_equal(got[ok], ref[ok]), what
+
+    for n in (399999, 400000, 1000003, 2000000, 3226387, 3226388):
+        p = rng.uniform(size=n)
+        p[rng.uniform(size=n) < 0.1] **= 8
+        p[rng.integers(0, n, n // 20)] = np.nan
+        bh_check(p, f"spiked uniform, n={n}")
+    n = 1 << 20
+    bh_check(np.sort(rng.uniform(size=n)), "sorted")
+    bh_check(np.sort(rng.uniform(size=n))[::-1].copy(), "reversed")
+    bh_check(np.full(n, 0.25), "constant")
+    p = rng.uniform(size=n)
+    p[: n // 2] = np.nan
+    bh_check(p, "half NA, in one block")
+    p = rng.uniform(size=n)
+    p[rng.integers(0, n, n // 2)] = 0.5
+    p[rng.integers(0, n, n // 4)] = 1.0
+    p[rng.integers(0, n, n // 8)] = 0.0
+    bh_check(p, "massive ties")
+    # every 16 384th-quantile position small, everything else large
+    p = rng.uniform(0.5, 1.0, size=n)
+    pos = (np.arange(16384, dtype=np.int64) * n) // 16384
+    p[pos] = rng.uniform(0.0, 0.1, size=16384)
+    bh_check(p, "structure at evenly spaced rows")
+
+    def if_check(bm, p, what):
+        hp, hinfo = results.independent_filtering(bm, p)
+        dp, dinfo = ctx.independent_filtering(dev(bm), dev(p))
+        assert np.array_equal(dinfo["numRej"], hinfo["numRej"]) and dinfo["index"] == hinfo["index"], what
+        assert np.isclose(dinfo["filterThreshold"], hinfo["filterThreshold"], rtol=1e-15), what
+        assert np.allclose(dp.cpu().numpy(), hp, rtol=1e-13, equal_nan=True), what
+
+    for n in (600000, 2000000):
+        bm = rng.lognormal(np.log(19), 1.4, n)
+        bm[rng.uniform(size=n) < 0.02] = 0.0
+        p = rng.uniform(size=n)
+        p[rng.uniform(size=n) < 0.15] **= 6
+        p[bm == 0] = np.nan
+        p[rng.integers(0, n, 500)] = p[11]
+        if_check(bm, p, f"n={n}")
+    n = 1 << 20
+    bm = rng.lognormal(np.log(19), 1.4, n)
+    p = rng.uniform(size=n) ** 2
+    bm2 = bm.copy()
+    bm2[pos] = 1e-3 * rng.uniform(size=16384)
+    if_check(bm2, p, "baseMean: structure at evenly spaced rows")
+    p2 = rng.uniform(0.5, 1.0, size=n)
+    p2[pos] = rng.uniform(0.0, 0.01, size=16384)
+    if_check(bm, p2, "p-values: structure at evenly spaced rows")
+
+
 def test_ihw_application_on_device_reproduces_golden_table(ctx, golden, oracle):
     """f3: chicdiff.R:2038-2049 on device against the reference's result table and against the oracle."""
     import torch
