@@ -272,6 +272,10 @@ def main():
                     slots = avg_ms * 1e-3 * 1024 * 2.4e9 / 4  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
                     valu = {"insts_per_launch": ent["valu"]["SQ_INSTS_VALU"], "issue_slot_fraction": round(ent["valu"]["SQ_INSTS_VALU"] / slots, 3),
                             "active_lanes_per_inst": ent["valu"]["active_lanes_per_inst"], "source": ent["valu"]["source"]}
+                    if "SQ_ACTIVE_INST_VALU" in ent["valu"]:
+                        # SQ_ACTIVE_INST_VALU counts, in units of four cycles, the cycles a SIMD spends executing VALU instructions: against
+                        # the launch's duration x 1024 SIMDs at the 2.4 GHz peak clock (a lower bound: under this load s_memtime shows ~2.15 GHz)
+                        valu["valu_busy_fraction"] = round(ent["valu"]["SQ_ACTIVE_INST_VALU"] * 4 / (avg_ms * 1e-3 * 1024 * 2.4e9), 3)
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

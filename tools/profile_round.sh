@@ -32,7 +32,8 @@ for k, kn in names.items():
     key = k + ":2000000x8"
     if key in tj and kn in g.index:
         r = g.loc[kn]
-        tj[key]["valu"] = {"SQ_INSTS_VALU": float(r["SQ_INSTS_VALU"]), "active_lanes_per_inst": round(float(r["SQ_THREAD_CYCLES_VALU"] / r["SQ_INSTS_VALU"]), 1),
+        tj[key]["valu"] = {"SQ_INSTS_VALU": float(r["SQ_INSTS_VALU"]), "SQ_ACTIVE_INST_VALU": float(r["SQ_ACTIVE_INST_VALU"]),
+                           "active_lanes_per_inst": round(float(r["SQ_THREAD_CYCLES_VALU"] / r["SQ_INSTS_VALU"]), 1),
                            "source": "profiles/${TAG}_pmc_sq_bench_2Mx8.csv"}
 json.dump(tj, open("$OUT/pmc_traffic.json", "w"), indent=1)
 PY
