@@ -556,8 +556,9 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
 // Samples-across-lanes evaluation for the end of the launch.  Once the queue is empty every wave is left
 // with a dozen rows that still need up to ~130 serial evaluations (flat likelihoods: DESeq2's step size
 // decays faster than the search converges, then the grid takes over), and a row-per-lane tick costs the same
-// ~1600 instructions whether 64 lanes or one are busy.  When at most 64/G rows are live (G = 2^lg >= S), the
-// g-th live row is evaluated by lanes G*g .. G*g+G-1, one sample each: every lane rebuilds the row
+// ~1600 instructions whether 64 lanes or one are busy.  When at most 64/G rows are live (G = 2^lg lanes per row), the
+// g-th live row is evaluated by lanes G*g .. G*g+G-1 — one sample each when G >= S, else samples jj, jj + G, ... (S = 8:
+// four lanes per row for 9-16 live rows, two for 17-32; round 3) —: every lane rebuilds the row
 // constants (same instructions, no extra cost in SIMD), walks its own prefix product, computes its sample's
 // five values, then every lane of the group folds the S results in sample order (so each holds the row's
 // sums) and the owning lane picks the result up.  Same functions, same operand values, same order of the
@@ -570,7 +571,10 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
                                                   bool p2, unsigned long long actmask, bool active, double a_eval,
                                                   bool use_prior, double prior_mean, double prior_isig,
                                                   double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
-    const int grp = lane >> lg, jj = lane & ((1 << lg) - 1);
+    // lanes per row L = 2^lg: one sample per lane when L >= S (at most 64 / L rows), else samples jj, jj + L, ... per lane — the
+    // layout also serves 9 .. 32 live rows (S = 8: four or two lanes per row), where a row-per-lane tick would still walk all S
+    // samples in every lane
+    const int L = 1 << lg, grp = lane >> lg, jj = lane & (L - 1), R = 64 >> lg;
     // owner of group g = the g-th live lane (wave-uniform walk over the set bits)
     int owner = 0, nact = 0;
     for (unsigned long long m = actmask; m; m &= m - 1ull, nact++)
@@ -579,44 +583,47 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
     const double a_o = __shfl(a_eval, owner);
     const double pm_o = use_prior ? __shfl(prior_mean, owner) : 0.0;
     const RowConsts c = row_consts(a_o, lt);
-    const bool mine = has && jj < S;
-    const int yi = mine ? s_y[jj * 64 + owner] : 0;
-    const double nfj = mine ? s_nf[jj * 64 + owner] : 1.0;
-    double P = 1.0, H = 0.0;
-    {
-        const int n = yi < c.nr ? yi : c.nr;
-        double zz = c.r;
-        for (int i = 0; i < n; i++) {  // the same recurrence as the table of eval_point(), stopped at entry n
-            P *= zz;
-            H += rcp(zz);
-            zz += 1.0;
+    // the five values of every sample pass through the wave's prefix-table area (idle in this layout), [value][sample R + group]:
+    // each lane then reads its group's S samples — four samples' loads in flight at a time, same address within a group (a
+    // broadcast), neighbouring banks across groups — and folds them in sample order.  (Round 2 fetched them with nine
+    // ds_bpermute per sample inside the fold loop: one LDS round trip per sample on the critical path of a tick that is all
+    // latency.)  S R <= 256 entries: 4 x 256 doubles + 256 ints of the 22 x 64 doubles.
+    int *s_xe = reinterpret_cast<int *>(s_x + 4 * 256);
+    for (int j = jj; j < S; j += L) {  // (the same trip count in every lane of a group up to the guard)
+        const int yi = has ? s_y[j * 64 + owner] : 0;
+        const double nfj = has ? s_nf[j * 64 + owner] : 1.0;
+        double P = 1.0, H = 0.0;
+        {
+            const int n = yi < c.nr ? yi : c.nr;
+            double zz = c.r;
+            for (int i = 0; i < n; i++) {  // the same recurrence as the table of eval_point(), stopped at entry n
+                P *= zz;
+                H += rcp(zz);
+                zz += 1.0;
+            }
         }
+        const SampleVals v = sample_values(c, nfj, yi, P, H, lt);
+        const int e = j * R + grp;
+        s_x[e] = v.wj;
+        s_x[256 + e] = v.pm;
+        s_x[512 + e] = v.tll;
+        s_x[768 + e] = v.tsd;
+        s_xe[e] = v.pe;
     }
-    const SampleVals v = sample_values(c, nfj, yi, P, H, lt);
-    // the five values of every sample pass through the wave's prefix-table area (idle in this layout), [value][lane]: each lane
-    // then reads its group's S samples — four samples' loads in flight at a time, same address within a group (a broadcast),
-    // neighbouring banks across groups — and folds them in sample order.  (Round 2 fetched them with nine ds_bpermute per sample
-    // inside the fold loop: one LDS round trip per sample on the critical path of a tick that is all latency.)
-    s_x[lane] = v.wj;
-    s_x[64 + lane] = v.pm;
-    s_x[128 + lane] = v.tll;
-    s_x[192 + lane] = v.tsd;
-    reinterpret_cast<int *>(s_x + 256)[lane] = v.pe;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     Acc acc;
-    const int base = grp << lg;
     for (int j0 = 0; j0 < S; j0 += 4) {
         SampleVals u[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int src = base + (j0 + t < S ? j0 + t : j0);
+            const int src = (j0 + t < S ? j0 + t : j0) * R + grp;
             u[t].wj = s_x[src];
-            u[t].pm = s_x[64 + src];
-            u[t].tll = s_x[128 + src];
-            u[t].tsd = s_x[192 + src];
-            u[t].pe = reinterpret_cast<const int *>(s_x + 256)[src];
+            u[t].pm = s_x[256 + src];
+            u[t].tll = s_x[512 + src];
+            u[t].tsd = s_x[768 + src];
+            u[t].pe = s_xe[src];
         }
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -823,6 +830,15 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         double l_new = 0, dl_new = 0, alpha_new = 0;
         const bool active = phase != PH_DONE && phase != PH_NEED;
         const unsigned long long actmask = __ballot(active);
+        // samples-across-lanes layout for this tick: the most lanes per row that still hold every live row (S = 8: eight lanes
+        // for up to 8 rows, four for up to 16, two for up to 32); -1 = row per lane
+        int lg_t = -1;
+        if (burst_owner < 0 && queue_empty && spread_lg >= 0) {
+            const int nact = __popcll(actmask), lg_min = spread_lg - 2 > 1 ? spread_lg - 2 : 1;
+            lg_t = spread_lg;
+            while (lg_t >= lg_min && (nact << lg_t) > 64) lg_t--;
+            if (lg_t < lg_min) lg_t = -1;
+        }
         DIAG({
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             if (tk_kind == 0) cy_row += now - cy_last; else if (tk_kind == 1) cy_spread += now - cy_last; else if (tk_kind == 2) cy_burst += now - cy_last;
@@ -831,12 +847,12 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             tk_kind = -1;
             if (queue_empty) {
                 if (burst_owner >= 0) { tk_burst++; tk_kind = 2; }
-                else if (spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) { tk_spread++; tk_kind = 1; }
+                else if (lg_t >= 0) { tk_spread++; tk_kind = 1; }
                 else { tk_row++; tk_kind = 0; }
             }
         })
-        if (burst_owner < 0 && queue_empty && spread_lg >= 0 && (__popcll(actmask) << spread_lg) <= 64) {
-            eval_point_spread(s_nf, s_y, s_tab, lane, S, spread_lg, gmask, p2, actmask, active, a_eval, MAP,
+        if (lg_t >= 0) {
+            eval_point_spread(s_nf, s_y, s_tab, lane, S, lg_t, gmask, p2, actmask, active, a_eval, MAP,
                               prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab);
         } else if (active || helper) {
             eval_point(s_nf, s_y, s_tab, lane, slot, S, gmask, p2, a_eval, MAP, pm_e, prior_isig, l_new,
