@@ -639,13 +639,16 @@ void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWor
     while (threads > 64 && lds_per_wave * (threads / 64) > 40 * 1024) threads >>= 1;
     const size_t lds = lds_per_wave * (threads / 64);
     int64_t blocks = ((d.n + 63) / 64 + threads / 64 - 1) / (threads / 64);
-    const int64_t per_cu = (int64_t)(160 * 1024 / lds) < 8 ? (int64_t)(160 * 1024 / lds) : 8;
+    int64_t per_cu = (int64_t)(160 * 1024 / lds) < 8 ? (int64_t)(160 * 1024 / lds) : 8;
+    const int64_t by_regs = 4 * WALD_MINW / (threads / 64);  // workgroups per CU the registers allow (WALD_MINW waves per SIMD)
+    if (per_cu > by_regs) per_cu = by_regs;                   // one resident round: a workgroup that starts late finds the queue empty
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     if (blocks < 1) blocks = 1;
-    // IRLS rows are short and alike (median 3 iterations), so large chunks cost no balance and spare the refill its
-    // chunk-boundary retries: about one chunk per wave for big fits (0.60 -> 0.50 ms at 2 M x 8), 64 rows for small ones
+    // Chunk = rows a wave takes from the queue per atomic.  Small chunks balance the waves' ends, but the queue's head is one hot
+    // word (~90 dequeues per us): measured at 2 M x 8 on the one-round grid — 64 rows 0.49 ms, 96 0.42, 128 0.40, 256 0.44, 512 0.61
+    // (S = 4: 0.47 / 0.36 / 0.33 / 0.33 / 0.48; S = 16: 0.59 / 0.59 / 0.57 / 0.65); 64 for small fits (few chunks per wave)
     const int64_t per_wave = d.n / (blocks * (threads / 64));
-    A.chunk = per_wave >= 192 ? 256 : (per_wave >= 96 ? 128 : 64);
+    A.chunk = per_wave >= 96 ? 128 : 64;
     wald_irls_kernel<<<(unsigned)blocks, threads, lds, st>>>(A);
 }
 void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
