@@ -404,7 +404,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
     const size_t selcnt = align256(sizeof(double) * (size_t)kSelMaxWorld * kMaxS * 2);
     const size_t rowpack = align256((size_t)row_stride(S) * (size_t)n);
-    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + 2 * hist + selcnt + align256(sizeof(FitScalars)) + 256 + 1024 + nfbytes + rowpack;
+    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + 2 * hist + selcnt + align256(sizeof(FitScalars)) + kQueueBytes + 1024 + nfbytes + rowpack;
     hipError_t e = hipMalloc(&c->ws, total);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "workspace of %zu bytes: %s", total, hipGetErrorString(e));
     c->ws_bytes = total;
@@ -424,7 +424,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     w.selcnt = (double *)p; p += selcnt;
     w.sc = (FitScalars *)p; p += align256(sizeof(FitScalars));
     w.logfact = c->d_logfact;
-    w.queue = (unsigned long long *)p; p += 256;
+    w.queue = (unsigned long long *)p; p += kQueueBytes;
     w.barrier = (unsigned int *)p; p += 1024;
     c->d_nf_tmp = (double *)p; p += nfbytes;
     w.rowpack = p;
@@ -814,7 +814,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     FitWork &w = c->w;
     c->tg_total = 0;
     // the scalars, the queue heads and the barrier counters sit next to each other in the workspace: one fill
-    HIPCHK(c, hipMemsetAsync(w.sc, 0, align256(sizeof(FitScalars)) + 256 + 1024, st));
+    HIPCHK(c, hipMemsetAsync(w.sc, 0, align256(sizeof(FitScalars)) + kQueueBytes + 1024, st));
     {
         Scope t(c, "prep");
         launch_prep(d_counts, d_nf, d, w, o, st);

@@ -161,9 +161,17 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
     const uint64_t gmask = A.d.gmask;
     const Opts o = A.o;
     const double lambda = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
-    unsigned long long *queue = A.w.queue + 2;
     const int32_t *__restrict__ order = A.order;
     const unsigned long long nTot = order ? (unsigned long long)A.w.sc->ord_n : (unsigned long long)n;
+    // Eight queue heads, 64 bytes apart: chunk c = 8 k + h is the k-th chunk taken from head h.  One head is one hot word
+    // (~90 dequeues per us for the whole GPU) and an IRLS row lasts ~6 us, which had forced chunks of 128 rows; eight heads
+    // take 64-row chunks without queueing up, and the waves' ends balance better.  A wave starts at the head of its XCD
+    // (workgroups are dealt round-robin) and moves on when a head runs dry; the schedule's slow-first order holds up to that interleaving.
+    unsigned long long *heads = A.w.queue + 32;
+    int cur_head = blockIdx.x & 7;
+    unsigned int heads_left = 0xffu;
+    const unsigned long long nchunks = (nTot + (unsigned long long)A.chunk - 1ull) / (unsigned long long)A.chunk;
+
     int spread_lg = A.spread ? 1 : -1;  // log2(lanes per row) of the samples-across-lanes layout; -1 = never
     while (spread_lg >= 0 && (1 << spread_lg) < S) spread_lg++;
 
@@ -182,13 +190,23 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                     if (need) done = true;
                     break;
                 }
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(queue, (unsigned long long)A.chunk);
-                b = __shfl(b, 0);
-                if (b >= nTot) {
+                if (heads_left == 0u) {
                     queue_empty = true;
                     continue;
                 }
+                unsigned long long kq = 0;
+                if (lane == 0) kq = atomicAdd(heads + 8 * cur_head, 1ull);
+                kq = __shfl(kq, 0);
+                const unsigned long long cq = kq * 8ull + (unsigned long long)cur_head;
+                if (cq >= nchunks) {  // this head is dry: on to the next one that is not known to be (uses up one attempt)
+                    heads_left &= ~(1u << cur_head);
+                    for (int t = 1; t <= 8; t++) {
+                        const int hn = (cur_head + t) & 7;
+                        if (heads_left & (1u << hn)) { cur_head = hn; break; }
+                    }
+                    continue;
+                }
+                const unsigned long long b = cq * (unsigned long long)A.chunk;
                 chunk_next = b;
                 chunk_end = b + A.chunk < nTot ? b + A.chunk : nTot;
             }
@@ -644,11 +662,12 @@ void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWor
     if (per_cu > by_regs) per_cu = by_regs;                   // one resident round: a workgroup that starts late finds the queue empty
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     if (blocks < 1) blocks = 1;
-    // Chunk = rows a wave takes from the queue per atomic.  Small chunks balance the waves' ends, but the queue's head is one hot
-    // word (~90 dequeues per us): measured at 2 M x 8 on the one-round grid — 64 rows 0.49 ms, 96 0.42, 128 0.40, 256 0.44, 512 0.61
-    // (S = 4: 0.47 / 0.36 / 0.33 / 0.33 / 0.48; S = 16: 0.59 / 0.59 / 0.57 / 0.65); 64 for small fits (few chunks per wave)
+    // Chunk = rows a wave takes from a queue head per atomic.  Small chunks balance the waves' ends but cost refill retries at
+    // their boundaries (and, on ONE head, queue up: ~90 dequeues per us for the whole GPU — 64 / 96 / 128 / 256 / 512 rows:
+    // 0.49 / 0.42 / 0.40 / 0.44 / 0.61 ms at 2 M x 8).  On the eight heads of the kernel: 32 / 64 / 128 rows 0.455 / 0.410 /
+    // 0.377 ms at 2 M x 8 (S = 4: 0.37 / 0.34 / 0.32; S = 16: - / 0.56 / 0.54), 500 k x 8: 0.217 / 0.195 / 0.210
     const int64_t per_wave = d.n / (blocks * (threads / 64));
-    A.chunk = per_wave >= 96 ? 128 : 64;
+    A.chunk = per_wave >= 256 ? 128 : 64;
     wald_irls_kernel<<<(unsigned)blocks, threads, lds, st>>>(A);
 }
 void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
