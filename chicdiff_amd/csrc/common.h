@@ -31,13 +31,13 @@ struct FitWork {
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
     double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut
     double *selcnt;               // kSelMaxWorld x kMaxS*2 doubles: per-rank candidate counts
-    unsigned long long *queue;    // work-queue heads (kQueueBytes): [0] gene-wise, [1] MAP, [8..15] spare, [32 + 8 h] the IRLS's eight heads, 64 bytes apart
+    unsigned long long *queue;    // work-queue heads (kQueueBytes): [0] gene-wise, [1] MAP, [8..15] spare, [32 + 8 h] the IRLS's eight heads, 64 bytes apart, [192 + 8 h] the MAP line search's
     unsigned int *barrier;        // 9 x 64 B: grid-barrier counters of the persistent trend kernel
     FitScalars *sc;
     const double *logfact;        // log(k!) for k < kLogFactN
 };
 constexpr int kLogFactN = 1024;
-constexpr int kQueueBytes = 1024;  // FitWork::queue
+constexpr int kQueueBytes = 2048;  // FitWork::queue
 // bytes between rows of FitWork::rowpack: 12 S rounded up so that a row never straddles more 128-byte lines than it must
 constexpr int kRowHdr = 32;  // four doubles in front of every row: what the kernel that visits the rows next needs besides the data —
                              // gene-wise search: group mean A, group mean B, alpha_init, log alpha_init; MAP search: the means, start
