@@ -343,6 +343,8 @@ typedef struct {
     int32_t launches;
 } chicdiff_kernel_time;
 int32_t chicdiff_hip_kernel_times(chicdiff_hip_ctx *ctx, chicdiff_kernel_time *out, int32_t cap);
+/* on: 0 = off, 1 = every stage of a call gets an event pair, 2 = only the three fit kernels (disp_gene, disp_map, wald_irls):
+ * an event pair costs ~2 us on the stream and again on the host, 0.09 ms per fit with all ~20 stages bracketed */
 int chicdiff_hip_enable_timing(chicdiff_hip_ctx *ctx, int32_t on);
 
 #ifdef __cplusplus
