@@ -914,6 +914,33 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
         assert np.array_equal(a[k], e[k], equal_nan=True), f"{k}: schedules differ in {np.sum(~((a[k] == e[k]) | (np.isnan(a[k]) & np.isnan(e[k]))))} rows"
 
 
+def test_kernel_timing_modes(ctx):
+    """chicdiff_hip_enable_timing: 1 brackets every stage of a call with HIP events, 2 only the three fit kernels (what bench.py's
+    timed region uses), 0 nothing; the results do not depend on it."""
+    d = synth.make(20000, 8)
+    dk = ctx.to_device(d["counts"], np.int32)
+    dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / 8), np.float64)
+    want = ["dispersion", "pvalue"]
+    try:
+        ctx.enable_timing(1)
+        a, _ = ctx.wald_test(dk, dfm, d["group"], theta=0.5, want=want)
+        full = ctx.kernel_times()
+        ctx.enable_timing(2)
+        b, _ = ctx.wald_test(dk, dfm, d["group"], theta=0.5, want=want)
+        fit = ctx.kernel_times()
+    finally:
+        ctx.enable_timing(0)
+    c, _ = ctx.wald_test(dk, dfm, d["group"], theta=0.5, want=want)
+    for name in ("size_factors", "offsets", "prep", "disp_gene", "trend_fit", "mad_select", "disp_map", "wald_prep", "wald_irls", "wald_final"):
+        assert name in full and full[name][0] > 0 and full[name][1] == 1, name
+    timed = {k for k, (ms, launches) in fit.items() if launches > 0}
+    assert timed == {"disp_gene", "disp_map", "wald_irls"}, timed
+    assert all(fit[k][0] > 0 for k in timed)
+    for k in want:
+        assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=True)
+        assert np.array_equal(a[k].cpu().numpy(), c[k].cpu().numpy(), equal_nan=True)
+
+
 def test_bh_on_device(ctx, oracle):
     """f1/f3: p.adjust(p, "BH") — device sort + suffix minimum against the oracle; NA, ties, p = 0/1, n = 1."""
     import torch
