@@ -192,20 +192,39 @@ def main():
     collectives, comm_ranks = "none (single rank)", 1
     if dist is not None:
         comm_ranks = dist.get_world_size()
-        try:  # the library's own RCCL communicator: ncclAllReduce issued from C++ on the fit's stream
+        # A rank that cannot bring its communicator up must end the job, not leave its peers waiting inside ncclCommInitRank:
+        # init_rccl() decides collectively (every rank raises or none does), and a watchdog ends THIS process with a non-zero
+        # code if the whole attempt does not return in time — torch.distributed.run then tears the other ranks down.
+        import threading
+        limit = float(os.environ.get("CHICDIFF_RCCL_INIT_TIMEOUT", "300"))
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(limit):
+                print(f"rank {rank}: communicator setup did not finish within {limit:.0f} s — giving up (exit 3)", file=sys.stderr, flush=True)
+                os._exit(3)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:  # the library's own RCCL communicator: ncclAllReduce / ncclAllGather issued from C++ on the fit's stream
             if share_gpu:
                 raise RuntimeError("CHICDIFF_BENCH_SHARE_GPU=1: RCCL refuses two ranks on one device")
             if os.environ.get("CHICDIFF_BENCH_COLLECTIVES") == "torch":
                 raise RuntimeError("CHICDIFF_BENCH_COLLECTIVES=torch")
             ctx.init_rccl()
-            collectives = "RCCL, called by the library (ncclAllReduce on device buffers)"
-        except Exception as e:  # same protocol through torch.distributed (one Python callback per collective)
-            if rank == 0:
-                print(f"direct RCCL unavailable ({e}); using the torch.distributed hook", file=sys.stderr)
+            collectives = "RCCL, called by the library (ncclAllReduce / ncclAllGather on device buffers)"
+        except Exception as e:  # same protocol through torch.distributed (one Python callback per collective) — on EVERY rank: the verdict is collective
+            print(f"rank {rank}: direct RCCL unavailable ({e}); using the torch.distributed hook", file=sys.stderr, flush=True)
+            if os.environ.get("CHICDIFF_BENCH_COLLECTIVES") == "rccl":  # asked for the direct path only: fail loudly, every rank alike
+                done.set()
+                dist.destroy_process_group()
+                raise SystemExit(4)
             ctx.set_process_group(memory="device_via_host" if share_gpu else "device")
-            collectives = ("gloo through torch.distributed.all_reduce, device buffers staged through the host (one-GPU rehearsal)" if share_gpu
-                           else "RCCL through torch.distributed.all_reduce (host callback)")
-    want = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue"]
+            collectives = ("gloo through torch.distributed, device buffers staged through the host (one-GPU rehearsal)" if share_gpu
+                           else "RCCL through torch.distributed.all_reduce / all_gather_into_tensor (host callback)")
+        done.set()
+    # the six result columns of SURVEY.md 8d plus what nbinomWaldTest always computes and results() reads for a 4v4 design:
+    # Cook's distances (chicdiff.R:1674, 1739) — inside the timed step since round 4
+    want = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue", "maxCooks", "cooksArgmax"]
 
     def barrier():
         if dist is not None:
@@ -247,16 +266,18 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        kfull = {}
+        kfull, coll = {}, {}
         if breakdown:  # the same K steps again, every stage and every collective bracketed (not part of `value`)
             ctx.enable_timing(1)
             for _ in range(args.steps):
                 step()
                 for k, (ms, cnt) in ctx.kernel_times().items():
                     a = kfull.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
+                for k, (cnt, ms, nbytes) in ctx.collective_stats().items():
+                    a = coll.setdefault(k, [0, 0.0, 0.0]); a[0] += cnt; a[1] += ms; a[2] += nbytes
             ctx.enable_timing(False)
             barrier()
-        return dict(elapsed=elapsed, n=n, n_global=n_global, ktimes=ktimes, kfull=kfull, sc=sc, d=d, dk=dk, dfm=dfm, group=group)
+        return dict(elapsed=elapsed, n=n, n_global=n_global, ktimes=ktimes, kfull=kfull, coll=coll, sc=sc, d=d, dk=dk, dfm=dfm, group=group)
 
     m = measure(args.scaling)
     elapsed, n, n_global, ktimes, kfull, sc, d, dk, dfm, group = (m[k] for k in ("elapsed", "n", "n_global", "ktimes", "kfull", "sc", "d", "dk", "dfm", "group"))
@@ -289,12 +310,22 @@ def main():
                         valu["valu_busy_fraction"] = round(ent["valu"]["SQ_ACTIVE_INST_VALU"] * 4 / (avg_ms * 1e-3 * 1024 * 2.4e9), 3)
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    # per-collective figures of one step on EVERY rank: a slow link or a straggling rank shows as one rank's stream time
+    my_coll = {k: {"count": v[0] // args.steps, "ms": round(v[1] / args.steps, 4), "bytes": int(v[2] / args.steps)} for k, v in m["coll"].items()}
+    coll_all = [my_coll]
+    if dist is not None:
+        print(f"rank {rank}: rows {n}, step {ms_per_step:.3f} ms (max over ranks), collectives per step {json.dumps(my_coll)}, refits {ctx.last_refits()}", file=sys.stderr, flush=True)
+        coll_all = [None] * world
+        dist.all_gather_object(coll_all, my_coll)
+    valu_busy = valu.get("valu_busy_fraction") if valu else None
+    roofline = {"bound": "valu", "valu_busy": valu_busy, "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "frac_of_measured_stream_6290": round(achieved / 6290.0, 5), "valu": valu,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "fit kernels are fp64-VALU/transcendental bound (~4e4 flop per interaction), not HBM bound; "
-                        "see kernels_ms for the whole step"}
+                "note": "the fit kernels are bound by fp64 VALU issue (~4e4 flop per interaction), hence bound = 'valu' and valu_busy = fraction of the "
+                        "launch the SIMDs spend executing VALU instructions (SQ_ACTIVE_INST_VALU x 4 cycles / (duration x 1024 SIMDs x 2.4 GHz), "
+                        "replayed from profiles/pmc_traffic.json: counters cannot be read inside a timed run); achieved / peak / frac stay the HBM "
+                        "figures BASELINE.json's north_star asks for (algorithmic bytes / launch duration against 8 TB/s)"}
     result = {
         "metric": "interactions/sec NB-GLM Wald test", "value": round(value, 1), "unit": "interactions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -309,6 +340,8 @@ def main():
         "collectives_per_step": ({"count": kfull["allreduce"][1] // args.steps, "ms": round(kfull["allreduce"][0] / args.steps, 4),
                                   "note": "sum-all-reduces of one fit on this rank and their summed duration on the stream (already inside the stages' kernels_ms)"}
                                  if "allreduce" in kfull else None),
+        "collectives_per_rank": coll_all if dist is not None else None,
+        "timed_outputs": want,
         "fit_status": int(sc["status"]),
     }
     if world > 1 and not args.one_mode:

@@ -36,6 +36,7 @@ struct KTimer {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     double ms = 0;
     int launches = 0;
+    double bytes = 0;  // collectives: payload this rank handed to the transport
 };
 
 struct chicdiff_hip_ctx {
@@ -54,6 +55,14 @@ struct chicdiff_hip_ctx {
     int32_t *tg_flags = nullptr;
     int32_t *h_flag = nullptr;  // pinned: sel_overflow of the size-factor select (read with the call's last synchronisation)
     int opt_no_local_substitute = 0;  // 1: a failed parametric trend is reported (CHICDIFF_ST_TREND_FAILED), not replaced by the local fit
+    // test hook (option "fault_inject", one-shot bits, consumed by the next call that reaches the step): 1 = this rank's fit reports a
+    // select candidate-list overflow, 2 = this rank's persistent trend kernel reports a grid-barrier timeout, 4 = this rank's
+    // size-factor select reports an overflow.  Each verdict is all-reduced, so every rank of a sharded fit must re-enter together.
+    int opt_trend_blocks = 0;  // persistent trend kernel: cap on its workgroups (0 = one per CU)
+    int opt_fault = 0;
+    int refits = 0;               // refits the last call went through (select overflow / barrier timeout / local substitute), for the tests
+    bool sf_overflow_seen = false;  // fit_dev_impl: some rank's size-factor select (run by the caller just before) overflowed
+    int32_t *d_carry = nullptr;   // device word that survives the fit's clearing of its scalars: sel_overflow of the size-factor select
     // host-buffer entry point: device arena + pinned staging, both grow-only (no allocation per call once warm)
     char *io_dev = nullptr, *io_pin = nullptr;
     size_t io_dev_bytes = 0, io_pin_bytes = 0;
@@ -75,10 +84,13 @@ struct chicdiff_hip_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     chicdiff_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
+    chicdiff_allgather_fn allgather = nullptr;  // optional: without it the trend rows are gathered by a sum-all-reduce over zero-filled arrays
+    void *allgather_user = nullptr;
     int world = 1, rank = 0;
     // direct RCCL path (chicdiff_hip_rccl_init): librccl is dlopen'ed, never linked
     void *rccl_lib = nullptr, *rccl_comm = nullptr;
     int (*rccl_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*rccl_allgather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*rccl_comm_destroy)(void *) = nullptr;
     const char *(*rccl_error_string)(int) = nullptr;
     char err[512] = {0};
@@ -164,6 +176,8 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     else if (k == "host_copy_threads" && value >= 1 && value <= 64) c->opt_host_threads = (int)value;
     else if (k == "select_all_rounds" && (value == 0 || value == 1)) c->opt_select_rounds = (int)value;
     else if (k == "trend_one_launch_per_pass" && (value == 0 || value == 1)) c->opt_trend_multilaunch = (int)value;
+    else if (k == "fault_inject" && value >= 0 && value <= 7) c->opt_fault = (int)value;
+    else if (k == "trend_persistent_blocks" && value >= 0 && value <= 256) c->opt_trend_blocks = (int)value;
     else return fail(c, CHICDIFF_E_INVALID, "set_option: unknown option or value (%s = %lld)", name, (long long)value);
     return CHICDIFF_OK;
 }
@@ -182,7 +196,8 @@ int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_sc, sizeof(FitScalars))) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_sf, sizeof(double) * (kMaxS + 1))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_sf, sizeof(double) * (kMaxS + 1 + kSelMaxWorld))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_sf, sizeof(double) * (kMaxS + 1 + kSelMaxWorld + 8))) != hipSuccess ||
+        (e = hipMemset(c->d_sf, 0, sizeof(double) * (kMaxS + 1 + kSelMaxWorld + 8))) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_logfact, sizeof(double) * kLogFactN)) != hipSuccess) {
         fail(nullptr, CHICDIFF_E_HIP, "context setup: %s", hipGetErrorString(e));
         delete c;
@@ -201,6 +216,7 @@ int chicdiff_hip_create(chicdiff_hip_ctx **out, int32_t device) {
             return CHICDIFF_E_HIP;
         }
     }
+    c->d_carry = reinterpret_cast<int32_t *>(c->d_sf + kMaxS + 1 + kSelMaxWorld);  // (zeroed above)
     c->stream = c->own_stream;
     *out = c;
     return CHICDIFF_OK;
@@ -244,10 +260,22 @@ int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *c, chicdiff_allreduce_fn fn, vo
         return fail(c, CHICDIFF_E_INVALID, "set_allreduce: bad arguments");
     c->allreduce = fn;
     c->allreduce_user = user;
+    c->allgather = nullptr;  // belongs to the transport that was replaced; set it again with chicdiff_hip_set_allgather
+    c->allgather_user = nullptr;
     c->world = world;
     c->rank = rank;
     return CHICDIFF_OK;
 }
+
+int chicdiff_hip_set_allgather(chicdiff_hip_ctx *c, chicdiff_allgather_fn fn, void *user) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (fn && !c->allreduce) return fail(c, CHICDIFF_E_INVALID, "set_allgather: register the all-reduce of the same transport first");
+    c->allgather = fn;
+    c->allgather_user = user;
+    return CHICDIFF_OK;
+}
+
+int32_t chicdiff_hip_last_refits(const chicdiff_hip_ctx *c) { return c ? c->refits : 0; }
 
 // ---- direct RCCL: the library calls ncclAllReduce itself on its own stream (no host callback per collective) ----
 struct RcclUniqueId { char internal[128]; };  // NCCL_UNIQUE_ID_BYTES
@@ -263,6 +291,15 @@ static int rccl_allreduce_cb(void *user, void *dev_buf, int64_t count) {
     const int r = c->rccl_allreduce(dev_buf, dev_buf, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->rccl_comm, c->stream);
     if (r != 0) {
         fail(c, CHICDIFF_E_COMM, "ncclAllReduce: %s", c->rccl_error_string ? c->rccl_error_string(r) : "error");
+        return 1;
+    }
+    return 0;
+}
+static int rccl_allgather_cb(void *user, const void *dev_send, void *dev_recv, int64_t count) {
+    chicdiff_hip_ctx *c = (chicdiff_hip_ctx *)user;
+    const int r = c->rccl_allgather(dev_send, dev_recv, (size_t)count, /*ncclFloat64*/ 8, c->rccl_comm, c->stream);
+    if (r != 0) {
+        fail(c, CHICDIFF_E_COMM, "ncclAllGather: %s", c->rccl_error_string ? c->rccl_error_string(r) : "error");
         return 1;
     }
     return 0;
@@ -284,6 +321,7 @@ int chicdiff_hip_rccl_init(chicdiff_hip_ctx *c, const char *librccl_path, const 
     HIPCHK(c, hipSetDevice(c->device));
     auto init = (int (*)(void **, int, RcclUniqueId, int))dlsym(c->rccl_lib, "ncclCommInitRank");
     c->rccl_allreduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(c->rccl_lib, "ncclAllReduce");
+    c->rccl_allgather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(c->rccl_lib, "ncclAllGather");
     c->rccl_comm_destroy = (int (*)(void *))dlsym(c->rccl_lib, "ncclCommDestroy");
     c->rccl_error_string = (const char *(*)(int))dlsym(c->rccl_lib, "ncclGetErrorString");
     if (!init || !c->rccl_allreduce || !c->rccl_comm_destroy) return fail(c, CHICDIFF_E_COMM, "librccl lacks ncclCommInitRank / ncclAllReduce / ncclCommDestroy");
@@ -300,6 +338,8 @@ int chicdiff_hip_rccl_init(chicdiff_hip_ctx *c, const char *librccl_path, const 
     }
     c->allreduce = rccl_allreduce_cb;
     c->allreduce_user = c;
+    c->allgather = c->rccl_allgather ? rccl_allgather_cb : nullptr;  // (a librccl without it: the sum-all-reduce way of gathering)
+    c->allgather_user = c;
     c->world = world;
     c->rank = rank;
     return CHICDIFF_OK;
@@ -359,6 +399,7 @@ static void timing_reset(chicdiff_hip_ctx *c) {
     for (auto &t : c->timers) {
         t.ms = 0;
         t.launches = 0;
+        t.bytes = 0;
     }
 }
 static void timing_collect(chicdiff_hip_ctx *c) {
@@ -384,6 +425,7 @@ extern "C" int32_t chicdiff_hip_kernel_times(chicdiff_hip_ctx *c, chicdiff_kerne
             out[k].name = t.name.c_str();
             out[k].ms = t.ms;
             out[k].launches = t.launches;
+            out[k].bytes = t.bytes;
         }
         k++;
     }
@@ -433,6 +475,9 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     w.rowpack = p;
     c->cap_n = n;
     c->cap_S = S;
+    // scalars, queue heads and barrier counters start from zero: size_factors_impl runs before any fit has cleared them, and a
+    // garbage sel_overflow there would send ONE rank of a sharded call into a second pass its peers do not make
+    HIPCHK(c, hipMemsetAsync(w.sc, 0, align256(sizeof(FitScalars)) + kQueueBytes + 1024, c->stream));
     return CHICDIFF_OK;
 }
 
@@ -450,22 +495,25 @@ static int ensure_aux(chicdiff_hip_ctx *c, size_t bytes) {
     return CHICDIFF_OK;
 }
 
-static int do_allreduce(chicdiff_hip_ctx *c, double *dev, int64_t count) {
-    if (!c->allreduce) return CHICDIFF_OK;  // a callback registered with world_size 1 is still called (tests)
-    // with timing on, every collective gets an event pair of its own, whatever scope it sits in: "allreduce" in
-    // chicdiff_hip_kernel_times = number of collectives of the call and their summed duration on the stream (that time is ALSO
-    // inside the enclosing scope's figure — size_factors, trend_fit, mad_select — so it is a breakdown, not an extra term)
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+// with timing on (mode 1), every collective gets an event pair of its own, whatever scope it sits in: "allreduce" / "allgather" in
+// chicdiff_hip_kernel_times = number of collectives of the call, their summed duration on the stream and the bytes this rank
+// handed over (that time is ALSO inside the enclosing scope's figure — size_factors, trend_fit, mad_select — so it is a
+// breakdown, not an extra term)
+struct CollTimer {
+    chicdiff_hip_ctx *c;
     int idx = -1;
-    if (c->timing == 1) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    CollTimer(chicdiff_hip_ctx *c_, const char *name, double bytes) : c(c_) {
+        if (c->timing != 1) return;
         for (size_t i = 0; i < c->timers.size(); i++)
-            if (c->timers[i].name == "allreduce") idx = (int)i;
+            if (c->timers[i].name == name) idx = (int)i;
         if (idx < 0) {
             KTimer t;
-            t.name = "allreduce";
+            t.name = name;
             c->timers.push_back(t);
             idx = (int)c->timers.size() - 1;
         }
+        c->timers[idx].bytes += bytes;
         auto take = [&]() {
             hipEvent_t e = nullptr;
             if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); } else (void)hipEventCreate(&e);
@@ -475,13 +523,32 @@ static int do_allreduce(chicdiff_hip_ctx *c, double *dev, int64_t count) {
         e1 = take();
         (void)hipEventRecord(e0, c->stream);
     }
-    const int rc = c->allreduce(c->allreduce_user, dev, count);
-    if (idx >= 0) {
+    ~CollTimer() {
+        if (idx < 0) return;
         (void)hipEventRecord(e1, c->stream);
         c->pending.push_back({idx, e0});
         c->pending.push_back({idx, e1});
     }
-    if (rc != 0) return fail(c, CHICDIFF_E_COMM, "all-reduce callback failed");
+};
+
+static int do_allreduce(chicdiff_hip_ctx *c, double *dev, int64_t count) {
+    if (!c->allreduce) return CHICDIFF_OK;  // a callback registered with world_size 1 is still called (tests)
+    int rc;
+    {
+        CollTimer t(c, "allreduce", 8.0 * (double)count);
+        rc = c->allreduce(c->allreduce_user, dev, count);
+    }
+    if (rc != 0) return c->err[0] && strstr(c->err, "nccl") ? CHICDIFF_E_COMM : fail(c, CHICDIFF_E_COMM, "all-reduce callback failed");
+    return CHICDIFF_OK;
+}
+// every rank contributes `count` doubles at `send`; `recv` gets world x count, rank r's block at r * count
+static int do_allgather(chicdiff_hip_ctx *c, const double *send, double *recv, int64_t count) {
+    int rc;
+    {
+        CollTimer t(c, "allgather", 8.0 * (double)count);
+        rc = c->allgather(c->allgather_user, send, recv, count);
+    }
+    if (rc != 0) return c->err[0] && strstr(c->err, "nccl") ? CHICDIFF_E_COMM : fail(c, CHICDIFF_E_COMM, "all-gather callback failed");
     return CHICDIFF_OK;
 }
 
@@ -640,6 +707,7 @@ static Opts make_opts(const chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *in, 
     r.min_waves = c->opt_min_waves;
     r.schedule = c->opt_schedule;
     r.deal = c->opt_deal;
+    r.trend_blocks = c->opt_trend_blocks;
     return r;
 }
 
@@ -756,10 +824,11 @@ static int local_trend_fit(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
 
 // Sharded fits: the parametric trend on ALL ranks' rows, on every rank.  The fit is ~20 dependent IRLS passes over two
 // doubles per row; sharding it costs one latency-bound all-reduce per pass (20 of a sharded fit's ~38 collectives), while
-// the rows themselves are small: 16 bytes each.  So the ranks exchange them once — their sizes (one all-reduce of `world`
-// doubles), then the rows (a sum-all-reduce over zero-initialised all-ranks arrays = an all-gather; 32 MB at 2 M rows) —
-// and each runs the single-launch persistent kernel on the whole set: two collectives instead of twenty, and the trend of
-// a sharded fit is bit-identical to the single-rank one (same rows, same order, same kernel).
+// the rows themselves are small: 16 bytes each.  So the ranks exchange them once — their sizes (with the argument verdicts),
+// then the rows: one all-gather of the ranks' padded (x | y) blocks (ncclAllGather, 32 MB received at 2 M rows), or, on a
+// transport without an all-gather hook, a sum-all-reduce over zero-initialised all-ranks arrays (twice the bytes) — and each
+// runs the single-launch persistent kernel on the whole set: one collective instead of twenty, and the trend of a sharded
+// fit is bit-identical to the single-rank one (same rows, same order, same kernel).
 static int gathered_trend(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
     hipStream_t st = c->stream;
     FitWork &w = c->w;
@@ -777,18 +846,24 @@ static int gathered_trend(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
         HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(double) * world, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
-    int64_t off = 0, total = 0;
+    int64_t off = 0, total = 0, maxn = 0;
     for (int r = 0; r < world; r++) {
         if (r < rank) off += (int64_t)cnt[(size_t)r];
         total += (int64_t)cnt[(size_t)r];
+        if ((int64_t)cnt[(size_t)r] > maxn) maxn = (int64_t)cnt[(size_t)r];
     }
+    // layout of the gather buffer: x[total], y[total], flags[total] (int32, zero), resid[total], then — all-gather transport —
+    // this rank's padded block (x[maxn] | y[maxn]) and the ranks' blocks as they arrive (world x 2 maxn)
+    const bool by_gather = c->allgather != nullptr && world <= kGatherMaxWorld;
     const size_t nd = align256(sizeof(double) * (size_t)total), ni = align256(sizeof(int32_t) * (size_t)total);
-    if (c->tg_bytes < 3 * nd + ni) {
+    const size_t blk = align256(sizeof(double) * 2 * (size_t)maxn);
+    const size_t need = 3 * nd + ni + (by_gather ? blk * (size_t)(world + 1) : 0);
+    if (c->tg_bytes < need) {
         if (c->tg_buf) { HIPCHK(c, hipStreamSynchronize(st)); HIPCHK(c, hipFree(c->tg_buf)); }
         c->tg_buf = nullptr;
         c->tg_bytes = 0;
-        HIPCHK(c, hipMalloc((void **)&c->tg_buf, 3 * nd + ni));
-        c->tg_bytes = 3 * nd + ni;
+        HIPCHK(c, hipMalloc((void **)&c->tg_buf, need));
+        c->tg_bytes = need;
     }
     double *xg = (double *)c->tg_buf, *yg = (double *)(c->tg_buf + nd);
     int32_t *flags = (int32_t *)(c->tg_buf + 2 * nd);
@@ -797,9 +872,26 @@ static int gathered_trend(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
     c->tg_y = yg;
     c->tg_flags = flags;
     c->tg_resid = (double *)(c->tg_buf + 2 * nd + ni);
-    HIPCHK(c, hipMemsetAsync(c->tg_buf, 0, 2 * nd + ni, st));
-    launch_trend_gather(d, w, o, xg + off, yg + off, st);
-    if ((rc = do_allreduce(c, xg, (int64_t)(2 * nd / sizeof(double))))) return rc;  // x and y are contiguous (padding included)
+    if (by_gather) {
+        // one ncclAllGather of the ranks' (x | y) blocks, padded to the largest shard, then a copy into the contiguous all-ranks
+        // arrays: half the bytes of the sum-all-reduce over zero-filled arrays it replaces, and no floating-point adds
+        double *send = (double *)(c->tg_buf + 3 * nd + ni), *recv = (double *)(c->tg_buf + 3 * nd + ni + blk);
+        HIPCHK(c, hipMemsetAsync(flags, 0, ni, st));
+        launch_trend_gather(d, w, o, send, send + maxn, st);
+        if ((rc = do_allgather(c, send, recv, (int64_t)(blk / sizeof(double))))) return rc;
+        GatherLayout gl{};
+        gl.world = world;
+        gl.block = (int64_t)(blk / sizeof(double));
+        gl.maxn = maxn;
+        int64_t o2 = 0;
+        for (int r = 0; r < world; r++) { gl.off[r] = o2; o2 += (int64_t)cnt[(size_t)r]; }
+        gl.off[world] = o2;
+        launch_trend_compact(gl, recv, xg, yg, st);
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->tg_buf, 0, 2 * nd + ni, st));
+        launch_trend_gather(d, w, o, xg + off, yg + off, st);
+        if ((rc = do_allreduce(c, xg, (int64_t)(2 * nd / sizeof(double))))) return rc;  // x and y are contiguous (padding included)
+    }
     FitDims dg = d;
     dg.n = total;
     FitWork wg = w;
@@ -818,13 +910,23 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     c->tg_total = 0;
     // the scalars, the queue heads and the barrier counters sit next to each other in the workspace: one fill
     HIPCHK(c, hipMemsetAsync(w.sc, 0, align256(sizeof(FitScalars)) + kQueueBytes + 1024, st));
+    // sharded: the column sums of nf travel as the ranks' double-double pairs (zero-filled slots + sum-all-reduce = an exact gather)
+    // and are added in rank order — the correctly rounded exact sum, as on one rank: same xim, same start values, same bits downstream
+    const int world = c->world > 0 ? c->world : 1;
+    const bool col_slots = c->allreduce && world <= kSelMaxWorld;
+    const size_t slot_doubles = (size_t)(d.S + 1) * 2;
+    double *slots = col_slots ? w.hist : nullptr;  // (the select histograms are idle here)
+    if (col_slots) HIPCHK(c, hipMemsetAsync(slots, 0, sizeof(double) * slot_doubles * world, st));
     {
         Scope t(c, "prep");
         launch_prep(d_counts, d_nf, d, w, o, st);
-        launch_prep_finish(d, w, st);
+        launch_prep_finish(d, w, col_slots ? slots + slot_doubles * c->rank : nullptr, st);
     }
-    if ((rc = do_allreduce(c, w.sc->colsum, kMaxS + 1))) return rc;  // colsum[kMaxS] + nnz are contiguous
-    launch_xim(d, w, st);
+    if (col_slots) {
+        if ((rc = do_allreduce(c, slots, (int64_t)(slot_doubles * world)))) return rc;
+    } else if ((rc = do_allreduce(c, w.sc->colsum, kMaxS + 1)))  // colsum[kMaxS] + nnz are contiguous
+        return rc;
+    launch_xim(d, w, slots, world, st);
     {
         Scope t(c, "disp_gene");
         launch_disp_gene(d_counts, d_nf, d, w, o, st);
@@ -887,6 +989,10 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         if (trc == -1) return CHICDIFF_E_COMM;
         if (trc == -2) return fail(c, CHICDIFF_E_NUMERIC, "trend state machine did not finish");
     }
+    if (c->opt_fault & 2) {  // test hook: this rank's trend kernel "lost its grid barrier"
+        c->opt_fault &= ~2;
+        launch_poke(&w.sc->failed, 3, st);
+    }
     int status = 0;
     const bool prior_by_simulation = !(o.dispPriorVarIn == o.dispPriorVarIn) && d.S - d.p <= 3 && d.S > d.p;
     // MAD of the log residuals.  A sharded fit that gathered the trend's rows has every rank's (baseMean, dispGeneEst) on this
@@ -930,6 +1036,10 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
             launch_prior_var(d, w, o, st);
         }
     }
+    if (c->opt_fault & 1) {  // test hook: this rank's select "could not fit its candidate list"
+        c->opt_fault &= ~1;
+        launch_poke(&w.sc->sel_overflow, 1, st);
+    }
     {
         Scope t(c, "disp_map");
         launch_disp_map(d_counts, d_nf, d, w, o, st);
@@ -960,8 +1070,10 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         Scope t(c, "wald_intercept");
         launch_wald_intercept(d_counts, d_nf, d, w, o, out, st);
     }
-    launch_dev_sum_finish(d, w, st);
-    if ((rc = do_allreduce(c, sums_of(w), 5))) return rc;  // deviance sum, non-converged rows, all-zero rows, ranks whose trend kernel timed out, ranks with a negative / NA count
+    launch_dev_sum_finish(d, w, c->d_carry, st);
+    // deviance sum, non-converged rows, all-zero rows, then four verdicts as rank counts: trend kernel timed out, negative / NA count,
+    // a select's candidate list overflowed in this fit, ... in the size-factor select the caller ran before it
+    if ((rc = do_allreduce(c, sums_of(w), 7))) return rc;
     // copy the per-row workspace columns the caller asked for
     const size_t nb = sizeof(double) * (size_t)d.n, ib = sizeof(int32_t) * (size_t)d.n;
 #define CPY(dst, src, bytes) \
@@ -971,7 +1083,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     CPY(dispGeneIter, w.geneIter, ib); CPY(dispIter, w.mapIter, ib); CPY(dispOutlier, w.outlier, ib);
     CPY(allZero, w.allZero, ib);
 #undef CPY
-    double hs[5];
+    double hs[7];
     HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(hs, sums_of(w), sizeof hs, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -981,23 +1093,30 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     if (hs[4] > 0)
         return fail(c, CHICDIFF_E_INVALID, c->h_sc->neg_counts ? "counts contain a negative value or NA_integer_"
                                                                : "counts contain a negative value or NA_integer_ (on another rank of the sharded fit)");
-    if (c->h_sc->sel_overflow && !c->opt_select_rounds) {  // a sharded select's candidate list did not fit (every rank sees the same flag)
+    // The verdicts below are sums over the ranks (hs[3..6]): whatever ONE rank saw, every rank takes the same branch and re-enters
+    // the fit together — none is left waiting in a collective its peers never issue.
+    c->sf_overflow_seen = hs[6] > 0;  // the caller (wald_test_dev) repeats size factors + fit with every histogram round
+    if (c->sf_overflow_seen && !c->opt_select_rounds) return CHICDIFF_OK;  // (results of this pass are discarded there)
+    if (hs[5] > 0 && !c->opt_select_rounds) {  // a sharded select's candidate list did not fit: every histogram round instead
         c->opt_select_rounds = 1;
+        c->refits++;
         rc = fit_dev_impl(c, d_counts, d_nf, d, o, d_out, scalars);
-        c->opt_select_rounds = 0;
+        c->opt_select_rounds = 0;  // (it was 0: checked above)
         return rc;
     }
-    if (c->h_sc->failed == 3 || hs[3] > 0) {  // (hs[3]: some rank of a sharded fit — every rank takes this branch together)
+    if (c->h_sc->failed == 3 || hs[3] > 0) {
         // the persistent trend kernel's workgroups were not all resident within the barrier's patience (a GPU shared
         // with other work): fit again with one launch per IRLS pass, and stay with that for this context
         if (c->no_persistent_trend) return fail(c, CHICDIFF_E_HIP, "trend fit: grid barrier timed out");
         c->no_persistent_trend = true;
+        c->refits++;
         return fit_dev_impl(c, d_counts, d_nf, d, o, d_out, scalars);
     }
     if (c->h_sc->failed && o.fit_type == 0 && !(o.trendIn[0] == o.trendIn[0]) && !c->opt_no_local_substitute) {
         // estimateDispersionsFit: the parametric fit failed -> fitType <- "local", and the fit is done again from the trend on
         // (everything before it is recomputed too: a rare path, kept simple)
         o.fit_type = 2;
+        c->refits++;
         return fit_dev_impl(c, d_counts, d_nf, d, o, d_out, scalars);
     }
     if (c->h_sc->failed) status |= CHICDIFF_ST_TREND_FAILED;
@@ -1028,10 +1147,12 @@ int chicdiff_hip_nbglm_fit_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
     FitDims d;
     int rc = (!d_counts || !d_nf) ? fail(c, CHICDIFF_E_INVALID, "counts / nf pointer is NULL") : check_counts_group(c, n, S, group, d);
     if (!rc) rc = check_opts(c, opts);
+    timing_reset(c);  // (before the verdicts' collective: it is one of the call's)
     if ((rc = shard_consensus(c, rc, n))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
-    timing_reset(c);
+    c->refits = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_carry, 0, sizeof(int32_t), c->stream));  // no size-factor select belongs to this call
     rc = fit_dev_impl(c, d_counts, d_nf, d, make_opts(c, opts, S), d_out, scalars);
     timing_collect(c);
     return rc;
@@ -1182,9 +1303,11 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const dou
     return CHICDIFF_OK;
 }
 
-// size factors -> c->d_sf (device) ; no host synchronisation
+// size factors -> c->d_sf (device) ; no host synchronisation.  The select's overflow verdict is left in c->d_carry (a device word
+// the fit does not clear), from where the fit's last all-reduce — or sf_overflow_consensus — makes it every rank's verdict.
 static int size_factors_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S) {
     Scope t(c, "size_factors");
+    HIPCHK(c, hipMemsetAsync(&c->w.sc->sel_overflow, 0, sizeof(int32_t), c->stream));  // (a fit clears it too, but none may have run yet)
     launch_row_ratio(d_counts, n, S, c->d_nf_tmp, c->stream);  // the offsets buffer is free until the size factors exist
     SelArgs sa{};
     sa.mode = SEL_SIZEFACTOR;
@@ -1193,29 +1316,56 @@ static int size_factors_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, int64
     sa.ratio = c->d_nf_tmp;
     sa.S = S;
     sa.sf_out = c->d_sf;  // the finishing step of the select writes the size factors there
-    return run_select(c, sa);
+    const int rc = run_select(c, sa);
+    if (rc) return rc;
+    if (c->opt_fault & 4) {  // test hook: this rank's size-factor select "could not fit its candidate list"
+        c->opt_fault &= ~4;
+        launch_poke(&c->w.sc->sel_overflow, 1, c->stream);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_carry, &c->w.sc->sel_overflow, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    return CHICDIFF_OK;
+}
+
+// did the size-factor select overflow on ANY rank?  (one 1-double sum-all-reduce when sharded; blocks)
+static int sf_overflow_consensus(chicdiff_hip_ctx *c, bool *overflow) {
+    double *d_flag = c->d_sf + kMaxS;  // spare doubles behind the size factors
+    launch_flag_to_double(c->d_carry, d_flag, c->stream);
+    int rc = do_allreduce(c, d_flag, 1);
+    if (rc) return rc;
+    double h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, d_flag, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *overflow = h > 0;
+    return CHICDIFF_OK;
 }
 
 int chicdiff_hip_size_factors_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S, double *sf_host) {
     if (!c) return CHICDIFF_E_INVALID;
     int rc = (!d_counts || !sf_host || n < 1 || S < 1 || S > kMaxS) ? fail(c, CHICDIFF_E_INVALID, "size_factors: bad arguments") : CHICDIFF_OK;
+    timing_reset(c);  // (before the verdicts' collective: it is one of the call's)
     if ((rc = shard_consensus(c, rc, n))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
-    timing_reset(c);
-    if ((rc = size_factors_impl(c, d_counts, n, S))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->h_sc, c->w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->h_sc->sel_overflow && !c->opt_select_rounds) {  // a candidate list of the sharded select did not fit: every histogram round instead
-        c->opt_select_rounds = 1;
-        HIPCHK(c, hipMemsetAsync(&c->w.sc->sel_overflow, 0, sizeof(int32_t), c->stream));
-        rc = size_factors_impl(c, d_counts, n, S);
-        c->opt_select_rounds = 0;
-        if (rc) return rc;
+    c->refits = 0;
+    const int saved_rounds = c->opt_select_rounds;
+    auto body = [&]() -> int {
+        for (int attempt = 0; attempt < 2; attempt++) {
+            int r = size_factors_impl(c, d_counts, n, S);
+            if (r) return r;
+            bool overflow = false;
+            if ((r = sf_overflow_consensus(c, &overflow))) return r;
+            if (!overflow || c->opt_select_rounds) break;
+            c->opt_select_rounds = 1;  // a candidate list of the sharded select did not fit on some rank: every histogram round instead
+            c->refits++;
+        }
         HIPCHK(c, hipMemcpyAsync(c->h_sc, c->w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
+        return CHICDIFF_OK;
+    };
+    rc = body();
+    c->opt_select_rounds = saved_rounds;  // whatever happened above, error returns included
     timing_collect(c);
+    if (rc) return rc;
     for (int j = 0; j < S; j++) {
         if (c->h_sc->sel_count[j] <= 0)
             return fail(c, CHICDIFF_E_NUMERIC, "every gene contains at least one zero, cannot compute log geometric means");
@@ -1233,27 +1383,33 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
     FitDims d;
     int rc = !d_counts ? fail(c, CHICDIFF_E_INVALID, "counts pointer is NULL") : check_counts_group(c, n, S, group, d);
     if (!rc) rc = check_opts(c, opts);
+    timing_reset(c);  // (before the verdicts' collective: it is one of the call's)
     if ((rc = shard_consensus(c, rc, n))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, n, S))) return rc;
-    timing_reset(c);
-    int32_t *h_overflow = reinterpret_cast<int32_t *>(c->h_sf + kMaxS);  // pinned
-    for (int attempt = 0; attempt < 2; attempt++) {
-        if ((rc = size_factors_impl(c, d_counts, n, S))) break;
-        const int mix = theta == theta;
-        {
-            Scope t(c, "offsets");
-            launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, c->d_nf_tmp, c->stream);
+    c->refits = 0;
+    const int saved_rounds = c->opt_select_rounds;  // restored below whatever happens (a user's "select_all_rounds" included)
+    auto body = [&]() -> int {
+        for (int attempt = 0; attempt < 2; attempt++) {
+            int r = size_factors_impl(c, d_counts, n, S);
+            if (r) return r;
+            const int mix = theta == theta;
+            {
+                Scope t(c, "offsets");
+                launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, c->d_nf_tmp, c->stream);
+            }
+            HIPCHK(c, hipMemcpyAsync(c->h_sf, c->d_sf, sizeof(double) * S, hipMemcpyDeviceToHost, c->stream));  // pinned: no stall
+            r = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(c, opts, S), d_out, scalars);  // ends with a stream sync
+            // the sharded size-factor select ran without a host look at its candidate lists: one that did not fit on ANY rank (massive
+            // ties) shows in the fit's last all-reduce, on every rank alike, and the call is repeated with every histogram round
+            if (r || !c->sf_overflow_seen || c->opt_select_rounds) return r;
+            c->opt_select_rounds = 1;
+            c->refits++;
         }
-        HIPCHK(c, hipMemcpyAsync(c->h_sf, c->d_sf, sizeof(double) * S, hipMemcpyDeviceToHost, c->stream));  // pinned: no stall
-        HIPCHK(c, hipMemcpyAsync(h_overflow, &c->w.sc->sel_overflow, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));  // (the fit clears the scalars next)
-        rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(c, opts, S), d_out, scalars);  // ends with a stream sync
-        // the sharded size-factor select ran without a host look at its candidate lists: one that did not fit (massive ties) shows
-        // now, on every rank alike, and the call is repeated with every histogram round
-        if (rc || !*h_overflow || c->opt_select_rounds) break;
-        c->opt_select_rounds = 1;
-    }
-    if (*h_overflow && c->opt_select_rounds) c->opt_select_rounds = 0;
+        return CHICDIFF_OK;
+    };
+    rc = body();
+    c->opt_select_rounds = saved_rounds;
     timing_collect(c);
     if (rc) return rc;
     for (int j = 0; j < S; j++) {
@@ -1333,6 +1489,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
     // (every rank must issue its collectives in the same order).
     const size_t ws_per_lane = sizeof(double) * (size_t)n * (22 + S) + (size_t)row_stride(S) * (size_t)n + (64u << 20);
     int lanes = c->allreduce ? 1 : (ntheta < c->opt_grid_lanes ? ntheta : c->opt_grid_lanes);
+    bool squeezed = false;  // the lanes' workspaces do not fit: their memory is given back before the thetas are fitted one after the other
     if (lanes > 1) {
         // the lanes' workspaces must fit what the device has free NOW (a shared GPU, the caller's own tensors, a smaller
         // part); lanes that already hold a workspace of this size cost nothing more
@@ -1340,21 +1497,31 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         int have = 0;
         for (chicdiff_hip_ctx *l : c->lanes) have += (l->cap_n >= n && l->cap_S >= S) ? 1 : 0;
-        while (lanes > 1 && lanes > have && (double)ws_per_lane * (lanes - have) > 0.9 * (double)free_b) lanes--;
+        while (lanes > 1 && lanes > have && (double)ws_per_lane * (lanes - have) > 0.9 * (double)free_b) {
+            lanes--;
+            squeezed = lanes <= 1;
+        }
     }
     while (lanes > 1 && (int)c->lanes.size() < lanes) {
         chicdiff_hip_ctx *l = nullptr;
-        if (chicdiff_hip_create(&l, c->device)) { lanes = 1; break; }
+        if (chicdiff_hip_create(&l, c->device)) { lanes = 1; squeezed = true; break; }
         c->lanes.push_back(l);
     }
     for (int k = 0; k < lanes && lanes > 1; k++)
-        if (ensure_workspace(c->lanes[k], n, S)) lanes = 1;  // no room after all: free the lanes, fit one theta after the other
+        if (ensure_workspace(c->lanes[k], n, S)) {  // no room after all
+            snprintf(c->err, sizeof c->err, "theta_grid: concurrent fits given up (%s)", c->lanes[k]->err);  // kept for the caller's log; the call goes on
+            lanes = 1;
+            squeezed = true;
+        }
     if (lanes <= 1) {
-        if (!c->allreduce && !c->lanes.empty()) {
+        // (a caller who simply asked for one lane — ntheta == 1, theta_grid_concurrency 1 — keeps the cached lanes: re-creating
+        // them costs streams, GBs of hipMalloc and event-pool warm-up on the next multi-theta call)
+        if (squeezed && !c->lanes.empty()) {
             for (chicdiff_hip_ctx *l : c->lanes) chicdiff_hip_destroy(l);
             c->lanes.clear();
         }
         if ((rc = ensure_workspace(c, n, S))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->d_carry, 0, sizeof(int32_t), c->stream));  // no size-factor select belongs to this call
         HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
         for (int t = 0; t < ntheta; t++) {
             {
@@ -1383,6 +1550,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         l->opt_trend_gather = c->opt_trend_gather;
         l->opt_select_rounds = c->opt_select_rounds;
         l->opt_trend_multilaunch = c->opt_trend_multilaunch;
+        l->opt_trend_blocks = c->opt_trend_blocks;
         l->no_persistent_trend = true;  // a grid barrier needs its workgroups co-resident: not guaranteed beside other fits
         workers.emplace_back([=, &lane_rc]() {
             int r = CHICDIFF_OK;

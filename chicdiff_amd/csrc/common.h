@@ -57,6 +57,7 @@ struct Opts {
     int32_t min_waves = 2;  // line search: waves per SIMD the kernel variant is built for
     int32_t schedule = 1;   // gene-wise line search / IRLS: visit the rows likely-long first (0 = natural order; 2 = class order through the queue only)
     int32_t deal = 0;       // ... entries per group of its static deal (0 = chosen from the number of entries per wave)
+    int32_t trend_blocks = 0;  // persistent trend kernel: at most this many workgroups (0 = one per CU); option "trend_persistent_blocks"
 };
 
 // one row of FitWork::rowpack -> the wave's LDS slice ([sample][lane]); 16-byte loads when S is a multiple of four
@@ -88,8 +89,8 @@ __device__ __forceinline__ void load_row(const char *rowpack, int64_t r, int S, 
 
 // ---- launchers (defined in the .hip files; all enqueue on `st` and never synchronise) -------
 void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
-void launch_prep_finish(FitDims d, FitWork w, hipStream_t st);          // partials -> colsum,nnz
-void launch_xim(FitDims d, FitWork w, hipStream_t st);                  // colsum -> xim
+void launch_prep_finish(FitDims d, FitWork w, double *slot, hipStream_t st);  // partials -> colsum, nnz (slot: as (hi, lo) pairs into this rank's slot instead)
+void launch_xim(FitDims d, FitWork w, const double *slots, int world, hipStream_t st);  // (the ranks' slots ->) colsum -> xim
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_order_build(FitDims d, FitWork w, int classesA, bool have_hist, hipStream_t st);  // w.cls -> w.order (schedule of a row-queue kernel)
 void launch_disp_map(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
@@ -105,6 +106,13 @@ void launch_lf_hist(FitDims d, FitWork w, Opts o, int use_dist, double xv, uint6
 void launch_lf_sums(FitDims d, FitWork w, Opts o, double xv, double h, double *partials, double *out8, hipStream_t st);
 void launch_lf_eval(FitDims d, FitWork w, const LfVerts &v, hipStream_t st);
 void launch_trend_gather(FitDims d, FitWork w, Opts o, double *xg, double *yg, hipStream_t st);
+// all-gather transport of the sharded trend: rank r's block of `block` doubles holds x[maxn] | y[maxn] (its first off[r+1] - off[r]
+// entries are rows); the copy below lays the ranks' rows out back to back
+constexpr int kGatherMaxWorld = 64;
+struct GatherLayout { int32_t world, _pad; int64_t block, maxn; int64_t off[kGatherMaxWorld + 1]; };
+void launch_trend_compact(const GatherLayout &gl, const double *recv, double *xg, double *yg, hipStream_t st);
+void launch_poke(int32_t *p, int32_t v, hipStream_t st);                       // *p = v on the stream (test hooks)
+void launch_flag_to_double(const int32_t *flag, double *out, hipStream_t st);  // *out = *flag != 0 (a verdict on its way to a sum-all-reduce)
 void launch_dispfit_resid(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_prior_var(FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_resid_hist(FitDims d, FitWork w, double *out40, hipStream_t st);  // residual histogram for the d.f. <= 3 prior
@@ -115,7 +123,7 @@ void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWo
                        const chicdiff_nbglm_out &out, hipStream_t st);
 void launch_wald_intercept(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                            const chicdiff_nbglm_out &out, hipStream_t st);
-void launch_dev_sum_finish(FitDims d, FitWork w, hipStream_t st);
+void launch_dev_sum_finish(FitDims d, FitWork w, const int32_t *carry, hipStream_t st);  // carry: the size-factor select's overflow flag (may be NULL)
 
 // radix select over keys produced on the fly; `mode` (SelMode, fit_driver.h) picks the key generator
 struct SelArgs {

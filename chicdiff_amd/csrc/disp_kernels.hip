@@ -207,26 +207,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const double *__restrict__ 
     if (threadIdx.x == 0) w.partials[(int64_t)j * gridDim.x + blockIdx.x] = red[0];
 }
 
-// one wave per column: strided fixed-order sum of the block partials, then a shuffle tree; dd: the partials are double-double pairs
-__global__ void colsum_finish_kernel(FitDims d, FitWork w, int nblk, int dd) {
+// one wave per column: strided fixed-order sum of the block partials, then a shuffle tree; dd: the partials are double-double pairs.
+// slot != NULL (sharded fit): the column's sum leaves as a (hi, lo) pair in this rank's slot of the all-ranks buffer instead of
+// rounded into the scalars — the ranks' pairs are exchanged (a sum-all-reduce over zero-filled slots) and added in rank order by
+// xim_kernel, in double-double: the correctly rounded exact sum again, so a sharded fit starts from the very xim of the one-rank fit
+__global__ void colsum_finish_kernel(FitDims d, FitWork w, int nblk, int dd, double *slot) {
     const int j = blockIdx.x, lane = threadIdx.x;
-    double s = 0;
+    DD a{0.0, 0.0};
     if (dd) {
-        DD a{0.0, 0.0};
         for (int b = lane; b < nblk; b += 64) dd_add(a, DD{w.partials[((int64_t)j * nblk + b) * 2], w.partials[((int64_t)j * nblk + b) * 2 + 1]});
         for (int off = 32; off > 0; off >>= 1) dd_add(a, DD{__shfl_down(a.hi, off), __shfl_down(a.lo, off)});
-        s = a.hi + a.lo;
     } else {
+        double s = 0;
         for (int b = lane; b < nblk; b += 64) s += w.partials[(int64_t)j * nblk + b];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        a.hi = s;
     }
     if (lane == 0) {
-        if (j < d.S) w.sc->colsum[j] = s; else w.sc->nnz = s;
+        if (slot) {
+            slot[2 * j] = a.hi;
+            slot[2 * j + 1] = a.lo;
+        } else {
+            const double s = a.hi + a.lo;
+            if (j < d.S) w.sc->colsum[j] = s; else w.sc->nnz = s;
+        }
     }
 }
 
-__global__ void xim_kernel(FitDims d, FitWork w) {
+// slots != NULL: first the ranks' (hi, lo) column sums, in rank order (see colsum_finish_kernel)
+__global__ void xim_kernel(FitDims d, FitWork w, const double *slots, int world) {
     if (threadIdx.x || blockIdx.x) return;
+    if (slots)
+        for (int j = 0; j <= d.S; j++) {
+            DD a{0.0, 0.0};
+            for (int r = 0; r < world; r++) dd_add(a, DD{slots[((size_t)r * (d.S + 1) + j) * 2], slots[((size_t)r * (d.S + 1) + j) * 2 + 1]});
+            const double s = a.hi + a.lo;
+            if (j < d.S) w.sc->colsum[j] = s; else w.sc->nnz = s;
+        }
     double x = 0;
     for (int j = 0; j < d.S; j++) x += 1.0 / (w.sc->colsum[j] / w.sc->nnz);
     w.sc->xim = x / d.S;
@@ -243,10 +260,10 @@ void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, 
         colsum_kernel<<<dim3(kColsumBlocks, d.S + 1), 256, 0, st>>>(nf, d, w);
     }
 }
-void launch_prep_finish(FitDims d, FitWork w, hipStream_t st) {
-    colsum_finish_kernel<<<d.S + 1, 64, 0, st>>>(d, w, d.S <= 16 ? prep16_blocks(d.S) : kColsumBlocks, d.S <= 16);
+void launch_prep_finish(FitDims d, FitWork w, double *slot, hipStream_t st) {
+    colsum_finish_kernel<<<d.S + 1, 64, 0, st>>>(d, w, d.S <= 16 ? prep16_blocks(d.S) : kColsumBlocks, d.S <= 16, slot);
 }
-void launch_xim(FitDims d, FitWork w, hipStream_t st) { xim_kernel<<<1, 64, 0, st>>>(d, w); }
+void launch_xim(FitDims d, FitWork w, const double *slots, int world, hipStream_t st) { xim_kernel<<<1, 64, 0, st>>>(d, w, slots, world); }
 
 // ------------------------------------------------------------------------------------------
 // Start values of the two line searches, one thread per row, so that the queue refill inside the

@@ -244,6 +244,26 @@ __global__ __launch_bounds__(256) void trend_gather_kernel(FitDims d, FitWork w,
 void launch_trend_gather(FitDims d, FitWork w, Opts o, double *xg, double *yg, hipStream_t st) {
     trend_gather_kernel<<<kRedBlocks, 256, 0, st>>>(d, w, o.minDisp, xg, yg);
 }
+__global__ __launch_bounds__(256) void trend_compact_kernel(GatherLayout gl, const double *__restrict__ recv, double *__restrict__ xg,
+                                                            double *__restrict__ yg) {
+    const int r = blockIdx.y;
+    const int64_t cnt = gl.off[r + 1] - gl.off[r];
+    const double *src = recv + (int64_t)r * gl.block;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) {
+        xg[gl.off[r] + i] = src[i];
+        yg[gl.off[r] + i] = src[gl.maxn + i];
+    }
+}
+void launch_trend_compact(const GatherLayout &gl, const double *recv, double *xg, double *yg, hipStream_t st) {
+    int64_t bx = (gl.maxn + 255) / 256;
+    if (bx > 2048 / gl.world) bx = 2048 / gl.world;
+    if (bx < 1) bx = 1;
+    trend_compact_kernel<<<dim3((unsigned)bx, (unsigned)gl.world), 256, 0, st>>>(gl, recv, xg, yg);
+}
+__global__ void poke_kernel(int32_t *p, int32_t v) { *p = v; }
+void launch_poke(int32_t *p, int32_t v, hipStream_t st) { poke_kernel<<<1, 1, 0, st>>>(p, v); }
+__global__ void flag_to_double_kernel(const int32_t *flag, double *out) { *out = *flag ? 1.0 : 0.0; }
+void launch_flag_to_double(const int32_t *flag, double *out, hipStream_t st) { flag_to_double_kernel<<<1, 1, 0, st>>>(flag, out); }
 int trend_persistent_blocks() { return kTpBlocks; }
 void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
     // (the barrier counters were zeroed with the fit's scalars; the trend runs once per fit)
@@ -254,6 +274,9 @@ void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
     int64_t blocks = (d.n + kTpMinRows - 1) / kTpMinRows;
     if (blocks < 1) blocks = 1;
     if (blocks > kTpBlocks) blocks = kTpBlocks;
+    // fewer on request: several fits sharing one GPU (the one-GPU rehearsal of a sharded fit) must keep ALL their trend kernels'
+    // workgroups resident at once, or the grid barriers time out; rows beyond the LDS cache stream from HBM / L2
+    if (o.trend_blocks > 0 && blocks > o.trend_blocks) blocks = o.trend_blocks;
     trend_persistent_kernel<<<(unsigned)blocks, kTpThreads, 0, st>>>(d, w, o.minDisp);
 }
 

@@ -17,6 +17,7 @@ import ctypes as C
 import numpy as np
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)  # chicdiff_allgather_fn: user, send, recv, count
 
 
 def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
@@ -83,3 +84,32 @@ class AllReduceHook:
                 return 1
 
         self.fn = ALLREDUCE_FN(cb)
+        self.gathers = 0
+        self.gather_doubles = 0
+
+        def gather_cb(_user, send, recv, count):
+            """chicdiff_allgather_fn: `count` doubles from every rank, rank r's block at recv + r * count."""
+            try:
+                count = int(count)
+                if memory == "host":
+                    s_ = torch.from_numpy(np.frombuffer((C.c_double * count).from_address(int(send)), dtype=np.float64))
+                    r_ = torch.from_numpy(np.frombuffer((C.c_double * (count * self.world)).from_address(int(recv)), dtype=np.float64))
+                    dist.all_gather_into_tensor(r_, s_, group=group)
+                else:
+                    s_ = torch.as_tensor(_RawDevice(int(send), count), device=device)
+                    r_ = torch.as_tensor(_RawDevice(int(recv), count * self.world), device=device)
+                    if memory == "device_via_host":  # gloo carries host tensors
+                        hs = s_.cpu()
+                        hr = torch.empty(count * self.world, dtype=torch.float64)
+                        dist.all_gather_into_tensor(hr, hs, group=group)
+                        r_.copy_(hr)
+                    else:
+                        dist.all_gather_into_tensor(r_, s_, group=group)
+                self.gathers += 1
+                self.gather_doubles += count
+                return 0
+            except Exception as e:
+                self.error = e
+                return 1
+
+        self.gather_fn = ALLGATHER_FN(gather_cb)

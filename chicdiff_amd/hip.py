@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from .dist import ALLREDUCE_FN
+from .dist import ALLGATHER_FN, ALLREDUCE_FN
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libchicdiff_hip.so")
@@ -23,7 +23,7 @@ ST_TREND_FAILED, ST_PRIORVAR_MC, ST_BETA_NONCONV, ST_ALLZERO_ROWS, ST_TREND_LOCA
 # every symbol include/chicdiff_hip.h declares (tests check the library exports each)
 EXPORTS = [
     "chicdiff_hip_create", "chicdiff_hip_destroy", "chicdiff_hip_last_error", "chicdiff_hip_set_stream",
-    "chicdiff_hip_set_allreduce", "chicdiff_hip_set_option", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
+    "chicdiff_hip_set_allreduce", "chicdiff_hip_set_allgather", "chicdiff_hip_last_refits", "chicdiff_hip_set_option", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
     "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
@@ -66,7 +66,7 @@ class ResultsInfo(C.Structure):
 
 
 class KernelTime(C.Structure):
-    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_int32)]
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_int32), ("_pad", C.c_int32), ("bytes", C.c_double)]
 
 
 class ChicdiffHipError(RuntimeError):
@@ -100,6 +100,9 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_last_error.restype = C.c_char_p
     L.chicdiff_hip_set_stream.argtypes = [vp, vp]
     L.chicdiff_hip_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32, i32]
+    L.chicdiff_hip_set_allgather.argtypes = [vp, ALLGATHER_FN, vp]
+    L.chicdiff_hip_last_refits.argtypes = [vp]
+    L.chicdiff_hip_last_refits.restype = i32
     L.chicdiff_hip_set_option.argtypes = [vp, C.c_char_p, i64]
     L.chicdiff_hip_default_opts.argtypes = [C.POINTER(Opts)]
     L.chicdiff_hip_default_opts.restype = None
@@ -212,12 +215,26 @@ class HipContext:
         k = self.lib.chicdiff_hip_kernel_times(self.h, buf, 32)
         return {buf[i].name.decode(): (buf[i].ms, buf[i].launches) for i in range(min(k, 32))}
 
-    def set_process_group(self, group=None, memory="device"):
-        """Route the library's sum-all-reduces through torch.distributed (backend nccl = RCCL)."""
+    def collective_stats(self) -> dict:
+        """Collectives of the last call (timing mode 1): {"allreduce" / "allgather": (count, ms on the stream, bytes handed over)}."""
+        buf = (KernelTime * 32)()
+        k = self.lib.chicdiff_hip_kernel_times(self.h, buf, 32)
+        return {buf[i].name.decode(): (buf[i].launches, buf[i].ms, buf[i].bytes) for i in range(min(k, 32))
+                if buf[i].name in (b"allreduce", b"allgather")}
+
+    def last_refits(self) -> int:
+        """Refits the last call went through (select overflow / barrier timeout / local substitute); the same on every rank."""
+        return int(self.lib.chicdiff_hip_last_refits(self.h))
+
+    def set_process_group(self, group=None, memory="device", allgather=True):
+        """Route the library's collectives through torch.distributed (backend nccl = RCCL): the sum-all-reduce hook and,
+        unless ``allgather`` is False, the all-gather hook for the rows of the dispersion trend."""
         from .dist import AllReduceHook
 
         self._hook = AllReduceHook(group, memory=memory, device=self.device)
         self._check(self.lib.chicdiff_hip_set_allreduce(self.h, self._hook.fn, None, self._hook.world, self._hook.rank))
+        if allgather:
+            self._check(self.lib.chicdiff_hip_set_allgather(self.h, self._hook.gather_fn, None))
 
     def init_rccl(self, group=None, librccl_path=None):
         """Direct RCCL: the library makes its own communicator over the ranks of ``group`` and issues

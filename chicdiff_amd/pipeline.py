@@ -54,9 +54,9 @@ def readAndFilterPeakMatrix(peakFiles, targetColumns, chicagoData, conditions, s
         x = x[sel2]
     x = x[x["dist"].notna()]                               # trans interactions out
     x = x[~((x["oeID"] == x["baitID"] + 1) | (x["oeID"] == x["baitID"] - 1))]   # directly adjacent fragments out
-    filtered = [b for b in all_baits if b not in set(x["baitID"])]
-    with open(f"{outprefix}_filteredBaits.txt", "w") as f:
-        f.write("\n".join(str(b) for b in filtered) + ("\n" if filtered else ""))
+    filtered = np.asarray(all_baits)[~np.isin(all_baits, x["baitID"].to_numpy())]   # one %in%, as chicdiff.R:271
+    with open(f"{outprefix}_filteredBaits.txt", "w") as f:                         # fwrite(list(...)): a "V1" header line, then the IDs
+        f.write("V1\n" + "".join(f"{b}\n" for b in filtered))
     return x.reset_index(drop=True)
 
 
@@ -113,10 +113,16 @@ def getControlRegionUniverse(chicdiff_settings, RU, ctx, rng=None):
     rmap = _read_rmap(s["rmapfile"])
     bmap = pd.read_csv(s["baitmapfile"], sep=r"\s+", header=None, quotechar='"', engine="python").iloc[:, :4]
     bmap.columns = ["chr", "start", "end", "ID"]
-    chr_of_id = dict(zip(rmap["otherEndID"].to_numpy(), rmap["OEchr"].astype(str).to_numpy()))
     ru_b, ru_o = RU["baitID"].cpu().numpy(), RU["otherEndID"].cpu().numpy()
-    ru_chr = np.array([chr_of_id[b] for b in ru_b])
-    contact = pd.DataFrame({"chr": ru_chr, "d": np.abs(ru_b.astype(np.int64) - ru_o)}).groupby("chr")["d"].max()   # :466
+    # merge(RU, rmap[, c("chr", "ID")], by.x = "baitID", by.y = "ID") (:465): an inner join — RU rows whose bait is not on the
+    # map drop out silently; dense chromosome codes per ID, -1 = not on the map
+    ids = rmap["otherEndID"].to_numpy(np.int64)
+    names, codes = np.unique(rmap["OEchr"].astype(str).to_numpy(), return_inverse=True)
+    code_of = np.full(int(max(ids.max(), ru_b.max())) + 2, -1, dtype=np.int64)
+    code_of[ids] = codes
+    ru_code = code_of[ru_b.astype(np.int64)]
+    on_map = ru_code >= 0
+    contact = pd.DataFrame({"chr": names[ru_code[on_map]], "d": np.abs(ru_b.astype(np.int64) - ru_o)[on_map]}).groupby("chr")["d"].max()   # :466
     n_regions = len(np.unique(RU["regionID"].cpu().numpy()))
     draw = rng.choice(bmap["ID"].to_numpy(), size=n_regions, replace=True)                                           # :468
     ctrl = pd.DataFrame({"ID": draw}).merge(bmap[bmap["chr"].astype(str).isin(contact.index)][["chr", "ID"]], on="ID")

@@ -54,6 +54,12 @@ typedef struct chicdiff_hip_ctx chicdiff_hip_ctx;
  * in the reference (single process); it is the hook for row sharding. */
 typedef int (*chicdiff_allreduce_fn)(void *user, void *dev_buf, int64_t count);
 
+/* Optional companion of the all-reduce hook: every rank contributes `count` doubles at DEVICE pointer `dev_send`; `dev_recv`
+ * (world_size x count doubles, distinct from dev_send) receives rank r's block at r * count, ordered on the context's stream.
+ * With it a sharded fit exchanges the rows of the dispersion trend by one all-gather (ncclAllGather); without it, by a
+ * sum-all-reduce over zero-filled all-ranks arrays (twice the bytes).  Same results either way. */
+typedef int (*chicdiff_allgather_fn)(void *user, const void *dev_send, void *dev_recv, int64_t count);
+
 int chicdiff_hip_create(chicdiff_hip_ctx **ctx, int32_t device);
 void chicdiff_hip_destroy(chicdiff_hip_ctx *ctx);
 const char *chicdiff_hip_last_error(const chicdiff_hip_ctx *ctx); /* ctx may be NULL: last create() error */
@@ -65,6 +71,12 @@ int chicdiff_hip_set_stream(chicdiff_hip_ctx *ctx, void *hip_stream);
  * where the all-reduce is the identity); fn = NULL restores the single-process path. */
 int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, void *user,
                                int32_t world_size, int32_t rank);
+/* After chicdiff_hip_set_allreduce (which clears it): the all-gather of the same transport; fn = NULL removes it. */
+int chicdiff_hip_set_allgather(chicdiff_hip_ctx *ctx, chicdiff_allgather_fn fn, void *user);
+/* Refits the last fit / size-factor / Wald-test call went through (a sharded select whose candidate list overflowed on some
+ * rank, a grid-barrier timeout of the trend kernel on some rank, the local-regression substitute): every rank of a sharded
+ * call reports the same number — each verdict is all-reduced before anybody acts on it. */
+int32_t chicdiff_hip_last_refits(const chicdiff_hip_ctx *ctx);
 
 /* Tuning / test options; results never depend on them, the defaults are what bench.py measures.
  *   "line_search_spread"        1 (default) | 0: evaluate straggler rows (line searches and IRLS) with their samples spread across lanes
@@ -78,14 +90,20 @@ int chicdiff_hip_set_allreduce(chicdiff_hip_ctx *ctx, chicdiff_allreduce_fn fn, 
  *   "trend_one_launch_per_pass" 0 (default) | 1: trend fit as one launch per IRLS pass instead of one persistent kernel
  *   "sharded_trend_gather"      1 (default) | 0: sharded fits exchange the trend's rows once and fit them on every rank,
  *                               instead of one all-reduce per IRLS pass (same coefficients up to summation order)
+ *   "trend_persistent_blocks"   0 (default: one workgroup per CU), 1 .. 256: cap on the workgroups of the single-launch trend
+ *                               kernel, for fits that share one GPU (its grid barrier needs all of them resident at once); the
+ *                               coefficients then differ in summation order only (1e-13)
+ *   "fault_inject"              0 (default); test hook, one-shot bits consumed by the next call: 1 = this rank reports a select
+ *                               overflow in its next fit, 2 = a grid-barrier timeout of its trend kernel, 4 = an overflow of its
+ *                               next size-factor select — to prove that all ranks of a sharded fit refit together
  * and one that does change the outcome of a fit whose parametric trend fails (DESeq2 offers the same choice through fitType):
  *   "local_trend_substitute"    1 (default) | 0: report CHICDIFF_ST_TREND_FAILED instead of substituting the local regression */
 int chicdiff_hip_set_option(chicdiff_hip_ctx *ctx, const char *name, int64_t value);
 
 /* Direct RCCL (backend of choice on one node: RCCL over xGMI).  The library dlopen()s librccl (librccl_path, or
  * "librccl.so" when NULL/empty — pass the copy the host process already uses, e.g. torch's), creates its own
- * communicator and from then on calls ncclAllReduce(ncclFloat64, ncclSum) itself, in place on its stream: no host
- * callback per collective.  Rank 0 makes the 128-byte id with _unique_id and the host broadcasts it (any
+ * communicator and from then on calls ncclAllReduce(ncclFloat64, ncclSum) — and ncclAllGather for the rows of the
+ * dispersion trend — itself, in place on its stream: no host callback per collective.  Rank 0 makes the 128-byte id with _unique_id and the host broadcasts it (any
  * transport); every rank then calls _init, which replaces a callback set with chicdiff_hip_set_allreduce. */
 int chicdiff_hip_rccl_unique_id(chicdiff_hip_ctx *ctx, const char *librccl_path, void *id128);
 int chicdiff_hip_rccl_init(chicdiff_hip_ctx *ctx, const char *librccl_path, const void *id128, int32_t world_size,
@@ -341,6 +359,8 @@ typedef struct {
     const char *name;
     double ms;
     int32_t launches;
+    int32_t _pad;
+    double bytes; /* "allreduce" / "allgather" (timing mode 1): payload this rank handed to the transport; 0 for kernels */
 } chicdiff_kernel_time;
 int32_t chicdiff_hip_kernel_times(chicdiff_hip_ctx *ctx, chicdiff_kernel_time *out, int32_t cap);
 /* on: 0 = off, 1 = every stage of a call gets an event pair, 2 = only the three fit kernels (disp_gene, disp_map, wald_irls):

@@ -176,3 +176,44 @@ def test_sharded_median_falls_back_when_the_gathered_list_would_overflow():
         assert calls == 8  # 2 histogram rounds + count rows + (empty) candidate buffer + 4 more histogram rounds
         assert np.allclose(sf, ref, rtol=1e-13)
     assert res[0][1] == res[1][1]
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from chicdiff_amd.dist import AllReduceHook
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hook = AllReduceHook(memory="host")
+        count = 1000
+        send = np.arange(count, dtype=np.float64) + 10000.0 * rank
+        recv = np.full(count * world, -1.0)
+        rc = hook.gather_fn(None, send.ctypes.data, recv.ctypes.data, count)
+        q.put((rank, rc, repr(hook.error), recv.tolist(), hook.gathers, hook.gather_doubles))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_hook_lays_the_ranks_blocks_out_in_rank_order():
+    """chicdiff_allgather_fn as chicdiff_amd.dist implements it (host memory, gloo, world_size 2): rank r's block lands at
+    r * count on every rank — the layout api.hip's gathered_trend / trend_compact_kernel read."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    want = np.concatenate([np.arange(1000.0), np.arange(1000.0) + 10000.0])
+    for rank, rc, err, recv, gathers, doubles in res:
+        assert rc == 0 and err == "None", (rank, err)
+        assert np.array_equal(np.array(recv), want) and gathers == 1 and doubles == 1000

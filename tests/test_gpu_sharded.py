@@ -1,0 +1,328 @@
+"""The row-sharded fit at CONFIG SIZE on the one GPU of the test box (BASELINE.json configs[3]: 2 M x 8 sharded).
+
+Two transports, same scenario (`_scenario`):
+  * world_size 4 — four PROCESSES sharing GPU 0, gloo carrying the device buffers through the host (RCCL refuses two
+    ranks on one device): the real hook path (chicdiff_amd.dist.AllReduceHook: all-reduce + all-gather);
+  * world_size 8 — eight THREADS of one process, each with its own context and stream, an in-process transport that
+    adds / concatenates the ranks' device buffers in rank order.  (Eight processes are not possible here: the GPU box
+    allows at most six processes on its card.)
+Every rank takes its `shard_bounds` block of the 2 M rows.  What is asserted:
+  * the concatenated result EQUALS the single-rank fit bit for bit — exact medians, the column sums exchanged as
+    double-double pairs, the trend's rows gathered and fitted by the single-rank kernel: nothing depends on the sharding
+    (the ranks and the reference cap the trend kernel at 256 / world workgroups so that all ranks' grid barriers can be
+    resident on the shared GPU at once);
+  * one all-gather carries the trend rows (half the bytes of the sum-all-reduce it replaced);
+  * a select overflow forced on ONE rank (size-factor select; MAD select) and a trend grid-barrier timeout forced on ONE
+    rank make EVERY rank refit, once, together: the verdicts are all-reduced before anybody acts on them."""
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+
+from chicdiff_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+WANT = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue", "dispGeneEst", "dispFit", "maxCooks", "betaIter"]
+N_ROWS, S = 2_000_000, 8
+LEGS = [("plain", None, 0), ("sf_select_overflow_on_rank_1", (1, 4), 1), ("fit_select_overflow_on_last_rank", (-1, 1), 1),
+        ("trend_barrier_timeout_on_rank_0", (0, 2), 1)]
+
+
+def rel(a, b):
+    return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+
+
+def _scenario(c, rank, world, ref_dir):
+    """One rank's part: the plain sharded fit, then the three forced refits; each compared with this rank's slice of the
+    single-rank reference the parent saved under `ref_dir`.  Returns a small report."""
+    from chicdiff_amd.dist import shard_bounds
+    lo, hi = shard_bounds(N_ROWS, world, rank)
+    d = synth.make(hi - lo, S, start=lo)
+    dk = c.to_device(d["counts"], np.int32)
+    dF = c.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)
+    c.set_option("trend_persistent_blocks", 256 // world)
+    ref = {k: np.load(os.path.join(ref_dir, k + ".npy"), mmap_mode="r")[lo:hi] for k in WANT}
+    ref_sc = np.load(os.path.join(ref_dir, "scalars.npy"))
+    report = dict(rank=rank, rows=hi - lo, legs={})
+    for name, fault, want_refits in LEGS:
+        if fault is not None and rank == (fault[0] % world):
+            c.set_option("fault_inject", fault[1])
+        c.enable_timing(1 if name == "plain" else 0)
+        out, sc = c.wald_test(dk, dF, d["group"], theta=0.5, want=WANT)
+        leg = dict(refits=c.last_refits(), want_refits=want_refits, trendCoef=[float(x) for x in sc["trendCoef"]], status=int(sc["status"]))
+        if name == "plain":
+            leg["collectives"] = {k: list(v) for k, v in c.collective_stats().items()}
+        c.enable_timing(0)
+        scal = np.array(list(sc["trendCoef"]) + [sc["varLogDispEsts"], sc["dispPriorVar"]] + list(sc["sizeFactors"]))
+        leg["scalars_identical"] = bool(np.array_equal(scal, ref_sc))
+        leg["scalars_max_rel"] = float(rel(scal, ref_sc).max())
+        worst, identical, off = 0.0, True, np.zeros(hi - lo, dtype=bool)
+        for k in WANT:
+            g, r = out[k].cpu().numpy(), np.asarray(ref[k])
+            same_nan = np.array_equal(np.isnan(g.astype(np.float64)), np.isnan(r.astype(np.float64)))
+            identical &= bool(np.array_equal(g, r, equal_nan=True))
+            ok = ~np.isnan(r.astype(np.float64))
+            rr = rel(g.astype(np.float64), r.astype(np.float64))
+            worst = max(worst, float(rr[ok].max()) if ok.any() else 0.0)
+            off |= ok & (rr > 1e-9)
+            leg.setdefault("nan_pattern_equal", True)
+            leg["nan_pattern_equal"] &= bool(same_nan)
+        leg["rows_identical"] = identical
+        leg["rows_max_rel"] = worst
+        leg["rows_off_1e-9"] = int(off.sum())
+        report["legs"][name] = leg
+    return report
+
+
+def _check_reports(reports, world):
+    assert sorted(r["rank"] for r in reports) == list(range(world))
+    for name, fault, want_refits in LEGS:
+        legs = [r["legs"][name] for r in sorted(reports, key=lambda r: r["rank"])]
+        refits = [leg["refits"] for leg in legs]
+        print(f"world {world} / {name}: refits per rank {refits}, scalars identical {[l['scalars_identical'] for l in legs]}, "
+              f"rows identical {[l['rows_identical'] for l in legs]}, worst rel {max(l['rows_max_rel'] for l in legs):.2e}")
+        assert refits == [want_refits] * world, (name, refits)   # every rank re-entered, once — or nobody did
+        assert all(l["nan_pattern_equal"] for l in legs), name
+        assert len({tuple(l["trendCoef"]) for l in legs}) == 1, name  # the same trend on every rank
+        if name != "trend_barrier_timeout_on_rank_0":
+            # same rows, same order, same kernels as the single-rank fit: the same bits
+            assert all(l["scalars_identical"] for l in legs), (name, [l["scalars_max_rel"] for l in legs])
+            assert all(l["rows_identical"] for l in legs), (name, [l["rows_max_rel"] for l in legs])
+        else:
+            # the refit runs the trend with one launch + one all-reduce per IRLS pass: the same sums in another order, coefficients
+            # ~1e-13 apart.  Rows follow to 1e-9 — but for the odd MAP search that stops one step apart under a prior mean shifted
+            # by 1e-13 (DESeq2's stopping rule `change < 1e-6` has no margin; DESIGN.md 3 shows the oracle doing the same against
+            # itself): counted, and bounded at one row in 100 000
+            n_off = sum(l["rows_off_1e-9"] for l in legs)
+            print(f"world {world} / {name}: scalars max rel {max(l['scalars_max_rel'] for l in legs):.2e}, rows beyond 1e-9: {n_off} of {N_ROWS}")
+            assert max(l["scalars_max_rel"] for l in legs) < 1e-10, name
+            assert n_off <= 1e-5 * N_ROWS, (name, n_off)
+    coll = [r["legs"]["plain"]["collectives"] for r in sorted(reports, key=lambda r: r["rank"])]
+    print(f"world {world}: collectives of one sharded fit on rank 0: {coll[0]}")
+    for cst in coll:
+        assert cst["allgather"][0] == 1  # the trend rows: ONE all-gather ...
+        blk = -(-(2 * max(r["rows"] for r in reports) * 8) // 256) * 256
+        assert cst["allgather"][2] == blk  # ... of this rank's padded (x | y) block — not 2 x 8 x 2 M bytes of zero-filled arrays
+        assert cst["allreduce"][0] <= 8
+    return coll
+
+
+@pytest.fixture(scope="module")
+def reference(tmp_path_factory):
+    """Single-rank fits of the 2 M x 8 matrix with the trend kernel capped as the ranks cap it (world 4: 64, world 8: 32)."""
+    import __graft_entry__ as g
+    g.build()
+    from chicdiff_amd import hip
+    c = hip.HipContext(0)
+    d = synth.make(N_ROWS, S)
+    dk = c.to_device(d["counts"], np.int32)
+    dF = c.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)
+    dirs = {}
+    for world in (4, 8):
+        c.set_option("trend_persistent_blocks", 256 // world)
+        out, sc = c.wald_test(dk, dF, d["group"], theta=0.5, want=WANT)
+        p = tmp_path_factory.mktemp(f"ref_world{world}")
+        for k in WANT:
+            np.save(os.path.join(p, k + ".npy"), out[k].cpu().numpy())
+        np.save(os.path.join(p, "scalars.npy"), np.array(list(sc["trendCoef"]) + [sc["varLogDispEsts"], sc["dispPriorVar"]] + list(sc["sizeFactors"])))
+        dirs[world] = str(p)
+    c.set_option("trend_persistent_blocks", 0)
+    out0, sc0 = c.wald_test(dk, dF, d["group"], theta=0.5, want=["pvalue"])
+    capped = np.load(os.path.join(dirs[8], "pvalue.npy"))
+    ok = ~np.isnan(capped)
+    r = rel(out0["pvalue"].cpu().numpy()[ok], capped[ok])
+    print(f"single rank, trend kernel with 256 vs 32 workgroups: trend {sc0['trendCoef']} vs {sc['trendCoef']}, p-values beyond 1e-9: {int((r > 1e-9).sum())} "
+          f"of {int(ok.sum())} (summation order of the trend sums only)")
+    assert np.allclose(sc0["trendCoef"], sc["trendCoef"], rtol=1e-11) and (r > 1e-9).sum() <= 1e-5 * ok.sum()
+    c.close()
+    return dirs
+
+
+def _process_worker(rank, world, port, ref_dir, q):
+    import torch.distributed as dist
+    from chicdiff_amd import hip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = hip.HipContext(0)
+        c.set_process_group(memory="device_via_host")
+        rep = _scenario(c, rank, world, ref_dir)
+        assert c._hook.error is None and c._hook.gathers >= 1
+        rep["hook"] = dict(allreduce_calls=c._hook.calls, allgather_calls=c._hook.gathers)
+        q.put(rep)
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world4_processes_sharing_the_gpu_at_2Mx8_equal_the_single_rank_fit(reference):
+    import torch.multiprocessing as mp
+    world = 4
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_process_worker, args=(r, world, port, reference[world], q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        reports = [q.get(timeout=600) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    _check_reports(reports, world)
+
+
+class _ThreadTransport:
+    """In-process stand-in for RCCL: the ranks are threads, each with its own context and stream; a collective waits for
+    every rank's stream, then adds (all-reduce) or lays out (all-gather) the ranks' device buffers in rank order."""
+
+    def __init__(self, world, torch, device):
+        from chicdiff_amd.dist import ALLGATHER_FN, ALLREDUCE_FN, _RawDevice
+        self.world, self.torch = world, torch
+        self.barrier = threading.Barrier(world, timeout=300)
+        self.slots = [None] * world
+        self.error = None
+        self.reduce_fns, self.gather_fns = [], []
+        view = lambda ptr, count: torch.as_tensor(_RawDevice(int(ptr), int(count)), device=device)
+
+        def make(rank):
+            def reduce_cb(_u, ptr, count):
+                try:
+                    self.slots[rank] = view(ptr, count)
+                    torch.cuda.synchronize()       # this rank's stream has produced the buffer (device-wide: simplest)
+                    self.barrier.wait()
+                    if rank == 0:
+                        acc = self.slots[0].clone()
+                        for r in range(1, world):  # fixed order
+                            acc += self.slots[r]
+                        self.total = acc
+                        torch.cuda.synchronize()
+                    self.barrier.wait()
+                    self.slots[rank].copy_(self.total)
+                    torch.cuda.synchronize()
+                    self.barrier.wait()
+                    return 0
+                except Exception as e:  # noqa: BLE001 — must not cross the C boundary
+                    self.error = e
+                    return 1
+
+            def gather_cb(_u, send, recv, count):
+                try:
+                    self.slots[rank] = view(send, count)
+                    torch.cuda.synchronize()
+                    self.barrier.wait()
+                    out = view(recv, int(count) * world)
+                    for r in range(world):
+                        out[r * int(count):(r + 1) * int(count)].copy_(self.slots[r])
+                    torch.cuda.synchronize()
+                    self.barrier.wait()
+                    return 0
+                except Exception as e:  # noqa: BLE001
+                    self.error = e
+                    return 1
+
+            return ALLREDUCE_FN(reduce_cb), ALLGATHER_FN(gather_cb)
+
+        for r in range(world):
+            a, g = make(r)
+            self.reduce_fns.append(a)
+            self.gather_fns.append(g)
+
+
+def test_world8_ranks_sharing_the_gpu_at_2Mx8_equal_the_single_rank_fit(reference):
+    import torch
+    from chicdiff_amd import hip
+    world = 8
+    tr = _ThreadTransport(world, torch, torch.device("cuda", 0))
+    ctxs = [hip.HipContext(0, use_torch_stream=False) for _ in range(world)]  # own non-blocking stream each
+    reports, errors = [None] * world, [None] * world
+
+    def run(rank):
+        try:
+            c = ctxs[rank]
+            c._check(c.lib.chicdiff_hip_set_allreduce(c.h, tr.reduce_fns[rank], None, world, rank))
+            c._check(c.lib.chicdiff_hip_set_allgather(c.h, tr.gather_fns[rank], None))
+            reports[rank] = _scenario(c, rank, world, reference[world])
+        except Exception as e:  # noqa: BLE001
+            errors[rank] = e
+            tr.barrier.abort()  # the peers' collectives fail instead of waiting for this rank for ever
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(900)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+    assert all(e is None for e in errors) and tr.error is None, (errors, tr.error)
+    _check_reports(reports, world)
+    for c in ctxs:
+        c.close()
+
+
+def test_option_select_all_rounds_survives_an_overflow_refit(reference):
+    """the size-factor overflow retry used to leave `select_all_rounds` stuck (and clobbered a user's own
+    setting).  One rank with a registered callback (so the sharded protocol runs), massive ties, a forced overflow: the
+    option reads back as the caller left it — observable through the number of collectives of the next call."""
+    import torch
+    from chicdiff_amd import hip
+    from chicdiff_amd.dist import ALLREDUCE_FN
+    c = hip.HipContext(0)
+    calls = [0]
+
+    def cb(_u, _p, _n):
+        calls[0] += 1
+        return 0
+
+    fn = ALLREDUCE_FN(cb)
+    c._check(c.lib.chicdiff_hip_set_allreduce(c.h, fn, None, 1, 0))
+    g = synth.groups(S)
+    rng = np.random.default_rng(5)
+    n = 60000
+
+    def collectives(dk, dF, **kw):
+        calls[0] = 0
+        out, sc = c.wald_test(dk, dF, g, theta=0.5, want=["pvalue"], **kw)
+        return calls[0], c.last_refits(), out["pvalue"].cpu().numpy(), sc["sizeFactors"]
+
+    # (1) massive ties: half the rows are constant, so 30 000 keys share every bit with each column's median and the candidate
+    # list of the sharded select (4096 entries) overflows for real — on every call alike
+    tied = rng.integers(1, 40, size=(n, S)).astype(np.int32)
+    tied[: n // 2] = 7
+    fm = rng.lognormal(2.0, 0.3, size=(n, S))
+    tk, tF = c.to_device(tied, np.int32), c.to_device(fm, np.float64)
+    t1 = collectives(tk, tF)
+    t2 = collectives(tk, tF)
+    print("massive ties: collectives, refits of two consecutive calls:", t1[:2], t2[:2])
+    assert t1[1] == 1 and t2[:2] == t1[:2] and np.array_equal(t1[2], t2[2], equal_nan=True) and np.array_equal(t1[3], t2[3])
+    c.set_option("select_all_rounds", 1)
+    t3 = collectives(tk, tF)   # the medians by histogram rounds from the start: same size factors, no refit
+    c.set_option("select_all_rounds", 0)
+    assert t3[1] == 0 and np.array_equal(t1[3], t3[3]) and np.array_equal(t1[2], t3[2], equal_nan=True)
+    # (2) ordinary counts, the overflow forced by the test hook
+    d = synth.make(n, S)
+    dk, dF = c.to_device(d["counts"], np.int32), c.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)
+    base_calls, base_refits, p0, sf0 = collectives(dk, dF)
+    c.set_option("fault_inject", 4)
+    forced_calls, forced_refits, p1, sf1 = collectives(dk, dF)
+    after_calls, after_refits, p2, sf2 = collectives(dk, dF)
+    print("collectives per call: plain", base_calls, "forced overflow", forced_calls, "the call after", after_calls, "| refits", base_refits, forced_refits, after_refits)
+    assert base_refits == 0 and forced_refits == 1 and forced_calls > base_calls
+    assert (after_calls, after_refits) == (base_calls, base_refits)   # the option is back where it was
+    assert np.array_equal(p0, p1, equal_nan=True) and np.array_equal(p0, p2, equal_nan=True) and np.array_equal(sf0, sf1)
+    c.set_option("select_all_rounds", 1)                               # a user's own setting survives a (would-be) retry too
+    user_calls, _, p3, _ = collectives(dk, dF)
+    c.set_option("fault_inject", 4)
+    user_forced_calls, user_forced_refits, p4, _ = collectives(dk, dF)
+    user_after_calls, _, _, _ = collectives(dk, dF)
+    assert user_forced_refits == 0 and user_forced_calls == user_calls == user_after_calls and user_calls > base_calls
+    assert np.array_equal(p0, p3, equal_nan=True) and np.array_equal(p0, p4, equal_nan=True)
+    c.close()
