@@ -428,6 +428,13 @@ struct DispArgs {
     int deal;                    // entries per group of the static deal (0 = by the number of entries per wave)
     int prefetch;                // 1 = warm the cache lines of the rows handed out next
 };
+// make ISA_MARK=1 (tools/isa_account.py): comment lines in the generated assembly that delimit the parts of a tick; a volatile asm
+// statement also keeps the compiler from moving code across it, so the marked build is for counting, not for running
+#ifdef CHICDIFF_ISA_MARK
+#define MARK(name) asm volatile("; MARK " name)
+#else
+#define MARK(name)
+#endif
 #ifdef CHICDIFF_DIAG
 #define DIAG(...) __VA_ARGS__
 constexpr int kStampSlots = 12;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
@@ -545,8 +552,10 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
                                            bool p2, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
                                            double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
+    MARK("row:begin");
     const RowConsts c = row_consts(a, lt);
     alpha_out = c.alpha;
+    MARK("row:row_consts_end");
     // per-tick table (LDS, [entry][lane]): P_n and H_n for n = 0..nr
     {
         double P = 1.0, H = 0.0, zz = c.r;
@@ -560,6 +569,7 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
             s_tab[(11 + i) * 64 + lane] = H;
         }
     }
+    MARK("row:table_end");
     Acc acc;
     for (int j = 0; j < S; j++) {
         const int yi = s_y[j * 64 + slot];
@@ -567,7 +577,9 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
         const bool g = (gmask >> j) & 1;
         accumulate(acc, sample_values(c, s_nf[j * 64 + slot], yi, s_tab[n * 64 + lane], s_tab[(11 + n) * 64 + lane], lt), g);
     }
+    MARK("row:samples_end");
     finish_point(acc, c, p2, use_prior, prior_mean, prior_isig, lp, dlp, lt);
+    MARK("row:finish_end");
 }
 
 // Samples-across-lanes evaluation for the end of the launch.  Once the queue is empty every wave is left
@@ -597,9 +609,11 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
     for (unsigned long long m = actmask; m; m &= m - 1ull, nact++)
         if (grp == nact) owner = __ffsll((long long)m) - 1;
     const bool has = grp < nact;
+    MARK("spread:owner_walk_end");
     const double a_o = __shfl(a_eval, owner);
     const double pm_o = use_prior ? __shfl(prior_mean, owner) : 0.0;
     const RowConsts c = row_consts(a_o, lt);
+    MARK("spread:row_consts_end");
     // the five values of every sample pass through the wave's prefix-table area (idle in this layout), [value][sample R + group]:
     // each lane then reads its group's S samples — four samples' loads in flight at a time, same address within a group (a
     // broadcast), neighbouring banks across groups — and folds them in sample order.  (Round 2 fetched them with nine
@@ -619,7 +633,9 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
                 zz += 1.0;
             }
         }
+        MARK("spread:prefix_walk_end");
         const SampleVals v = sample_values(c, nfj, yi, P, H, lt);
+        MARK("spread:sample_end");
         const int e = j * R + grp;
         s_x[e] = v.wj;
         s_x[256 + e] = v.pm;
@@ -627,6 +643,7 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
         s_x[768 + e] = v.tsd;
         s_xe[e] = v.pe;
     }
+    MARK("spread:exchange_store_end");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -647,13 +664,16 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
             if (j0 + t < S) accumulate(acc, u[t], (gmask >> (j0 + t)) & 1);
     }
     __builtin_amdgcn_wave_barrier();  // (the area is written again only after every lane has read it)
+    MARK("spread:fold_end");
     double lp_g, dlp_g;
     finish_point(acc, c, p2, use_prior, pm_o, prior_isig, lp_g, dlp_g, lt);
+    MARK("spread:finish_end");
     // an active lane's group is its rank among the active lanes
     const int src = (active ? __popcll(actmask & ((1ull << lane) - 1ull)) : 0) << lg;
     lp = __shfl(lp_g, src);
     dlp = __shfl(dlp_g, src);
     alpha_out = __shfl(c.alpha, src);
+    MARK("spread:pickup_end");
 }
 
 template <bool MAP, int MINW>
@@ -713,6 +733,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
          if (A.stamps && lane == 0) A.stamps[gwave * kStampSlots + 0] = __builtin_amdgcn_s_memrealtime();)
 
     for (;;) {
+        MARK("tick:begin");
         // ---- refill: lanes without a row pull the next ones from the queue -----------------
 #pragma unroll 1
         for (int attempt = 0; attempt < (MAP ? 4 : 10); attempt++) {
@@ -797,6 +818,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
         }
         if (__ballot(phase != PH_DONE) == 0ull) break;
+        MARK("tick:refill_end");
         // warm the lines of the rows this wave hands out next (its private chunk continues at chunk_next): the load is consumed one
         // tick later (pf_acc), long after it has landed, so the next refill finds its rows in the cache instead of in HBM
         pf_acc ^= pf_val;
@@ -861,6 +883,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         }
 
         // ---- evaluate -------------------------------------------------------------------------
+        MARK("tick:choose_point_end");
         double l_new = 0, dl_new = 0, alpha_new = 0;
         const bool active = phase != PH_DONE && phase != PH_NEED;
         const unsigned long long actmask = __ballot(active);
@@ -892,6 +915,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             eval_point(s_nf, s_y, s_tab, lane, slot, S, gmask, p2, a_eval, MAP, pm_e, prior_isig, l_new,
                        dl_new, alpha_new, s_logtab);
         }
+        MARK("tick:evaluate_end");
         bool burst_done = false;  // this lane owns the burst: l_new / hk now describe the best of the 20 points
         if (burst_owner >= 0) {
             const bool part = helper || lane == burst_owner;
@@ -910,6 +934,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         }
 
         // ---- advance the per-lane state machine ---------------------------------------------
+        MARK("tick:burst_reduce_end");
         bool finished = false;  // line search over: decide between result and grid fallback
         double result = 0;
         bool have_result = false;
@@ -1006,6 +1031,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
             phase = PH_NEED;
         }
+        MARK("tick:state_machine_end");
     }
     if (A.prefetch == 0x7fffffff) A.w.queue[8 + (pf_acc & 7)] = pf_acc;  // (never: keeps the warming loads alive)
     DIAG(if (A.stamps && lane == 0) {

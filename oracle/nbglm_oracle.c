@@ -48,6 +48,7 @@ void oracle_nbglm_default_opts(oracle_nbglm_opts *o) {
     o->trendCoef[0] = o->trendCoef[1] = NAN;
     o->fitType = 0;
     o->noLocalSubstitute = 0;
+    o->dispFitIn = NULL;
     o->varLogDispEsts = NAN;
     o->xim = NAN;
 }
@@ -589,7 +590,9 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
     double coefs[2] = {NAN, NAN};
     int32_t outer = 0;
     int trc = 0;
-    if (!isnan(o.trendCoef[0]) && !isnan(o.trendCoef[1])) { /* dispersionFunction<- : a caller-supplied trend */
+    if (o.dispFitIn) { /* the fitted values themselves are given (below) */
+        if (o.fitType == 2) status |= ORACLE_ST_TREND_LOCAL;
+    } else if (!isnan(o.trendCoef[0]) && !isnan(o.trendCoef[1])) { /* dispersionFunction<- : a caller-supplied trend */
         coefs[0] = o.trendCoef[0];
         coefs[1] = o.trendCoef[1];
     } else if (o.fitType == 1) {
@@ -617,7 +620,7 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
      * ("a local regression fit was automatically substituted") — locfit_oracle.c */
     oracle_locfit lfit;
     int use_local = 0;
-    if (o.fitType == 2 || (o.fitType == 0 && trc && isnan(o.trendCoef[0]) && !o.noLocalSubstitute)) {
+    if (!o.dispFitIn && (o.fitType == 2 || (o.fitType == 0 && trc && isnan(o.trendCoef[0]) && !o.noLocalSubstitute))) {
         trc = oracle_local_dispersion_fit(fm, fd, nfit, &lfit);
         if (!trc) {
             use_local = 1;
@@ -633,7 +636,7 @@ int oracle_nbglm_fit(const int32_t *counts, const double *nf, int64_t n, int32_t
     /* varLogDispEsts = mad(log dispGeneEst - log dispFit)[dispGeneEst >= 100*minDisp]^2 */
     int64_t nres = 0;
     for (int64_t i = 0; i < n; i++) {
-        dispFit[i] = allZero[i] ? NAN : (use_local ? exp(oracle_locfit_eval(&lfit, log(baseMean[i]))) : coefs[0] + coefs[1] / baseMean[i]);
+        dispFit[i] = allZero[i] ? NAN : (o.dispFitIn ? o.dispFitIn[i] : use_local ? exp(oracle_locfit_eval(&lfit, log(baseMean[i]))) : coefs[0] + coefs[1] / baseMean[i]);
         SET(dispFit, i, dispFit[i]);
         if (!allZero[i] && dispGene[i] >= 100 * o.minDisp) fm[nres++] = log(dispGene[i]) - log(dispFit[i]);
     }

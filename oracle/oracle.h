@@ -38,6 +38,8 @@ typedef struct {
     int32_t noLocalSubstitute; /* 1: a failed parametric fit is reported (ORACLE_ST_TREND_FAILED) and the coefficients reached are kept */
     double varLogDispEsts; /* NaN = estimate (mad^2 of the log residuals); else as given: lets a SLICE of a larger fit be checked with
                               all three global scalars (trend, prior variance, this) pinned to the whole fit's */
+    const double *dispFitIn; /* NULL = fit the trend; else the fitted dispersions themselves, one per row (DESeq2: mcols(dds)$dispFit given):
+                              lets everything downstream of a LOCAL trend be checked under the trend of the fit it is compared with */
     double xim;            /* NaN = estimate (mean_j 1 / colMeans(nf)_j, momentsDispEstimate); else as given — the fourth global scalar: it
                               enters every row's start value alpha_init = min(roughDisp, momentsDisp), hence where the search stops */
 } oracle_nbglm_opts;

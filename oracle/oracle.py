@@ -35,7 +35,7 @@ class Opts(C.Structure):
                 ("maxit", C.c_int32), ("betaMaxit", C.c_int32), ("betaTol", C.c_double),
                 ("minmu", C.c_double), ("outlierSD", C.c_double), ("dispPriorVar", C.c_double),
                 ("nthreads", C.c_int32), ("_pad", C.c_int32), ("trendCoef", C.c_double * 2), ("fitType", C.c_int32),
-                ("noLocalSubstitute", C.c_int32), ("varLogDispEsts", C.c_double), ("xim", C.c_double)]
+                ("noLocalSubstitute", C.c_int32), ("varLogDispEsts", C.c_double), ("dispFitIn", C.c_void_p), ("xim", C.c_double)]
 
 
 _PD, _PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)
@@ -128,6 +128,9 @@ def default_opts(**kw) -> Opts:
     for k, v in kw.items():
         if k == "trendCoef":
             o.trendCoef[0], o.trendCoef[1] = float(v[0]), float(v[1])
+        elif k == "dispFitIn":  # per-row fitted dispersions (kept alive on the struct)
+            o._dispFitIn = np.ascontiguousarray(v, dtype=np.float64)
+            o.dispFitIn = o._dispFitIn.ctypes.data
         else:
             setattr(o, k, v)
     return o

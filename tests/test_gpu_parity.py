@@ -2,10 +2,12 @@
 same seeded inputs, and against the reference's golden table where it pins something.
 
 Bar (BASELINE.json north_star): log2FoldChange and Wald p within 1e-6 relative; integer work
-bit-exact.  The dispersion line search and the IRLS stop on data-dependent tolerance tests, so
-a last-bit difference between libm and the device math can flip one stopping decision in a
-rare row; the tests therefore require >= 99.9 % of rows within 1e-6 AND every row within a
-loose bound, and print the exact counts."""
+bit-exact.  The dispersion line searches and the IRLS stop on data-dependent tolerance tests, so
+a last-bit difference between libm and the device math can flip one stopping decision in a rare
+row.  There is NO blanket allowance for that any more: every fit is compared with the oracle run
+under the same global scalars (`explain_fit` -> `assert_rows_explained`), where EVERY row must be
+within the bounds or on a list whose every entry a referee explains (binary128 re-run of the line
+search, trace of the IRLS); `check_close` requires every row within its tolerance."""
 import os
 
 import numpy as np
@@ -39,27 +41,21 @@ def rel(a, b):
 PARITY_LOG = []  # every comparison of this module; tests/conftest.py writes it to gpurun_out/parity_gpu.json
 
 
-def check_close(name, got, ref, mask, tol=1e-6, frac=None, loose=None, noise_rows=0):
-    """>= `frac` of the rows within `tol` AND every row (but at most `noise_rows` explicitly allowed ones) within
-    `loose`.  frac defaults to 0.9999 from 20 000 rows up, 0.999 below; loose to 1e-3 (p-values 1e-2)."""
+def check_close(name, got, ref, mask, tol=1e-6):
+    """EVERY row of `mask` within `tol` (relative).  For columns without data-dependent stopping decisions, or for rows
+    that `assert_rows_explained` has already found free of them."""
     import inspect
     r = rel(got[mask], ref[mask])
     n = int(mask.sum())
-    if frac is None:
-        frac = 0.9999 if n >= 20000 else 0.999
-    if loose is None:
-        loose = 1e-2 if "pvalue" in name or "padj" in name else 1e-3
     ok = r <= tol
-    off_loose = int((r > loose).sum())
     test = next((f.function for f in inspect.stack() if f.function.startswith("test_")), "?")
     PARITY_LOG.append(dict(test=test, column=name, rows=n, tol=tol, max_rel=float(r.max()) if n else 0.0, rows_off=int((~ok).sum()),
-                           frac_within=float(ok.mean()) if n else 1.0, required_frac=frac, loose=loose, rows_beyond_loose=off_loose,
-                           noise_rows_allowed=noise_rows))
-    print(f"{name}: n={n} max rel {r.max():.3e} within {tol:g}: {ok.mean():.6f} ({(~ok).sum()} rows off, {off_loose} beyond {loose:g})")
+                           frac_within=float(ok.mean()) if n else 1.0, required_frac=1.0, loose=None, rows_beyond_loose=0,
+                           noise_rows_allowed=0))
+    print(f"{name}: n={n} max rel {r.max() if n else 0.0:.3e} within {tol:g}: {ok.mean() if n else 1.0:.6f} ({(~ok).sum()} rows off)")
     if os.environ.get("CHICDIFF_PARITY_RECORD_ONLY") == "1":  # survey run: collect the numbers, judge nothing
         return
-    assert ok.mean() >= frac, name
-    assert off_loose <= noise_rows, (name, float(r.max()))
+    assert ok.all(), (name, float(r.max()), np.flatnonzero(mask)[~ok][:10])
 
 
 WANT = ["baseMean", "baseVar", "dispGeneEst", "dispFit", "dispMAP", "dispersion", "log2FoldChange", "lfcSE", "stat",
@@ -86,31 +82,30 @@ def test_fit_parity_two_groups(ctx, oracle, n, S):
     assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-7)
     assert np.isclose(sc["varLogDispEsts"], ref["varLogDispEsts"], rtol=1e-7)
     assert np.isclose(sc["dispPriorVar"], ref["dispPriorVar"], rtol=1e-7)
-    check_close("baseMean", got["baseMean"], ref["baseMean"], nz, 1e-13, 1.0)
-    check_close("baseVar", got["baseVar"], ref["baseVar"], nz & (ref["baseVar"] > 0), 1e-11, 1.0)
+    check_close("baseMean", got["baseMean"], ref["baseMean"], nz, 1e-13)
+    check_close("baseVar", got["baseVar"], ref["baseVar"], nz & (ref["baseVar"] > 0), 1e-11)
     # gene-wise estimates at the floor (alpha < 1e-6, i.e. 1/alpha > 1e6): the profile likelihood is flat to
     # within its own rounding noise there (DESeq2 included) and the grid argmax is decided by that noise;
     # such rows are excluded from the trend (alpha > 1e-6 rule) and restart from the trend in the MAP step,
     # so only "both at the floor" is required of them
     floor = ref["dispGeneEst"] < 1e-6
     assert np.all(got["dispGeneEst"][nz & floor] < 1e-6)
-    check_close("dispGeneEst", got["dispGeneEst"], ref["dispGeneEst"], nz & ~floor, 1e-6)
-    check_close("dispFit", got["dispFit"], ref["dispFit"], nz, 1e-7, 1.0)
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
-    check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6)
-    check_close("lfcSE", got["lfcSE"], ref["lfcSE"], nz, 1e-6)
-    check_close("pvalue", got["pvalue"], ref["pvalue"], nz, 1e-6)
-    check_close("deviance", got["deviance"], ref["deviance"], nz, 1e-6)
-    mc = nz & np.isfinite(ref["maxCooks"])
+    # every row of the fit against the oracle under the GPU's trend: within the bounds or refereed
+    ref_g, listed = explain_fit(f"{n} x {S}", oracle, d["counts"], d["nf"], d["group"], got, sc)
+    clean = nz & ~listed
+    check_close("dispFit", got["dispFit"], ref_g["dispFit"], nz, 1e-12)
+    check_close("lfcSE", got["lfcSE"], ref_g["lfcSE"], clean, 1e-6)
+    check_close("deviance", got["deviance"], ref_g["deviance"], clean, 1e-6)
+    mc = nz & np.isfinite(ref_g["maxCooks"])
     assert mc.sum() == nz.sum()
-    check_close("maxCooks", got["maxCooks"], ref["maxCooks"], mc & (ref["maxCooks"] > 1e-12), 1e-5)
+    check_close("maxCooks", got["maxCooks"], ref_g["maxCooks"], clean & (ref_g["maxCooks"] > 1e-12), 1e-5)
     # rows sitting at alpha = minDisp (1/alpha = 1e8) search on pure cancellation noise in DESeq2 as well:
     # their iteration count is not reproducible across libm implementations, their estimate (1e-8) is.
-    interior = nz & (ref["dispGeneEst"] > 1e-6)
-    assert np.mean(got["dispGeneIter"][interior] == ref["dispGeneIter"][interior]) > 0.999
-    assert np.mean(got["dispIter"][nz] == ref["dispIter"][nz]) > 0.999
-    assert np.mean(got["betaIter"][nz] == ref["betaIter"][nz]) > 0.999
-    assert np.array_equal(got["dispOutlier"][nz], ref["dispOutlier"][nz]) or np.mean(got["dispOutlier"][nz] == ref["dispOutlier"][nz]) > 0.9999
+    interior = clean & (ref_g["dispGeneEst"] > 1e-6)
+    same_it = got["dispGeneIter"][interior] == ref_g["dispGeneIter"][interior]
+    print(f"gene-wise iteration counts equal on {same_it.sum()} of {interior.sum()} unlisted interior rows; MAP / IRLS step counts on unlisted rows compared exactly")
+    assert np.array_equal(got["dispIter"][clean], ref_g["dispIter"][clean]) and np.array_equal(got["betaIter"][clean], ref_g["betaIter"][clean])
+    assert np.array_equal(got["dispOutlier"][clean], ref_g["dispOutlier"][clean])
     assert np.all(np.isnan(got["pvalue"][~nz])) and np.all(np.isnan(got["log2FoldChange"][~nz]))
     assert np.isnan(sc["sumDeviance"]) == bool((~nz).any())
 
@@ -119,11 +114,8 @@ def test_fit_parity_2v2_with_prior(ctx, oracle):
     d = synth.make(20000, 4)
     got, sc = run_fit(ctx, d, d["group"], dispPriorVar=0.8)
     ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], dispPriorVar=0.8)
-    nz = ref["allZero"] == 0
-    assert sc["dispPriorVar"] == 0.8
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
-    check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], nz & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6)
-    check_close("pvalue", got["pvalue"], ref["pvalue"], nz, 1e-6)
+    assert sc["dispPriorVar"] == 0.8 and np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6)
+    explain_fit("20000 x 4 (2v2), dispPriorVar given", oracle, d["counts"], d["nf"], d["group"], got, sc, dispPriorVar=0.8)
     assert np.all(np.isnan(got["maxCooks"]))
     # without a caller-supplied prior the closed form is used and flagged
     _, sc2 = run_fit(ctx, d, d["group"])
@@ -140,9 +132,10 @@ def test_fit_parity_intercept_only(ctx, oracle, S):
     got, sc = run_fit(ctx, d, g, dispPriorVar=0.6)
     ref = oracle.nbglm_fit(d["counts"], d["nf"], g, dispPriorVar=0.6)
     nz = np.ones(len(d["counts"]), bool)
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
-    check_close("intercept", got["intercept"], ref["beta0"], nz, 1e-12, 1.0)
-    check_close("deviance", got["deviance"], ref["deviance"], nz, 1e-6)
+    assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6)
+    ref_g, listed = explain_fit(f"design ~1, S = {S}", oracle, d["counts"], d["nf"], g, got, sc, dispPriorVar=0.6)
+    check_close("intercept", got["intercept"], ref_g["beta0"], nz, 1e-12)
+    check_close("deviance", got["deviance"], ref_g["deviance"], nz & ~listed, 1e-6)
     assert np.isclose(sc["sumDeviance"], ref["sumDeviance"], rtol=1e-7)
     assert np.all(np.isnan(got["log2FoldChange"]))
 
@@ -332,9 +325,7 @@ def test_host_entry_point_and_errors(ctx, oracle):
     from chicdiff_amd import hip
     d = synth.make(3000, 8)
     res, sc = ctx.nbglm_fit_host(d["counts"], d["nf"], d["group"])
-    ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"])
-    nz = ref["allZero"] == 0
-    check_close("pvalue(host)", res["pvalue"], ref["pvalue"], nz, 1e-6)
+    explain_fit("host entry point, 3000 x 8", oracle, d["counts"], d["nf"], d["group"], res, sc)
     with pytest.raises(hip.ChicdiffHipError):
         ctx.nbglm_fit_host(d["counts"], d["nf"], [0, 0, 1, 1, 2, 2, 0, 1])
     with pytest.raises(hip.ChicdiffHipError):
@@ -463,22 +454,37 @@ def test_deseq2wrap_mirror(ctx, oracle, tmp_path, norm):
         tt = settings["theta_grid"][int(np.argmin(devs))]
         assert out.attrs["theta"] == tt
         nf = oracle.offsets(FM, sf, tt)
-    ref = oracle.nbglm_fit(N, nf, group)
-    check_close("lfc", out["log2FoldChange"].to_numpy(), ref["log2FoldChange"], np.abs(ref["log2FoldChange"]) > 1e-3, 1e-6)
-    pv, nout = results.cooks_filter(ref["pvalue"], ref["maxCooks"], ref["cooksArgmax"], lambda idx: N[idx], group)
+    # the table's numbers are those of the library's fit on the same matrices (bit for bit: the same calls the mirror makes),
+    # and that fit is the oracle's: every row within the bounds or refereed
+    import torch
+    dN, dFM = ctx.window_sums(ctx.to_device(fN, np.int32), ctx.to_device(fM, np.float64), torch.as_tensor(rp).to(ctx.device))
+    sf_dev = ctx.size_factors(dN)
+    assert np.allclose(sf_dev, sf, rtol=1e-13)
+    if norm == "standard":
+        dnf = torch.as_tensor(sf_dev, device=ctx.device)[:, None].expand(8, n).contiguous()
+    else:
+        dnf = ctx.offsets(dFM, sf_dev, None if norm == "fullmean" else out.attrs["theta"])
+    assert np.allclose(dnf.cpu().numpy().T, nf, rtol=1e-12)
+    fit, sc = ctx.nbglm_fit(dN, dnf, group, want=WANT + ["cooksArgmax"])
+    got = {k: v.cpu().numpy() for k, v in fit.items()}
+    ref, listed = explain_fit(f"DESeq2Wrap mirror, norm = {norm}", oracle, N, dnf.cpu().numpy().T, group, got, sc)
+    for col in ("baseMean", "log2FoldChange", "lfcSE", "stat"):
+        assert np.array_equal(out[col].to_numpy(), got[col], equal_nan=True), col
+    pv, nout = results.cooks_filter(got["pvalue"], got["maxCooks"], got["cooksArgmax"], lambda idx: N[idx], group)
+    pv_o, nout_o = results.cooks_filter(ref["pvalue"], ref["maxCooks"], ref["cooksArgmax"], lambda idx: N[idx], group)
     got_p = out["pvalue"].to_numpy()
-    assert np.array_equal(np.isnan(got_p), np.isnan(pv)) and nout > 0  # Cook's outliers flagged identically (4v4)
+    assert np.array_equal(np.isnan(got_p), np.isnan(pv)) and nout > 0  # Cook's outliers flagged (4v4) ...
+    assert np.array_equal(np.isnan(pv)[~listed], np.isnan(pv_o)[~listed])  # ... as the oracle flags them
+    assert np.array_equal(got_p, pv, equal_nan=True)
     # rows whose IRLS diverged on the injected outliers go through the optim fallback on both sides (the
     # posterior mode DESeq2's L-BFGS-B call targets); they must be re-fitted, not left flagged
     assert (ref["betaIter"] >= 100).sum() > 0 and np.all(ref["betaConv"][ref["allZero"] == 0] == 1)
-    conv = ref["betaConv"] == 1
-    ok = ~np.isnan(pv) & conv
-    check_close("pvalue", got_p, pv, ok, 1e-6)
-    padj_ref, _ = results.independent_filtering(ref["baseMean"], pv)
-    got = out["padj"].to_numpy()
-    assert np.array_equal(np.isnan(got), np.isnan(padj_ref))
-    okp = ~np.isnan(padj_ref) & conv
-    check_close("padj", got, padj_ref, okp, 1e-6)
+    # results(): independent filtering + BH of the table's own p-values by the host restatement the golden table pins
+    padj_ref, _ = results.independent_filtering(out["baseMean"].to_numpy(), got_p)
+    gpadj = out["padj"].to_numpy()
+    assert np.array_equal(np.isnan(gpadj), np.isnan(padj_ref))
+    okp = ~np.isnan(padj_ref)
+    assert np.allclose(gpadj[okp], padj_ref[okp], rtol=1e-12)
     # annotation: window bounds and rmap coordinates (chicdiff.R:1703-1714)
     r0 = out.iloc[0]
     assert r0["minOE"] == RU[RU.regionID == 1].otherEndID.min() and r0["OEstart"] == (r0["minOE"] - 1) * 1000 + 1
@@ -564,16 +570,18 @@ def assert_rows_explained(tag, oracle, d, group, got, ref, dispPriorVar, maxit=1
       map  : MAP line search ended elsewhere              -> binary128 re-run (stage 1) sides with one side
       irls : the IRLS stopped one step apart              -> conv_test at the disputed step is within 1e-3 of betaTol, and each
                                                              side's estimate is the trace's iterate at its own step count
+    Design ~1 (group all zero) has no IRLS: the intercept (log2 scale) takes the fold change's place.
     No blanket allowance: returns the list (written to gpurun_out/ for profiles/)."""
     n = len(ref["allZero"])
     live = ref["allZero"] == 0
     listed = []
+    two_groups = bool(np.any(np.asarray(group) != 0))
     # gene-wise stage (the caller may have arbitrated these rows already)
     gene_off = np.flatnonzero(live & ((ref["dispGeneEst"] > 1e-6) | (got["dispGeneEst"] > 1e-6)) & (rel(got["dispGeneEst"], ref["dispGeneEst"]) > 1e-6))
     if gene_listed is None:
         arb = oracle.arbitrate_disp(d["counts"], d["nf"], group, gene_off, ref) if len(gene_off) else np.empty(0)
         eg, eo = rel(got["dispGeneEst"][gene_off], arb), rel(ref["dispGeneEst"][gene_off], arb)
-        assert int(((eg > 1e-6) & (eo > 1e-6)).sum()) <= 2, (tag, "gene-wise rows neither side gets right")
+        assert int(((eg > 1e-6) & (eo > 1e-6)).sum()) <= 2, (tag, "gene-wise rows neither side gets right", gene_off[(eg > 1e-6) & (eo > 1e-6)])
         listed += [dict(row=int(i), kind="gene", gpu=float(got["dispGeneEst"][i]), oracle=float(ref["dispGeneEst"][i]), referee=float(a))
                    for i, a in zip(gene_off, arb)]
     else:
@@ -582,7 +590,7 @@ def assert_rows_explained(tag, oracle, d, group, got, ref, dispPriorVar, maxit=1
     in_gene[gene_off] = True
     if gene_listed is not None:
         in_gene[np.asarray(sorted(gene_listed), dtype=np.int64)] = True
-    assert len(gene_off) <= 3e-5 * live.sum(), (tag, len(gene_off))
+    assert len(gene_off) <= 3e-5 * live.sum() + 2, (tag, len(gene_off))   # (a sanity bound on the list's length: each entry is refereed)
     # MAP stage, rows whose gene-wise estimates agree
     assert np.allclose(got["dispFit"][live], ref["dispFit"][live], rtol=1e-12), tag   # same trend on both sides
     map_off = np.flatnonzero(live & ~in_gene & (rel(got["dispMAP"], ref["dispMAP"]) > 1e-6))
@@ -615,8 +623,9 @@ def assert_rows_explained(tag, oracle, d, group, got, ref, dispPriorVar, maxit=1
     wald_listed[flip] = True
     chk = live & ~wald_listed
     assert np.array_equal(got["betaConv"][chk], ref["betaConv"][chk]), tag
-    dl = np.abs(got["log2FoldChange"] - ref["log2FoldChange"])
-    bad = chk & ~(dl <= 1e-6 * np.maximum(np.abs(ref["log2FoldChange"]), 1e-2))
+    coef_got, coef_ref = (got["log2FoldChange"], ref["log2FoldChange"]) if two_groups else (got["intercept"], ref["beta0"])
+    dl = np.abs(coef_got - coef_ref)
+    bad = chk & ~(dl <= 1e-6 * np.maximum(np.abs(coef_ref), 1e-2))
     assert not bad.any(), (tag, "log2FoldChange off on unlisted rows", np.flatnonzero(bad)[:10], dl[bad][:10])
     z2 = np.maximum(1.0, ref["stat"] ** 2)
     badp = chk & ~(rel(got["pvalue"], ref["pvalue"]) <= 1e-6 * z2)
@@ -624,12 +633,38 @@ def assert_rows_explained(tag, oracle, d, group, got, ref, dispPriorVar, maxit=1
     n_optim = int((chk & optim).sum())   # rows through the optim fallback are held to the same bounds (not masked)
     kinds = {k: sum(1 for x in listed if x["kind"] == k) for k in ("gene", "map", "irls")}
     print(f"{tag}: {int(live.sum())} rows, every one within bounds except {len(listed)} refereed rows {kinds}; {n_optim} optim-fallback rows inside the bounds; "
-          f"max rel dispersion {rd[chk].max():.2e}, lfc {(dl[chk] / np.maximum(np.abs(ref['log2FoldChange'][chk]), 1e-2)).max():.2e}, "
+          f"max rel dispersion {rd[chk].max():.2e}, lfc {(dl[chk] / np.maximum(np.abs(coef_ref[chk]), 1e-2)).max():.2e}, "
           f"p/(z^2) {(rel(got['pvalue'], ref['pvalue'])[chk] / z2[chk]).max():.2e}")
     PARITY_LOG.append(dict(test="assert_rows_explained", column=tag, rows=int(live.sum()), tol=1e-6, max_rel=float(rd[chk].max()), rows_off=len(listed),
                            frac_within=1.0 - len(listed) / max(int(live.sum()), 1), required_frac=1.0, loose=None, rows_beyond_loose=0,
                            noise_rows_allowed=0, refereed=kinds))
     return listed, wald_listed
+
+
+def explain_fit(tag, oracle, counts, nf, group, got, sc, rows=None, **oracle_kw):
+    """A GPU fit (free: its own trend) against the oracle run under the GPU's trend — the two then share their global scalars
+    up to the prior variance the oracle derives from (almost) the same residuals — through `assert_rows_explained`: every
+    row within the bounds or refereed.  A local trend (status bit 16) is handed over as its fitted values (oracle option
+    dispFitIn), a parametric one as its two coefficients.  `rows` (bool mask) restricts the row-level comparison.
+    Returns (oracle fit under the GPU's trend, mask of rows on the refereed list)."""
+    kw = dict(oracle_kw)
+    if sc["status"] & 16:
+        kw.update(fitType=2, dispFitIn=np.nan_to_num(got["dispFit"]))
+    else:
+        kw["trendCoef"] = sc["trendCoef"]
+    ref_g = oracle.nbglm_fit(counts, nf, group, **kw)
+    assert np.array_equal(got["allZero"], ref_g["allZero"]), tag
+    assert np.isclose(sc["varLogDispEsts"], ref_g["varLogDispEsts"], rtol=1e-5), (tag, sc["varLogDispEsts"], ref_g["varLogDispEsts"])
+    assert np.isclose(sc["dispPriorVar"], ref_g["dispPriorVar"], rtol=1e-5), (tag, sc["dispPriorVar"], ref_g["dispPriorVar"])
+    if rows is None:
+        listed, wl = assert_rows_explained(tag, oracle, dict(counts=counts, nf=nf), group, got, ref_g, ref_g["dispPriorVar"], maxit=oracle_kw.get("betaMaxit", 100))
+        return ref_g, wl
+    cut = lambda f: {k: (v[rows] if isinstance(v, np.ndarray) and v.shape[:1] == rows.shape else v) for k, v in f.items()}
+    listed, wl_sub = assert_rows_explained(tag, oracle, dict(counts=counts[rows], nf=nf[rows]), group, cut(got), cut(ref_g), ref_g["dispPriorVar"],
+                                           maxit=oracle_kw.get("betaMaxit", 100))
+    wl = np.zeros(len(rows), dtype=bool)
+    wl[np.flatnonzero(rows)[wl_sub]] = True
+    return ref_g, wl
 
 
 def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
@@ -661,8 +696,6 @@ def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     got = {k: v.cpu().numpy() for k, v in out.items()}
     threads = min(16, os.cpu_count() or 1)
     ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], nthreads=threads)
-    nz = (ref["allZero"] == 0) & (ref["betaConv"] == 1)
-    big = nz & (np.abs(ref["log2FoldChange"]) > 1e-2)
     print("trend", sc["trendCoef"], ref["trendCoef"], sc["trendOuterIter"], ref["trendOuterIter"])
     assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=2e-5) and sc["trendOuterIter"] == ref["trendOuterIter"]
     # (1) rows that enter the trend on either side (alpha > 1e-6) and differ: list and arbitrate
@@ -754,8 +787,6 @@ def test_full_size_C2_200k_x4_2v2_against_oracle(ctx, oracle):
     ref_g = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], nthreads=min(16, os.cpu_count() or 1), trendCoef=sc["trendCoef"])
     assert ref_g["dispPriorVar"] == sc["dispPriorVar"]
     assert_rows_explained("C2 (200 000 x 4, 2v2), GPU free fit vs oracle under the GPU's trend", oracle, d, d["group"], got, ref_g, sc["dispPriorVar"])
-    nz = (ref["allZero"] == 0) & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
-    check_close("dispersion(C2, free vs free)", got["dispersion"], ref["dispersion"], nz, 1e-5, 0.9999)
     assert np.all(np.isnan(got["maxCooks"]))  # no group with >= 3 replicates
     # a heterogeneous 2v2 matrix of the same size: the prior variance lands above DESeq2's 0.25 floor
     from test_oracle import heterogeneous_counts
@@ -764,9 +795,9 @@ def test_full_size_C2_200k_x4_2v2_against_oracle(ctx, oracle):
     ref = oracle.nbglm_fit(counts, nf, d["group"], nthreads=min(16, os.cpu_count() or 1))
     print("heterogeneous: dispPriorVar", sc["dispPriorVar"], ref["dispPriorVar"])
     assert sc["dispPriorVar"] == ref["dispPriorVar"] and sc["dispPriorVar"] > 0.3
-    nz = (ref["allZero"] == 0) & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
-    check_close("dispersion(C2 heterogeneous)", got["dispersion"], ref["dispersion"], nz, 1e-6)
-    check_close("pvalue(C2 heterogeneous)", got["pvalue"], ref["pvalue"], nz, 1e-6)
+    assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6)
+    ref_g, _ = explain_fit("C2 heterogeneous (200 000 x 4, 2v2)", oracle, counts, nf, d["group"], got, sc, nthreads=min(16, os.cpu_count() or 1))
+    assert ref_g["dispPriorVar"] == sc["dispPriorVar"]
 
 
 def _two_rank_worker(rank, world, port, n, S, q):
@@ -1245,10 +1276,7 @@ def test_fit_edge_shapes(ctx, oracle, n, S, nB):
     nz = ref["allZero"] == 0
     assert np.array_equal(got["allZero"], ref["allZero"])
     assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6, equal_nan=True)
-    conv = nz & (ref["betaConv"] == 1)
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
-    check_close("log2FoldChange", got["log2FoldChange"], ref["log2FoldChange"], conv & (np.abs(ref["log2FoldChange"]) > 1e-3), 1e-6)
-    check_close("pvalue", got["pvalue"], ref["pvalue"], conv, 1e-6)
+    explain_fit(f"edge shape {n} x {S} ({S - nB}v{nB})", oracle, counts, nf, group, got, sc)
 
 
 def _extreme_matrix():
@@ -1284,8 +1312,7 @@ def test_fit_type_mean_and_trend_failure(ctx, oracle):
     ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], trendCoef=sc["trendCoef"])
     nz = ref["allZero"] == 0
     assert np.nanmax(got["dispFit"]) == np.nanmin(got["dispFit"]) == sc["trendCoef"][0]
-    check_close("dispersion(fitType mean)", got["dispersion"], ref["dispersion"], nz, 1e-6)
-    check_close("pvalue(fitType mean)", got["pvalue"], ref["pvalue"], nz & (ref["betaConv"] == 1), 1e-6)
+    assert_rows_explained("fitType mean, 30000 x 8", oracle, d, d["group"], got, ref, ref["dispPriorVar"])
     # a matrix on which the parametric fit fails (300 rows with counts ~1e9): with DESeq2's substitution switched off the
     # failure is reported on both sides (status bit 1), and fitType = "mean" is a clean way out
     counts, nf, group, _ = _extreme_matrix()
@@ -1318,11 +1345,12 @@ def test_fit_type_local_and_local_substitute(ctx, oracle):
         use = nz & (got["dispGeneEst"] > 1e-6)
         _, pred = oracle.local_dispersion_fit(ref["baseMean"][use], got["dispGeneEst"][use])
         assert np.allclose(got["dispFit"][nz], np.exp(pred(np.log(ref["baseMean"][nz]))), rtol=1e-9)
-        check_close("dispFit(local)", got["dispFit"], ref["dispFit"], nz, 1e-6, frac=0.999, loose=1e-3)
-        assert np.isclose(sc["varLogDispEsts"], ref["varLogDispEsts"], rtol=1e-5) and np.isclose(sc["dispPriorVar"], ref["dispPriorVar"], rtol=1e-5)
-        conv = nz & (ref["betaConv"] == 1)
-        check_close("dispersion(local)", got["dispersion"], ref["dispersion"], nz, 1e-6, frac=0.998)
-        check_close("pvalue(local)", got["pvalue"], ref["pvalue"], conv, 1e-6, frac=0.998)
+        # (the two FREE local trends differ where a noise-decided gene-wise row moved an order statistic of the fit: reported)
+        rf = rel(got["dispFit"][nz], ref["dispFit"][nz])
+        print(f"local trend {n} x {S}: free GPU vs free oracle dispFit max rel {rf.max():.2e}, rows beyond 1e-6: {int((rf > 1e-6).sum())}")
+        assert np.isclose(sc["varLogDispEsts"], ref["varLogDispEsts"], rtol=1e-4) and np.isclose(sc["dispPriorVar"], ref["dispPriorVar"], rtol=1e-4)
+        # everything downstream of the trend: the oracle under the GPU's fitted values, every row within the bounds or refereed
+        explain_fit(f"local trend, {n} x {S}", oracle, d["counts"], d["nf"], d["group"], got, sc)
     # the substitution: same results as asking for the local fit, on both sides
     counts, nf, group, big = _extreme_matrix()
     a, sa = run_fit(ctx, dict(counts=counts, nf=nf), group)
@@ -1333,16 +1361,23 @@ def test_fit_type_local_and_local_substitute(ctx, oracle):
     ref = oracle.nbglm_fit(counts, nf, group)
     assert (ref["status"] & 16) and not (ref["status"] & 1)
     nz = ref["allZero"] == 0
-    isbig = np.zeros(len(counts), bool)
-    isbig[big] = True
-    check_close("dispFit(substituted local fit)", a["dispFit"], ref["dispFit"], nz, 1e-3, frac=0.99, loose=0.1)
+    # the substituted trend is the oracle's local fit of the GPU's own gene-wise estimates (the free oracle fit's differs where the
+    # ~1e9 rows — noise-decided on both sides, test_fit_extreme_counts — moved an order statistic: reported)
+    use = nz & (a["dispGeneEst"] > 1e-6)
+    _, pred = oracle.local_dispersion_fit(ref["baseMean"][use], a["dispGeneEst"][use])
+    assert np.allclose(a["dispFit"][nz], np.exp(pred(np.log(ref["baseMean"][nz]))), rtol=1e-9)
+    rf = rel(a["dispFit"][nz], ref["dispFit"][nz])
+    print(f"substituted local trend: free GPU vs free oracle dispFit max rel {rf.max():.2e}, rows beyond 1e-3: {int((rf > 1e-3).sum())} of {int(nz.sum())}")
     # a design ~1 fit (the theta grid's) takes the same path
     g0 = np.zeros(8, dtype=np.int32)
     d = synth.make(8000, 8)
     got, sc = run_fit(ctx, d, g0, fitType=2)
     ref = oracle.nbglm_fit(d["counts"], d["nf"], g0, fitType=2)
-    check_close("dispFit(local, ~1)", got["dispFit"], ref["dispFit"], ref["allZero"] == 0, 1e-6, frac=0.999, loose=1e-3)
     nz = ref["allZero"] == 0
+    use = nz & (got["dispGeneEst"] > 1e-6)
+    _, pred = oracle.local_dispersion_fit(ref["baseMean"][use], got["dispGeneEst"][use])
+    assert np.allclose(got["dispFit"][nz], np.exp(pred(np.log(ref["baseMean"][nz]))), rtol=1e-9)
+    explain_fit("local trend, design ~1, 8000 x 8", oracle, d["counts"], d["nf"], g0, got, sc)
     assert np.isclose(np.sum(got["deviance"][nz]), np.sum(ref["deviance"][nz]), rtol=1e-7)  # what the theta grid sums
 
 
@@ -1369,10 +1404,10 @@ def test_fit_extreme_counts(ctx, oracle):
     nz = ref["allZero"] == 0
     isbig = np.zeros(n, bool)
     isbig[big] = True
-    check_close("baseMean", got["baseMean"], ref["baseMean"], nz, 1e-12, 1.0)
+    check_close("baseMean", got["baseMean"], ref["baseMean"], nz, 1e-12)
     # gene-wise estimates: ordinary rows to 1e-6; the ~1e9 rows are noise-decided on BOTH double-precision sides, so
     # each side is compared with the binary128 arbiter instead
-    check_close("dispGeneEst(ordinary rows)", got["dispGeneEst"], ref["dispGeneEst"], nz & ~isbig & (ref["dispGeneEst"] > 1e-6), 1e-6)
+    # (ordinary rows: explain_fit below, every row)
     bigrows = np.nonzero(nz & isbig)[0]
     arb = oracle.arbitrate_disp(counts, nf, group, bigrows, ref)
     eg, eo = rel(got["dispGeneEst"][bigrows], arb), rel(ref["dispGeneEst"][bigrows], arb)
@@ -1387,14 +1422,17 @@ def test_fit_extreme_counts(ctx, oracle):
     assert (rc != 0) == bool(sc["status"] & 1) == bool(ref["status"] & 1) and itg == sc["trendOuterIter"]
     assert np.allclose(cg, sc["trendCoef"], rtol=1e-9)
     assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-4)
-    ref = oracle.nbglm_fit(counts, nf, group, trendCoef=sc["trendCoef"])
-    conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
-    assert conv.sum() > 0.98 * nz.sum()
-    check_close("dispersion(ordinary rows)", got["dispersion"], ref["dispersion"], nz & ~isbig, 1e-6)
-    check_close("pvalue(ordinary rows)", got["pvalue"], ref["pvalue"], conv & ~isbig, 1e-6)
-    check_close("dispersion(counts ~1e9)", got["dispersion"], ref["dispersion"], nz & isbig, 2e-2, 0.97, loose=1.0)
+    # ordinary rows: every one within the bounds or refereed, under the GPU's trend
+    ref, _ = explain_fit("extreme-count matrix, the 3700 ordinary rows", oracle, counts, nf, group, got, sc, rows=~isbig)
+    # the ~1e9 rows: MAP estimates against the binary128 arbiter, as the gene-wise ones above (both double-precision sides are
+    # noise-decided there: the oracle's lgamma difference carries ~1e-5 of rounding noise, the search stops on 1e-6)
+    arb_m = oracle.arbitrate_disp(counts, nf, group, bigrows, dict(dispGeneEst=got["dispGeneEst"], dispFit=got["dispFit"], dispPriorVar=sc["dispPriorVar"]), stage="map")
+    em = rel(got["dispMAP"][bigrows], arb_m)
+    print(f"counts ~1e9, MAP vs binary128 arbiter (under the GPU's own gene-wise estimates, trend and prior): GPU median {np.median(em):.1e} max {em.max():.1e}")
+    assert np.median(em) < 1e-4 and np.mean(em < 2e-2) > 0.97
     # the IRLS stops on a relative deviance change of 1e-8 while the deviance itself (~250, the difference of two
     # ~1e10 sums) carries ~1e-5 of noise on both sides: fold changes agree to a few 1e-3 (absolute, log2 units)
+    conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
     irls = conv & isbig & (ref["betaIter"] < 100) & (got["betaIter"] < 100)
     assert irls.sum() > 150 and np.max(np.abs(got["log2FoldChange"][irls] - ref["log2FoldChange"][irls])) < 1e-2
     assert np.all(np.isfinite(got["log2FoldChange"][nz])) and np.all(np.isfinite(got["lfcSE"][nz]))
@@ -1499,9 +1537,9 @@ def test_independent_filtering_edge_cases(ctx):
 
 def test_fit_fuzz_shapes_and_designs(ctx, oracle):
     """Random sample counts, group splits and row counts (both designs) against the oracle: every configuration must
-    agree on the NA pattern and on >= 99 % of the rows to 1e-6 (small n makes single noise-decided rows visible)."""
+    agree on the NA pattern and on every row (within the bounds, or refereed: explain_fit)."""
     rng = np.random.default_rng(2024)
-    worst = 1.0
+    worst = 0
     for trial in range(14):
         S = int(rng.integers(3, 21))
         n = int(rng.integers(800, 4000))
@@ -1522,16 +1560,12 @@ def test_fit_fuzz_shapes_and_designs(ctx, oracle):
         nz = ref["allZero"] == 0
         assert np.array_equal(got["allZero"], ref["allZero"])
         assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6, equal_nan=True), (trial, sc["trendCoef"], ref["trendCoef"])
-        r = rel(got["dispersion"][nz], ref["dispersion"][nz])
-        worst = min(worst, float(np.mean(r < 1e-6)))
-        assert np.mean(r < 1e-6) > 0.99, (trial, S, n, group.tolist())
-        if group.any():
-            conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
-            rp = rel(got["pvalue"][conv], ref["pvalue"][conv])
-            assert np.mean(rp < 1e-6) > 0.99 and np.array_equal(np.isnan(got["pvalue"]), np.isnan(ref["pvalue"])), (trial, S, n)
-        else:
+        _, listed = explain_fit(f"fuzz trial {trial}: {n} x {S}, group {group.tolist()}", oracle, d["counts"], d["nf"], group, got, sc)
+        worst = max(worst, int(listed.sum()))
+        assert np.array_equal(np.isnan(got["pvalue"]), np.isnan(ref["pvalue"])), (trial, S, n)
+        if not group.any():
             assert np.isclose(sc["sumDeviance"], ref["sumDeviance"], rtol=1e-6, equal_nan=True)
-    print("fuzz: worst fraction of rows within 1e-6:", worst)
+    print("fuzz: most refereed rows in one configuration:", worst)
 
 
 @pytest.mark.parametrize("S,group", [(4, [0, 0, 1, 1]), (4, [0, 0, 0, 0]), (5, [0, 0, 1, 1, 1]), (3, [0, 0, 0])])
@@ -1546,11 +1580,9 @@ def test_prior_variance_by_simulation_matches_oracle(ctx, oracle, S, group):
     assert sc["status"] & 2 and ref["status"] & 2
     assert np.isclose(sc["varLogDispEsts"], ref["varLogDispEsts"], rtol=1e-7)
     assert sc["dispPriorVar"] == ref["dispPriorVar"] and sc["dispPriorVar"] > 0.3, (sc["dispPriorVar"], ref["dispPriorVar"])
-    nz = ref["allZero"] == 0
-    check_close("dispersion", got["dispersion"], ref["dispersion"], nz, 1e-6)
-    if group.any():
-        conv = nz & (ref["betaConv"] == 1) & (got["betaConv"] == 1)
-        check_close("pvalue", got["pvalue"], ref["pvalue"], conv, 1e-6)
+    assert np.allclose(sc["trendCoef"], ref["trendCoef"], rtol=1e-6)
+    ref_g, _ = explain_fit(f"prior variance by simulation, S = {S}, group {group.tolist()}", oracle, counts, nf, group, got, sc)
+    assert ref_g["dispPriorVar"] == sc["dispPriorVar"]
 
 
 def test_chinput_ingestion_on_device(ctx, oracle, tmp_path):
@@ -1673,28 +1705,30 @@ def test_pipeline_from_peaks_and_chinput_text_to_weighted_padj(ctx, oracle, gold
     assert np.allclose(dFM.cpu().numpy().T, FM_w, rtol=1e-13, equal_nan=True) and np.isnan(FM_w).any()
     # a4-a7 in one call, then a9
     theta = 0.5
-    want = ["baseMean", "log2FoldChange", "lfcSE", "stat", "pvalue", "maxCooks", "cooksArgmax"]
-    out, sc = ctx.wald_test(dN, dFM, group, theta=theta, want=want)
+    out, sc = ctx.wald_test(dN, dFM, group, theta=theta, want=WANT + ["cooksArgmax"])
+    got = {k: v.cpu().numpy().copy() for k, v in out.items()}   # (before the Cook's filter rewrites the p-values in place)
     sf = oracle.size_factors(N_w)
-    ref = oracle.nbglm_fit(N_w, oracle.offsets(FM_w, sf, theta), group)
     assert np.allclose(sc["sizeFactors"], sf, rtol=1e-12)
+    nf_dev = ctx.offsets(dFM, sc["sizeFactors"], theta).cpu().numpy().T   # the offsets the fused call formed (test_fused_wald_test_equals_composed_calls)
+    assert np.allclose(nf_dev, oracle.offsets(FM_w, sf, theta), rtol=1e-12)
+    # a4-a7: every row of the fit within the bounds of the oracle under the same trend, or refereed
+    ref, listed = explain_fit("pipeline from peaks and chinput text", oracle, N_w, nf_dev, group, got, sc)
+    # a9 on the device against the host restatement (pinned by the reference's golden table) fed the device's own numbers: exact
     cutoff = stats.f.ppf(0.99, 2, S - 2)
     ctx.cooks_filter(dN, group, out["maxCooks"], out["cooksArgmax"], out["pvalue"], cutoff)
+    p_twin, _ = results.cooks_filter(got["pvalue"], got["maxCooks"], got["cooksArgmax"], lambda idx: N_w[idx], group, cutoff=cutoff)
     p_ref, _ = results.cooks_filter(ref["pvalue"], ref["maxCooks"], ref["cooksArgmax"], lambda idx: N_w[idx], group, cutoff=cutoff)
     d_padj, info = ctx.independent_filtering(out["baseMean"], out["pvalue"])
-    padj_ref, info_ref = results.independent_filtering(ref["baseMean"], p_ref)
     got_p, got_padj = out["pvalue"].cpu().numpy(), d_padj.cpu().numpy()
-    assert np.array_equal(np.isnan(got_p), np.isnan(p_ref))
-    live = (ref["allZero"] == 0) & (ref["betaConv"] == 1)
-    check_close("pipeline log2FoldChange", out["log2FoldChange"].cpu().numpy(), ref["log2FoldChange"], live & (np.abs(ref["log2FoldChange"]) > 1e-2),
-                1e-6, frac=0.998, noise_rows=3)
-    check_close("pipeline pvalue", got_p, p_ref, live & ~np.isnan(p_ref), 1e-6, frac=0.998, noise_rows=3)
-    # the filter choice is a discrete decision on 50 rejection counts: when it agrees (it does unless a noise-decided
-    # row sits exactly on a rank boundary) padj follows p
-    assert abs(info["index"] - info_ref["index"]) <= 1
-    if info["index"] == info_ref["index"]:
-        assert np.array_equal(np.isnan(got_padj), np.isnan(padj_ref))
-        check_close("pipeline padj", got_padj, padj_ref, ~np.isnan(padj_ref), 1e-6, frac=0.998, noise_rows=3)
+    assert np.array_equal(got_p, p_twin, equal_nan=True)
+    assert np.array_equal(np.isnan(got_p)[~listed], np.isnan(p_ref)[~listed])    # the oracle flags the same Cook's outliers
+    padj_twin, info_twin = results.independent_filtering(got["baseMean"], got_p)
+    padj_ref, info_ref = results.independent_filtering(ref["baseMean"], p_ref)
+    assert info["index"] == info_twin["index"] and np.array_equal(np.isnan(got_padj), np.isnan(padj_twin))
+    okp = ~np.isnan(padj_twin)
+    assert np.allclose(got_padj[okp], padj_twin[okp], rtol=1e-12)
+    # (against the oracle's own p-values the filter choice is a discrete decision on 50 rejection counts: reported)
+    print(f"independent filtering: device index {info['index']}, on the oracle's p-values {info_ref['index']}")
     # f3: IHW application with the reference's trained weight table
     breaks, avWeights = ihw_tables_from_golden(golden)
     avDist = ((midsum[po.astype(np.int64).clip(1, nid) - 1] - midsum[pb.astype(np.int64) - 1]) / 2.0).astype(np.float64)
@@ -1814,8 +1848,8 @@ def test_full_size_C5_20M_x16_pipeline_properties_and_slice_parity(ctx, oracle):
     listed, wl = assert_rows_explained("C5 slice (200 000 of 20 M x 16), scalars pinned to the whole fit's", oracle, dict(counts=cs, nf=nfs), group, sl, ref,
                                        sc["dispPriorVar"])
     nz = (ref["allZero"] == 0) & ~wl
-    check_close("baseMean(C5 slice)", sl["baseMean"], ref["baseMean"], nz, 1e-13, 1.0)
-    check_close("maxCooks(C5 slice)", sl["maxCooks"], ref["maxCooks"], nz & (ref["maxCooks"] > 1e-12), 1e-5, 1.0)
+    check_close("baseMean(C5 slice)", sl["baseMean"], ref["baseMean"], nz, 1e-13)
+    check_close("maxCooks(C5 slice)", sl["maxCooks"], ref["maxCooks"], nz & (ref["maxCooks"] > 1e-12), 1e-5)
     # row permutation
     del av, ihw, w, wp
     perm = torch.randperm(n, device=dev, generator=g)
@@ -1937,11 +1971,18 @@ def test_chicdiffPipeline_mirror_from_peak_matrix_to_weighted_padj(ctx, oracle, 
     sf = oracle.size_factors(N_w)
     devs = [oracle.nbglm_fit(N_w, oracle.offsets(FM_w, sf, t), np.zeros(S, dtype=np.int32))["sumDeviance"] for t in s["theta_grid"]]
     assert s["theta_grid"][int(np.argmin(devs))] == theta
-    ref = oracle.nbglm_fit(N_w, oracle.offsets(FM_w, sf, theta), group)
-    live = (ref["allZero"] == 0) & (ref["betaConv"] == 1)
-    check_close("pipeline mirror pvalue", out_r["pvalue"].to_numpy(), ref["pvalue"], live, 1e-6, frac=0.998, noise_rows=2)
-    check_close("pipeline mirror lfc", out_r["log2FoldChange"].to_numpy(), ref["log2FoldChange"], live & (np.abs(ref["log2FoldChange"]) > 1e-2), 1e-6,
-                frac=0.998, noise_rows=2)
+    # the table's fit = the library's fit on the block's matrices (the calls DESeq2Wrap makes; 2v2: no Cook's cutoff), bit for bit,
+    # and that fit against the oracle under the same trend: every row within the bounds or refereed
+    dN, dFM = ctx.window_sums(frd[0]["fragN"], frd[0]["fragFullMean"], frd[0]["region_ptr"])
+    assert np.array_equal(dN.cpu().numpy().T, N_w)
+    dnf = ctx.offsets(dFM, ctx.size_factors(dN), theta)
+    fit, sc = ctx.nbglm_fit(dN, dnf, group, want=WANT)
+    got = {k: v.cpu().numpy() for k, v in fit.items()}
+    for col in ("baseMean", "log2FoldChange", "lfcSE", "stat", "pvalue"):
+        assert np.array_equal(out_r[col].to_numpy(), got[col], equal_nan=True), col
+    nf_dev = dnf.cpu().numpy().T
+    assert np.allclose(nf_dev, oracle.offsets(FM_w, sf, theta), rtol=1e-12, equal_nan=True)
+    explain_fit(f"chicdiffPipeline mirror (with_chinput = {with_chinput})", oracle, N_w, nf_dev, group, got, sc)
     # IHW side: the control fit's covariate trains the stand-in ihw(); the application reproduces the oracle's columns
     ctl = pipeline.DESeq2Wrap(settings, RUc, frd[1], suffix="Control", theta=theta, ctx=ctx)
     df, w = quantile_ihw()(ctl["pvalue"].to_numpy(), np.abs(N_ref[id(frd[1])][1]), 0.05)
