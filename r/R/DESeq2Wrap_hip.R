@@ -1,13 +1,13 @@
-## DESeq2Wrap_hip.R -- Chicdiff's DESeq2Wrap() with the MI355X backend behind it.
+## DESeq2Wrap_hip.R -- the MI355X path of Chicdiff's DESeq2Wrap().
 ##
-## Drop-in for the exported function of the reference (chicdiff.R:1494):
+## The exported function of the reference (chicdiff.R:1494),
 ##     DESeq2Wrap(chicdiff.settings, RU, FullRegionData, suffix = "", theta = NULL)
-## Same arguments, messages, warnings, errors and returned data.table (columns and order of chicdiff.R:1752-1757,
-## attr "theta" as :1759-1760).  With chicdiff.settings[["backend"]] == "hip" the DESeq2 hand-off of
-## chicdiff.R:1540-1691 (+ results(), :1720-1750) runs in libchicdiff_hip.so through the .Call routines of
-## r/src/chicdiff_hip_shim.c; with any other value the reference's own body runs (the maintainer keeps it under the
-## name .DESeq2WrapReference, see INTEGRATION.md).  New optional settings: backend ("hip"), hipDevice (GPU index, default 0;
-## NOT `device`, which is the reference's plot device "png", chicdiff.R:20), trendFallback ("mean").
+## stays the reference's own: r/patches/chicdiff_hip.patch adds, after its argument handling and warnings (:1496-1521), the call
+##     if (identical(chicdiff.settings[["backend"]], "hip")) return(.DESeq2WrapHip(..., theta = theta, norm = norm))
+## .DESeq2WrapHip() below replaces the DESeq2 hand-off of chicdiff.R:1540-1691 (+ results(), :1720-1750) by libchicdiff_hip.so
+## through the .Call routines of r/src/chicdiff_hip_shim.c, with the reference's messages and its returned data.table (columns
+## and order of chicdiff.R:1752-1757, attr "theta" as :1759-1760).  New optional settings: backend ("hip"), hipDevice (GPU
+## index, default 0; NOT `device`, which is the reference's plot device "png", chicdiff.R:20), trendFallback ("mean").
 ##
 ## NOT run in this repository: there is no R in the authoring image or on the GPU box (SURVEY.md §0).  The tested
 ## twin with the same control flow is chicdiff_amd/deseq2wrap.py (pandas standing in for data.table).
@@ -79,34 +79,33 @@ DESeq2Hip <- function(regionDataMatrix, normFactors, condition, device = 0L, alp
 ## setkey(fragData, otherEndID) and by = c("baitID", "regionID", "sample") of chicdiff.R:1526, :1540-1547: inside a
 ## region the fragments are added in ascending otherEndID order.
 .hipDenseFragments <- function(FullRegionData) {
-  fragData <- data.table::copy(FullRegionData)  # as the reference: the caller's table must not change
-  data.table::setkey(fragData, otherEndID)
-  samples <- unique(fragData$sample)
+  fd <- data.table::copy(FullRegionData)        # as the reference: the caller's table must not change
+  data.table::setkeyv(fd, "otherEndID")
+  samples <- unique(fd$sample)
   S <- length(samples)
-  condition <- fragData$condition[seq_len(S)]   # colData, chicdiff.R:1556
-  if (!identical(as.character(fragData$sample[seq_len(S)]), as.character(samples)))
+  condition <- fd$condition[seq_len(S)]   # colData, chicdiff.R:1556
+  if (!identical(as.character(fd$sample[seq_len(S)]), as.character(samples)))
     stop("FullRegionData: the first rows do not hold one row per sample (recast layout expected)")
-  if (anyNA(fragData$N)) stop("FullRegionData: NA counts")
-  ord <- order(match(fragData$sample, samples), fragData$regionID, fragData$otherEndID)
-  nfrag <- nrow(fragData) %/% S
-  if (nfrag * S != nrow(fragData)) stop("FullRegionData: samples do not cover the same (regionID, otherEndID) rows")
-  region <- matrix(fragData$regionID[ord], ncol = S)
-  oe <- matrix(fragData$otherEndID[ord], ncol = S)
+  if (anyNA(fd$N)) stop("FullRegionData: NA counts")
+  ord <- order(match(fd$sample, samples), fd$regionID, fd$otherEndID)
+  nfrag <- nrow(fd) %/% S
+  if (nfrag * S != nrow(fd)) stop("FullRegionData: samples do not cover the same (regionID, otherEndID) rows")
+  region <- matrix(fd$regionID[ord], ncol = S)
+  oe <- matrix(fd$otherEndID[ord], ncol = S)
   if (any(region != region[, 1L]) || any(oe != oe[, 1L]))
     stop("FullRegionData: samples do not cover the same (regionID, otherEndID) rows")
   ids <- unique(region[, 1L])
   if (!identical(as.integer(ids), seq_along(ids)))
     stop("identical(1:nrow(annoData), annoData$regionID) is not TRUE")  # the reference's stopifnot, chicdiff.R:1717
   list(samples = samples, condition = condition, S = S, n = length(ids),
-       fragN = matrix(as.integer(fragData$N[ord]), ncol = S),
-       fragFullMean = matrix(as.double(fragData$FullMean[ord]), ncol = S),
+       fragN = matrix(as.integer(fd$N[ord]), ncol = S),
+       fragFullMean = matrix(as.double(fd$FullMean[ord]), ncol = S),
        region_ptr = as.double(c(match(ids, region[, 1L]) - 1L, nfrag)))
 }
 
 ## annotation columns of the output table, chicdiff.R:1699-1717
 .hipAnnotation <- function(RU, rmapfile, n) {
-  rmap <- data.table::fread(rmapfile)
-  data.table::setnames(rmap, c("chr", "start", "end", "ID"))
+  rmap <- .hipReadRmap(rmapfile)
   ru <- RU[, list(baitID = baitID[1L], minOE = min(otherEndID), maxOE = max(otherEndID)), by = "regionID"]
   data.table::setkey(ru, regionID)
   lo <- match(ru$minOE, rmap$ID); hi <- match(ru$maxOE, rmap$ID); b <- match(ru$baitID, rmap$ID)
@@ -118,32 +117,16 @@ DESeq2Hip <- function(regionDataMatrix, normFactors, condition, device = 0L, alp
   anno
 }
 
-DESeq2Wrap <- function(chicdiff.settings, RU, FullRegionData, suffix = "", theta = NULL) {
-
-  if (!identical(chicdiff.settings[["backend"]], "hip"))
-    return(.DESeq2WrapReference(chicdiff.settings, RU, FullRegionData, suffix = suffix, theta = theta))
+## Entered from the reference's DESeq2Wrap() AFTER its own argument handling (chicdiff.R:1496-1521: theta from the settings,
+## the unknown-norm stop, the two theta = 0 / 1 warnings that rewrite `norm`): r/patches/chicdiff_hip.patch adds the call
+## there, so `theta` and `norm` arrive resolved and none of those statements is restated here.
+.DESeq2WrapHip <- function(chicdiff.settings, RU, FullRegionData, suffix = "", theta = NULL, norm = chicdiff.settings[["norm"]]) {
 
   Grid <- chicdiff.settings[["theta_grid"]]
   rmapfile <- chicdiff.settings[["rmapfile"]]
   saveAux <- chicdiff.settings[["saveAuxData"]]
   outprefix <- chicdiff.settings[["outprefix"]]
   device <- .hipDeviceIndex(chicdiff.settings)   # the new key `hipDevice` (r/R/getFullRegionData_hip.R); never `device`
-
-  if (is.null(theta) & !is.null(chicdiff.settings[["theta"]])) theta <- chicdiff.settings[["theta"]]
-
-  norm <- chicdiff.settings[["norm"]]
-  if (!norm %in% c("standard", "fullmean", "combined")) stop("DESeq2Wrap error: Unknown normalisation method.")
-
-  if (!is.null(theta)) {
-    if (theta == 1 & norm != "standard") {
-      warning("Mixing parameter theta set to 1, equivalent to norm = \"standard\". The norm method has been reset accordingly.")
-      norm <- "standard"
-    }
-    if (!theta & norm != "fullmean") {
-      warning("Mixing parameter theta set to 0, equivalent to norm = \"fullmean\". The norm method has been reset accordingly.")
-      norm <- "fullmean"
-    }
-  }
 
   ctx <- .hipContext(device)
   ## either the reference's long "recast" table, or the device-resident fragment block of getFullRegionDataHip()
@@ -163,17 +146,17 @@ DESeq2Wrap <- function(chicdiff.settings, RU, FullRegionData, suffix = "", theta
       .Call("chicdiff_hip_wald_test", ctx, ws$N, fullMean, group, as.double(tt), NA_real_, fitType, cooks, 0.1,
             as.double(n), S, PACKAGE = "chicdiffhip")))
 
-  if (norm == "standard") {           # model 1: size factors only (chicdiff.R:1572-1575)
+  if (identical(norm, "standard")) {  # model 1: size factors only (chicdiff.R:1572-1575)
     fit <- fitWith(NULL, NA_real_)
     label <- "Standard DESeq2 normalisation"
   }
-  if (norm == "fullmean") {           # model 3: normFactorsM3 (chicdiff.R:1598-1604)
+  if (identical(norm, "fullmean")) {  # model 3: normFactorsM3 (chicdiff.R:1598-1604)
     fit <- fitWith(ws$FullMean, NA_real_)
     label <- "Chicago full mean-based normalisation"
   }
-  if (norm == "combined") {           # model 5: sc(theta) (chicdiff.R:1612-1674)
+  if (identical(norm, "combined")) {  # model 5: sc(theta) (chicdiff.R:1612-1674)
     tt <- theta
-    if (is.null(tt)) {
+    if (!length(tt)) {               # NULL: scan the grid
       message("Optimising scaling factors...")
       nullSizeFactors <- .Call("chicdiff_hip_size_factors", ctx, ws$N, as.double(n), S, PACKAGE = "chicdiffhip")
       deviances <- .Call("chicdiff_hip_theta_grid", ctx, ws$N, ws$FullMean, nullSizeFactors, as.double(Grid), as.double(n), S,
@@ -184,6 +167,10 @@ DESeq2Wrap <- function(chicdiff.settings, RU, FullRegionData, suffix = "", theta
       tt <- Grid[which(deviances == min(deviances)[1])]
     }
     message("Theta=", tt)
+    ## A deliberate stop (INTEGRATION.md 2): the reference carries on with whatever which() returned — numeric(0) when an
+    ## all-zero region made every deviance NA (sum() without na.rm, chicdiff.R:1647), several values on a tie — and fails later, in
+    ## `normFactorsM3*(1-tt)` (:1666), with R's own "non-conformable" / recycling message.  A .Call cannot be handed a
+    ## zero-length or longer theta, so the same situation is reported here, in words.
     if (length(tt) != 1L) stop("theta grid: no unique minimum of the total deviance (an all-zero region makes every deviance NA)")
     fit <- fitWith(ws$FullMean, tt)
     label <- "combined normalisation"

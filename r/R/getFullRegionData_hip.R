@@ -1,7 +1,7 @@
 ## getFullRegionData_hip.R -- the step before DESeq2Wrap() with the MI355X backend behind it (SURVEY.md §8 f2, a1, a3).
 ##
-## Drop-in for the exported function of the reference (chicdiff.R:1460-1478):
-##     getFullRegionData(chicdiff.settings, RU, RUcontrol, suffix = "")
+## The device path of the exported function of the reference (chicdiff.R:1460-1478),
+##     getFullRegionData(chicdiff.settings, RU, RUcontrol, suffix = "")  ->  .getFullRegionDataHip(same arguments)
 ## With chicdiff.settings[["backend"]] == "hip" it returns list(test, control, countput) like the reference, but the
 ## first two entries are "chicdiffHipRegionData" blocks instead of the long "recast" tables (one row per region,
 ## fragment and sample: 176 M rows at 2 M regions x 8 samples, 3.5 G at 20 M x 16): per-sample fragment columns N and
@@ -10,7 +10,7 @@
 ## (r/R/DESeq2Wrap_hip.R) and IHWcorrection() (r/R/post_hip.R) accept the blocks in place of the tables.  Every
 ## Chicago data set and every chinput file is read ONCE for both universes -- what parallel = TRUE
 ## (getFullRegionData2, chicdiff.R:948-1456) does in the reference; the result does not depend on it.  With any other
-## backend the reference's own function runs (kept by the maintainer as .getFullRegionDataReference, INTEGRATION.md).
+## backend the reference's own function body runs: the patch (r/patches/chicdiff_hip.patch) adds one line at its top.
 ##
 ##   reference step                                              here
 ##   fread(chinput); setkey; x[J(baits)]        chicdiff.R:828-831   chicdiff_hip_chinput_table (host threads + device sort)
@@ -26,6 +26,13 @@
 ## same control flow is chicdiff_amd/pipeline.py:getFullRegionData (tests/test_gpu_parity.py::test_chicdiffPipeline_*).
 
 .hipCall <- function(name, ...) .Call(name, ..., PACKAGE = "chicdiffhip")
+
+## the restriction map as Chicago's .readRmap gives it: four columns chr, start, end, ID
+.hipReadRmap <- function(path) {
+  m <- data.table::fread(path)
+  data.table::setnames(m, c("chr", "start", "end", "ID"))
+  m
+}
 
 ## GPU index of this R process: the NEW optional key `hipDevice` (default 0).  Never `device`: that key is the
 ## reference's plot device ("png", chicdiff.R:20, used at :1960 and :2058).
@@ -107,8 +114,7 @@
   conditions <- rep(names(chicagoData), sapply(chicagoData, length))   # chicdiff.R:921-923
   ctx <- .hipContext(.hipDeviceIndex(chicdiff.settings))
 
-  rmap <- data.table::fread(rmapfile)
-  data.table::setnames(rmap, c("chr", "start", "end", "ID"))
+  rmap <- .hipReadRmap(rmapfile)
   nid <- max(rmap$ID)
   midsum <- rep(NA_real_, nid); midsum[rmap$ID] <- as.double(rmap$start) + as.double(rmap$end)
   chrcode <- rep(-1L, nid); chrcode[rmap$ID] <- as.integer(factor(rmap$chr)) - 1L
@@ -178,8 +184,4 @@
   out
 }
 
-getFullRegionData <- function(chicdiff.settings, RU, RUcontrol, suffix = "") {
-  if (!identical(chicdiff.settings[["backend"]], "hip"))
-    return(.getFullRegionDataReference(chicdiff.settings, RU, RUcontrol, suffix = suffix))
-  .getFullRegionDataHip(chicdiff.settings, RU, RUcontrol, suffix = suffix)
-}
+## (entered from the first line of the reference's getFullRegionData() when backend == "hip": r/patches/chicdiff_hip.patch)

@@ -54,6 +54,13 @@ def test_r_host_never_reinterprets_a_reference_settings_key():
                 if key in ref and key != "RUexpand":
                     assert "as.integer(" not in line and ".hipContext(" not in line and ".hipDeviceIndex" not in line, f"{name}: reference key `{key}` reinterpreted: {line.strip()}"
         assert not re.search(r'\[\["device"\]\][^\n]*(hipContext|as\.integer)', code), name
+    # `backend` is read by the lines r/patches/chicdiff_hip.patch adds to the reference's own functions, `hipDevice` by the R host
+    patch = open(os.path.join(ROOT, "r", "patches", "chicdiff_hip.patch")).read()
+    for line in patch.splitlines():
+        if line.startswith("+") and not line.startswith("+++"):
+            for key in _settings_reads(line.split("##")[0]):
+                seen.add(key)
+                assert key in st.HIP_KEYS, f"the patch reads chicdiff.settings[[\"{key}\"]]: only new keys may select the device path"
     assert "hipDevice" in seen and "backend" in seen                                # the GPU index has a key of its own
     # the same for the Python mirrors: no module reads settings["device"]
     for name in os.listdir(os.path.join(ROOT, "chicdiff_amd")):
