@@ -1586,10 +1586,10 @@ extern "C" int chicdiff_hip_wald_pvalues_dev(chicdiff_hip_ctx *c, const double *
     return CHICDIFF_OK;
 }
 
-// device-math self test: op 0 flog, 1 tlog (table), 2 rcp, 3 lgamma, 4 digamma, 5 2*pnorm(-|x|)
+// device-math self test: op 0 flog, 1 tlog (table), 2 rcp, 3 lgamma, 4 digamma, 5 2*pnorm(-|x|), 6 / 7 raw v_rcp_f64 (+ one Newton step), 8 texp (table)
 extern "C" int chicdiff_hip_selftest_math_dev(chicdiff_hip_ctx *c, int32_t op, const double *d_x, int64_t n, double *d_out) {
     if (!c) return CHICDIFF_E_INVALID;
-    if (!d_x || !d_out || n < 0 || op < 0 || op > 7) return fail(c, CHICDIFF_E_INVALID, "selftest_math: bad arguments");
+    if (!d_x || !d_out || n < 0 || op < 0 || op > 8) return fail(c, CHICDIFF_E_INVALID, "selftest_math: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     if (n > 0) launch_math_selftest(op, d_x, n, d_out, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));

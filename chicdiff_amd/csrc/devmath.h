@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "exp_table.h"
 #include "fit_state.h"
 #include "log_table.h"
 
@@ -96,6 +97,35 @@ __device__ __forceinline__ double tlog(double x, const LogEntry *tab) {
 }
 __device__ __forceinline__ double tlog1p_from(double u, double t, double rt, const LogEntry *tab) {
     return fma(u - (t - 1.0), rt, tlog(t, tab));
+}
+
+// ---- table-driven exp for the hot loops ------------------------------------------------------
+// x = (64 m + j) ln2/64 + r, |r| <= ln2/128: exp x = 2^m 2^(j/64) (1 + expm1 r), 2^(j/64) tabulated as (hi, lo)
+// (exp_table.h), expm1 r by its degree-5 Taylor polynomial (truncation r^6/720 < 3.5e-17).  ~16 VALU instructions + one
+// ds_read_b128 against ~38 for the device-library exp; <= 1 ulp.  Finite x only (NaN stays NaN; +-Inf gives NaN: the callers'
+// arguments are bounded — log alpha in [-30, 10], IRLS coefficients within +-30).  The 1 KB table lives in LDS (`tab`).
+struct ExpEntry {
+    double hi, lo;
+};
+static __device__ const ExpEntry kExpTable[64] = {CD_EXP_TABLE_INIT};
+
+// (call before a __syncthreads() that precedes the first use: log_table_to_lds() ends with one)
+__device__ __forceinline__ void exp_table_to_lds(ExpEntry *s_tab) {
+    if (threadIdx.x < 64) s_tab[threadIdx.x] = kExpTable[threadIdx.x];
+}
+
+__device__ __forceinline__ double texp(double x, const ExpEntry *tab) {
+    const double kd = rint(x * 92.33248261689366);              // 64 / ln2
+    const int k = (int)kd;
+    double r = fma(-kd, 0x1.62e42fee00000p-7, x);               // ln2/64, high part: 32 significant bits, k * hi is exact
+    r = fma(-kd, 0x1.a39ef35793c76p-39, r);
+    const ExpEntry e = tab[k & 63];
+    const double r2 = r * r;
+    const double a = fma(r, 1.0 / 6.0, 0.5);
+    const double b = fma3(r, 1.0 / 120.0, 1.0 / 24.0);
+    const double q = fma(r2, b, a);
+    const double p = fma(r2, q, r);                             // expm1(r)
+    return ldexp(e.hi + fma(e.hi, p, e.lo), k >> 6);
 }
 
 // log1p(u) for u >= 0 where t = 1 + u and rt = 1/t are already at hand: log(t) plus the

@@ -461,10 +461,10 @@ struct RowConsts {  // what depends only on the evaluation point a = log(alpha)
     double a, alpha, r, lgS0, dgS0;
     int nr;
 };
-__device__ __forceinline__ RowConsts row_consts(double a, const LogEntry *lt) {
+__device__ __forceinline__ RowConsts row_consts(double a, const LogEntry *lt, const ExpEntry *et) {
     RowConsts c;
     c.a = a;
-    c.alpha = exp(a);
+    c.alpha = texp(a, et);
     c.r = rcp(c.alpha);
     c.nr = c.r < 10.0 ? (int)ceil(10.0 - c.r) : 0;  // unit steps lifting r to r0 = r + nr >= 10
     const double r0 = c.r + (double)c.nr;
@@ -499,6 +499,10 @@ __device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double m
     double dlg = 0.0, ddg = H;
     v.pe = __builtin_amdgcn_frexp_exp(P);
     v.pm = __builtin_amdgcn_frexp_mant(P);
+    // (Measured, round 4: the two halves of a sample — log1p(mu alpha) with its reciprocal, the Stirling difference at z = y + r
+    // with its logarithm and reciprocal — written side by side and branch-free, so that the compiler interleaves the two
+    // dependency chains: bit-identical, 207 VGPRs instead of 196, and no faster — gene-wise 1.560 -> 1.565 ms at 2 M x 8,
+    // 0.603 -> 0.614 at 250 k.  profiles/r04_ab_line_search_trims.txt)
     if (yi > c.nr) {
         const double z = y + c.r;
         double lgz, dgz;
@@ -551,9 +555,9 @@ __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c,
 __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int slot, int S, uint64_t gmask,
                                            bool p2, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
-                                           double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
+                                           double &lp, double &dlp, double &alpha_out, const LogEntry *lt, const ExpEntry *et) {
     MARK("row:begin");
-    const RowConsts c = row_consts(a, lt);
+    const RowConsts c = row_consts(a, lt, et);
     alpha_out = c.alpha;
     MARK("row:row_consts_end");
     // per-tick table (LDS, [entry][lane]): P_n and H_n for n = 0..nr
@@ -599,7 +603,7 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
 __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int *s_y, double *s_x, int lane, int S, int lg, uint64_t gmask,
                                                   bool p2, unsigned long long actmask, bool active, double a_eval,
                                                   bool use_prior, double prior_mean, double prior_isig,
-                                                  double &lp, double &dlp, double &alpha_out, const LogEntry *lt) {
+                                                  double &lp, double &dlp, double &alpha_out, const LogEntry *lt, const ExpEntry *et) {
     // lanes per row L = 2^lg: one sample per lane when L >= S (at most 64 / L rows), else samples jj, jj + L, ... per lane — the
     // layout also serves 9 .. 32 live rows (S = 8: four or two lanes per row), where a row-per-lane tick would still walk all S
     // samples in every lane
@@ -612,7 +616,7 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
     MARK("spread:owner_walk_end");
     const double a_o = __shfl(a_eval, owner);
     const double pm_o = use_prior ? __shfl(prior_mean, owner) : 0.0;
-    const RowConsts c = row_consts(a_o, lt);
+    const RowConsts c = row_consts(a_o, lt, et);
     MARK("spread:row_consts_end");
     // the five values of every sample pass through the wave's prefix-table area (idle in this layout), [value][sample R + group]:
     // each lane then reads its group's S samples — four samples' loads in flight at a time, same address within a group (a
@@ -680,6 +684,8 @@ template <bool MAP, int MINW>
 __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     extern __shared__ double smem[];
     __shared__ LogEntry s_logtab[64];
+    __shared__ ExpEntry s_exptab[64];
+    exp_table_to_lds(s_exptab);
     log_table_to_lds(s_logtab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = A.d.S;
@@ -910,10 +916,10 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         })
         if (lg_t >= 0) {
             eval_point_spread(s_nf, s_y, s_tab, lane, S, lg_t, gmask, p2, actmask, active, a_eval, MAP,
-                              prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab);
+                              prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab, s_exptab);
         } else if (active || helper) {
             eval_point(s_nf, s_y, s_tab, lane, slot, S, gmask, p2, a_eval, MAP, pm_e, prior_isig, l_new,
-                       dl_new, alpha_new, s_logtab);
+                       dl_new, alpha_new, s_logtab, s_exptab);
         }
         MARK("tick:evaluate_end");
         bool burst_done = false;  // this lane owns the burst: l_new / hk now describe the best of the 20 points

@@ -1349,6 +1349,8 @@ void launch_fragment_background(const int32_t *bait, const int32_t *oe, int64_t 
 __global__ __launch_bounds__(256) void math_selftest_kernel(int op, const double *__restrict__ x, int64_t n,
                                                             double *__restrict__ out) {
     __shared__ LogEntry s_logtab[64];
+    __shared__ ExpEntry s_exptab[64];
+    exp_table_to_lds(s_exptab);
     log_table_to_lds(s_logtab);
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const double v = x[i];
@@ -1362,6 +1364,7 @@ __global__ __launch_bounds__(256) void math_selftest_kernel(int op, const double
             case 5: r = pnorm_two_sided(v); break;
             case 6: r = __builtin_amdgcn_rcp(v); break;  // raw v_rcp_f64 (~25 bits)
             case 7: { double q = __builtin_amdgcn_rcp(v); r = fma(q, fma(-v, q, 1.0), q); } break;  // + 1 Newton step
+            case 8: r = texp(v, s_exptab); break;
         }
         out[i] = r;
     }

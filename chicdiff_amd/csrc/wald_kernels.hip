@@ -152,6 +152,8 @@ struct WaldArgs {
 __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
     extern __shared__ double smem[];
     __shared__ LogEntry s_logtab[64];
+    __shared__ ExpEntry s_exptab[64];
+    exp_table_to_lds(s_exptab);
     log_table_to_lds(s_logtab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = A.d.S;
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
             const bool mine = grp < nact && jj < S;
             const double b0o = __shfl(b0, owner), b1o = __shfl(b1, owner), alo = __shfl(alpha, owner), szo = __shfl(size, owner);
             const double etaAo = b0o, etaBo = b0o + b1o;
-            const double E0 = exp(etaAo), E1 = exp(etaBo);
+            const double E0 = texp(etaAo, s_exptab), E1 = texp(etaBo, s_exptab);
             const double nfj = mine ? s_nf[jj * 64 + owner] : 1.0;
             const double y = mine ? (double)s_y[jj * 64 + owner] : 0.0;
             const bool g = (gmask >> jj) & 1;
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
             const double etaA = b0, etaB = b0 + b1;
             double E0 = 0, E1 = 0;
             if (!spread_now) {  // (wave-uniform)
-                E0 = exp(etaA);
-                E1 = exp(etaB);
+                E0 = texp(etaA, s_exptab);
+                E1 = texp(etaB, s_exptab);
             }
             for (int j = 0; j < (spread_now ? 0 : S); j++) {
                 const double nfj = s_nf[j * 64 + lane];

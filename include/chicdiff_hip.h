@@ -337,7 +337,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *ctx, const int32_t *d_counts, 
 int chicdiff_hip_wald_pvalues_dev(chicdiff_hip_ctx *ctx, const double *d_stat, int64_t n, double *d_p);
 
 /* Device-math self test: out[i] = f(x[i]) with op 0 log (polynomial), 1 log (table), 2 reciprocal,
- * 3 lgamma, 4 digamma, 5 2*pnorm(-|x|) — the special functions the fit kernels are built on. */
+ * 3 lgamma, 4 digamma, 5 2*pnorm(-|x|), 8 exp (table) — the special functions the fit kernels are built on. */
 int chicdiff_hip_selftest_math_dev(chicdiff_hip_ctx *ctx, int32_t op, const double *d_x, int64_t n, double *d_out);
 
 /* Host-side self tests of the pieces behind CHICDIFF_ST_PRIORVAR_MC (no device, no context).

@@ -544,6 +544,19 @@ def test_device_math(ctx):
     di = ctx.selftest_math(4, dg).cpu().numpy()
     ref = special.digamma(xg)
     assert np.max(np.abs(di - ref) / np.maximum(1, np.abs(ref))) < 4e-15
+    # texp (table-driven exp of the line searches and the IRLS): against 50-digit arithmetic on a sample, numpy on the rest
+    import mpmath as mp
+    xe = np.concatenate([rng.uniform(-30, 10, 200000), rng.uniform(-700, 700, 50000), rng.uniform(-1e-3, 1e-3, 20000), [0.0, -745.0, 709.0]])
+    ge = ctx.selftest_math(8, torch.as_tensor(xe).to(ctx.device)).cpu().numpy()
+    re_ = np.exp(xe)
+    ok = re_ > 1e-300   # (denormal results: ldexp rounds once more)
+    r = np.abs(ge[ok] - re_[ok]) / re_[ok]
+    print("texp max rel vs numpy", r.max())
+    assert r.max() < 4e-16 and ge[np.flatnonzero(xe == 0.0)[0]] == 1.0
+    mp.mp.dps = 50
+    worst = max(abs(mp.mpf(float(g)) / mp.exp(mp.mpf(float(v))) - 1) for g, v in zip(ge[:2000], xe[:2000]))
+    print("texp max rel vs 50 digits (2000 points)", float(worst))
+    assert worst < 2.5e-16
 
 
 def test_fragment_background(ctx, oracle):

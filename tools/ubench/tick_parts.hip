@@ -6,6 +6,8 @@ namespace cd {
 
 #define LT                                 \
     __shared__ LogEntry s_lt[64];          \
+    __shared__ ExpEntry s_et[64];          \
+    exp_table_to_lds(s_et);                \
     log_table_to_lds(s_lt);
 
 // the empty frame: what every kernel below pays for its loads / stores / table set-up
@@ -15,10 +17,14 @@ extern "C" __global__ void part_frame(const double *in, double *out) {
 }
 extern "C" __global__ void part_row_consts(const double *in, double *out) {
     LT;
-    const RowConsts c = row_consts(in[threadIdx.x], s_lt);
+    const RowConsts c = row_consts(in[threadIdx.x], s_lt, s_et);
     out[threadIdx.x] = c.alpha + c.r + c.lgS0 + c.dgS0 + (double)c.nr;
 }
-extern "C" __global__ void part_exp(const double *in, double *out) { out[threadIdx.x] = exp(in[threadIdx.x]); }
+extern "C" __global__ void part_exp_library(const double *in, double *out) { out[threadIdx.x] = exp(in[threadIdx.x]); }
+extern "C" __global__ void part_texp(const double *in, double *out) {
+    LT;
+    out[threadIdx.x] = texp(in[threadIdx.x], s_et);
+}
 extern "C" __global__ void part_rcp(const double *in, double *out) { out[threadIdx.x] = rcp(in[threadIdx.x]); }
 extern "C" __global__ void part_tlog(const double *in, double *out) {
     LT;
