@@ -59,6 +59,7 @@ struct chicdiff_hip_ctx {
     // select candidate-list overflow, 2 = this rank's persistent trend kernel reports a grid-barrier timeout, 4 = this rank's
     // size-factor select reports an overflow.  Each verdict is all-reduced, so every rank of a sharded fit must re-enter together.
     int opt_trend_blocks = 0;  // persistent trend kernel: cap on its workgroups (0 = one per CU)
+    int opt_mad_in_kernel = 1; // the persistent trend kernel also takes the median / MAD of the residuals (0: separate launches, as round 3)
     int opt_fault = 0;
     int refits = 0;               // refits the last call went through (select overflow / barrier timeout / local substitute), for the tests
     bool sf_overflow_seen = false;  // fit_dev_impl: some rank's size-factor select (run by the caller just before) overflowed
@@ -178,6 +179,7 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     else if (k == "trend_one_launch_per_pass" && (value == 0 || value == 1)) c->opt_trend_multilaunch = (int)value;
     else if (k == "fault_inject" && value >= 0 && value <= 7) c->opt_fault = (int)value;
     else if (k == "trend_persistent_blocks" && value >= 0 && value <= 256) c->opt_trend_blocks = (int)value;
+    else if (k == "trend_mad_in_kernel" && (value == 0 || value == 1)) c->opt_mad_in_kernel = (int)value;
     else return fail(c, CHICDIFF_E_INVALID, "set_option: unknown option or value (%s = %lld)", name, (long long)value);
     return CHICDIFF_OK;
 }
@@ -898,7 +900,8 @@ static int gathered_trend(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
     wg.baseMean = xg;
     wg.dispGene = yg;
     wg.allZero = flags;  // all zero: a row that does not take part carries y = NaN
-    launch_trend_persistent(dg, wg, o, st);
+    wg.resid = c->tg_resid;
+    launch_trend_persistent(dg, wg, o, st, c->opt_mad_in_kernel != 0);
     return CHICDIFF_OK;
 }
 
@@ -932,6 +935,7 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         launch_disp_gene(d_counts, d_nf, d, w, o, st);
     }
     // trend: fit_driver.h runs batches of IRLS passes and polls the finished flag between batches
+    bool mad_in_kernel = false;  // the persistent trend kernel went on to the residuals, their median and MAD, and the closed-form prior variance
     if (o.trendIn[0] == o.trendIn[0] && o.trendIn[1] == o.trendIn[1]) {  // caller-supplied dispersion function
         launch_trend_init(d, w, o, st);
         HIPCHK(c, hipMemcpyAsync(w.sc->coefs, o.trendIn, sizeof(double) * 2, hipMemcpyHostToDevice, st));
@@ -976,11 +980,13 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
             return rc;
     } else if (!c->allreduce && !c->no_persistent_trend && c->cu_count >= trend_persistent_blocks() && !c->opt_trend_multilaunch) {
         Scope t(c, "trend_fit");  // single rank: one persistent launch (LDS-resident rows, grid barrier per IRLS pass)
-        launch_trend_persistent(d, w, o, st);  // no host round trip: `failed` comes back with the final scalars
+        launch_trend_persistent(d, w, o, st, c->opt_mad_in_kernel != 0);  // no host round trip: `failed` comes back with the final scalars
+        mad_in_kernel = c->opt_mad_in_kernel != 0;
     } else if (c->allreduce && c->opt_trend_gather && !c->no_persistent_trend && c->cu_count >= trend_persistent_blocks() &&
                !c->opt_trend_multilaunch) {
         Scope t(c, "trend_fit");
         if ((rc = gathered_trend(c, d, o))) return rc;
+        mad_in_kernel = c->opt_mad_in_kernel != 0;
     } else {
         Scope t(c, "trend_fit");
         HipBackend be{c, d, o, SelArgs{}};
@@ -1009,31 +1015,45 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         wm.allZero = c->tg_flags;
         wm.resid = c->tg_resid;
     }
-    launch_dispfit_resid(dm, wm, o, st);
-    SelArgs sa{};
-    sa.n = dm.n;
-    sa.ncol = 1;
-    sa.resid = wm.resid;
-    {
-        Scope t(c, "mad_select");
-        sa.mode = SEL_RESID;
-        if ((rc = run_select(c, sa, mad_local))) return rc;
-        sa.mode = SEL_ABSDEV;
-        if ((rc = run_select(c, sa, mad_local))) return rc;
-        if (prior_by_simulation) {
-            // residual d.f. <= 3: DESeq2 matches the prior variance by simulation (prior_mc.h).  The 200 x 40 simulated
-            // densities are constants (built once per process and d.f.); the matching itself runs on the device
+    if (mad_in_kernel) {
+        if (prior_by_simulation) {  // the residuals are in wm.resid: their histogram, then the simulation-matched prior variance
+            Scope t(c, "prior_mc");
             double *d_hist = sums_of(w) + 32;
             launch_resid_hist(dm, wm, d_hist, st);
-            if (!mad_local && (rc = do_allreduce(c, d_hist, kPmcBins))) return rc;
             const int df = d.S - d.p;
             if (!c->d_pmc[df]) {  // built once per process, uploaded once per context
                 HIPCHK(c, hipMalloc((void **)&c->d_pmc[df], sizeof(PmcTable)));
                 HIPCHK(c, hipMemcpy(c->d_pmc[df], &pmc_table(df), sizeof(PmcTable), hipMemcpyHostToDevice));
             }
             launch_prior_mc(d, w, d_hist, c->d_pmc[df], st);
-        } else {
-            launch_prior_var(d, w, o, st);
+        }
+    } else {
+        launch_dispfit_resid(dm, wm, o, st);
+        SelArgs sa{};
+        sa.n = dm.n;
+        sa.ncol = 1;
+        sa.resid = wm.resid;
+        {
+            Scope t(c, "mad_select");
+            sa.mode = SEL_RESID;
+            if ((rc = run_select(c, sa, mad_local))) return rc;
+            sa.mode = SEL_ABSDEV;
+            if ((rc = run_select(c, sa, mad_local))) return rc;
+            if (prior_by_simulation) {
+                // residual d.f. <= 3: DESeq2 matches the prior variance by simulation (prior_mc.h).  The 200 x 40 simulated
+                // densities are constants (built once per process and d.f.); the matching itself runs on the device
+                double *d_hist = sums_of(w) + 32;
+                launch_resid_hist(dm, wm, d_hist, st);
+                if (!mad_local && (rc = do_allreduce(c, d_hist, kPmcBins))) return rc;
+                const int df = d.S - d.p;
+                if (!c->d_pmc[df]) {  // built once per process, uploaded once per context
+                    HIPCHK(c, hipMalloc((void **)&c->d_pmc[df], sizeof(PmcTable)));
+                    HIPCHK(c, hipMemcpy(c->d_pmc[df], &pmc_table(df), sizeof(PmcTable), hipMemcpyHostToDevice));
+                }
+                launch_prior_mc(d, w, d_hist, c->d_pmc[df], st);
+            } else {
+                launch_prior_var(d, w, o, st);
+            }
         }
     }
     if (c->opt_fault & 1) {  // test hook: this rank's select "could not fit its candidate list"
@@ -1551,6 +1571,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         l->opt_select_rounds = c->opt_select_rounds;
         l->opt_trend_multilaunch = c->opt_trend_multilaunch;
         l->opt_trend_blocks = c->opt_trend_blocks;
+        l->opt_mad_in_kernel = c->opt_mad_in_kernel;
         l->no_persistent_trend = true;  // a grid barrier needs its workgroups co-resident: not guaranteed beside other fits
         workers.emplace_back([=, &lane_rc]() {
             int r = CHICDIFF_OK;

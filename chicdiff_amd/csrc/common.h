@@ -94,7 +94,9 @@ void launch_xim(FitDims d, FitWork w, const double *slots, int world, hipStream_
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_order_build(FitDims d, FitWork w, int classesA, bool have_hist, hipStream_t st);  // w.cls -> w.order (schedule of a row-queue kernel)
 void launch_disp_map(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
-void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st);  // single rank: whole trend fit, one launch
+// single rank (or the gathered rows of a sharded fit): whole trend fit, one launch; with_mad: the same launch goes on to the residuals,
+// their median and MAD and the closed-form prior variance (w.resid, sc->med / nres / mad / varLogDispEsts / dispPriorVar)
+void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st, bool with_mad);
 int trend_persistent_blocks();  // workgroups that must be co-resident (grid barrier): needs that many CUs
 void launch_trend_init(FitDims d, FitWork w, Opts o, hipStream_t st);
 int trend_blocks();                                                       // grid of the trend pass = rows of 8 partial sums

@@ -155,7 +155,205 @@ __device__ __forceinline__ bool grid_sync(unsigned int *top, unsigned int *group
     return ok != 0;
 }
 
-__global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d, FitWork w, double minDisp) {
+// ---- MAD of the log residuals inside the persistent trend kernel ------------------------------------------------------
+// Round 3 followed the trend kernel with resid_kernel and two radix selects — 14 dependent launches and 4 fills that move 16 MB
+// each and take 0.17 ms at 2 M rows, 0.11 ms at 250 k: pure launch latency.  The trend kernel has every row in LDS and a grid
+// barrier at hand, so it goes on: residuals (written to w.resid as before), then for the median and for the median of the
+// absolute deviations the same exact radix select — 12-bit digit histograms (LDS, then one global atomic per non-empty bin), a
+// grid barrier, every workgroup picks the bins that hold the two middle ranks, next digit ... until at most kSelCap keys share
+// the chosen prefix (after two rounds unless the data are massively tied), then the candidates are appended to a global list,
+// one more barrier, and every workgroup sorts the same short list in LDS and reads the order statistics off it.  Exact, so the
+// medians — and everything downstream — are the bits of the launches it replaces.
+// Global scratch (w.hist, as 32-bit words, zeroed by the kernel): per select s in {median, absdev} and slot q in {lower, upper}
+//   hist[s][round 0..5][q][4096], cnt[s][q], then 64-bit keys cand[s][q][kSelCap].
+constexpr int kMadSortMax = 512;  // candidates per slot that are sorted rather than narrowed down by another round (<= kSelCap)
+constexpr int kMadHistWords = 2 * 6 * 2 * kSelBins;
+constexpr int kMadCntWords = 8;                                  // 2 x 2 counters (+ pad)
+constexpr int kMadScratchWords = kMadHistWords + kMadCntWords;   // what must be zero; the candidate lists follow (8-byte aligned)
+struct MadArgs {
+    int enabled;       // 0: the kernel stops after the trend (the host launches the separate MAD step)
+    int S, p;
+    double prior_in;   // NaN = estimate; the closed-form prior variance is finished here unless by_simulation
+    int by_simulation; // residual d.f. <= 3: the host follows up with the residual histogram and prior_mc
+};
+
+#ifdef CHICDIFF_MAD_STAMPS
+#define MSTAMP(label) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_mad_n < 64) { g_mad_lab[g_mad_n] = (label); g_mad_t[g_mad_n++] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+__device__ unsigned long long g_mad_t0, g_mad_t[64];
+__device__ int g_mad_lab[64], g_mad_n;
+#else
+#define MSTAMP(label)
+#endif
+// wave-aggregated histogram update: lanes that hold the same digit add once (the first digit — sign and exponent — is shared by
+// almost every key of a column, and 64 lanes adding 1 to one LDS word serialise)
+__device__ __forceinline__ void hist_add(unsigned int *h, bool valid, unsigned int digit) {
+    unsigned long long todo = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    for (int it = 0; it < 4 && todo; it++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned int dl = (unsigned int)__shfl((int)digit, leader);
+        const unsigned long long same = __ballot(valid && digit == dl) & todo;
+        if (lane == leader) atomicAdd(&h[dl], (unsigned int)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&h[digit], 1u);  // (digits of the later rounds differ from lane to lane)
+}
+
+// One exact select over the keys key_fn(k) of this workgroup's rows; returns the two middle order statistics as keys.
+// `sel` picks the scratch; s_a / s_b: two LDS histograms of kSelBins words; sortbuf: kSelCap 64-bit words (may alias them).
+// Every workgroup executes the same barriers and reaches the same result.  Returns false if a grid barrier timed out.
+template <class KeyFn>
+__device__ bool mad_select(KeyFn key_fn, int64_t nrows_block, int sel, unsigned int *gscratch, unsigned int *s_a, unsigned int *s_b,
+                           uint64_t *sortbuf, unsigned int *ctr, unsigned int *grp, unsigned int &pass, uint64_t (&result)[2], double &population) {
+    __shared__ uint64_t sh_pre[2];
+    __shared__ double sh_rank[2], sh_pop;
+    __shared__ unsigned int sh_cnt[2];
+    __shared__ double sh_scan[kTpThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned int *ghist = gscratch + (size_t)sel * 6 * 2 * kSelBins;
+    unsigned int *gcnt = gscratch + kMadHistWords + sel * 2;
+    uint64_t *gcand = reinterpret_cast<uint64_t *>(gscratch + kMadScratchWords) + (size_t)sel * 2 * kSelCap;
+    uint64_t p0 = 0, p1 = 0;
+    double rank0 = 0, rank1 = 0;
+    int fixed_hi = 64;  // bits [fixed_hi, 64) of the two prefixes are decided
+    for (int r = 0; r < 6; r++) {
+        const int shift = kSelShifts[r], bits = sel_bits(shift), nb = 1 << bits;
+        const bool same = p0 == p1;
+        for (int k = tid; k < kSelBins; k += kTpThreads) { s_a[k] = 0; s_b[k] = 0; }
+        __syncthreads();
+        const int64_t trips = (nrows_block + kTpThreads - 1) / kTpThreads;  // (every thread the same number: hist_add ballots)
+        for (int64_t t = 0; t < trips; t++) {
+            const int64_t k = t * kTpThreads + tid;
+            uint64_t key = 0;
+            const bool valid = k < nrows_block && key_fn(k, key);
+            const unsigned int dig = (unsigned int)((key >> shift) & (uint64_t)(nb - 1));
+            const bool m0 = valid && sel_match(key, p0, fixed_hi), m1 = valid && !same && !m0 && sel_match(key, p1, fixed_hi);
+            hist_add(s_a, m0, dig);
+            if (!same) hist_add(s_b, m1, dig);
+        }
+        __syncthreads();
+        unsigned int *g0 = ghist + ((size_t)r * 2 + 0) * kSelBins, *g1 = g0 + kSelBins;
+        for (int k = tid; k < nb; k += kTpThreads) {
+            if (s_a[k]) atomicAdd(&g0[k], s_a[k]);
+            if (!same && s_b[k]) atomicAdd(&g1[k], s_b[k]);
+        }
+        MSTAMP(1);
+        if (!grid_sync(ctr, grp, pass++)) return false;
+        MSTAMP(2);
+        // every workgroup: pick, for each slot, the bin that holds its rank (fit_state.h sel_pick, parallel: per-thread partial
+        // sums over 4 consecutive bins, a scan over the 1024 threads, the owning thread refines)
+        for (int hsel = 0; hsel < (same ? 1 : 2); hsel++) {  // one scan per distinct histogram; both slots read theirs off it
+            const unsigned int *g = hsel ? g1 : g0;
+            const int per = (nb + kTpThreads - 1) / kTpThreads;  // 4 (1 in the last, 16-bin round)
+            double mine[4] = {0, 0, 0, 0}, acc = 0;
+            for (int q = 0; q < per; q++) {
+                const int b = tid * per + q;
+                mine[q] = b < nb ? (double)g[b] : 0.0;
+                acc += mine[q];
+            }
+            double incl = acc;  // inclusive scan over the workgroup (counts: exact in fp64)
+            for (int off = 1; off < 64; off <<= 1) {
+                const double o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            if (lane == 63) sh_scan[wave] = incl;
+            __syncthreads();
+            double before_wave = 0, total = 0;
+            for (int q = 0; q < kTpThreads / 64; q++) {
+                if (q < wave) before_wave += sh_scan[q];
+                total += sh_scan[q];
+            }
+            incl += before_wave;
+            if (r == 0 && tid == 0) sh_pop = total;
+            const double before = incl - acc;
+            const bool last_thread = tid == (nb - 1) / per;
+            for (int slot = 0; slot < 2; slot++) {
+                if ((slot == 1 && !same) != (hsel == 1)) continue;  // slot 1 reads the second histogram when the prefixes differ
+                double rank = slot ? rank1 : rank0;
+                if (r == 0) {  // the first histogram's total is the population: ranks of the two middles (R median())
+                    const int64_t mi = (int64_t)total;
+                    rank = slot ? (double)(mi / 2) : (double)((mi - 1) / 2);
+                }
+                if ((before <= rank && rank < incl) || (last_thread && rank >= incl && incl == total)) {
+                    double cum = before;
+                    int q = 0;
+                    for (; q < per - 1 && tid * per + q < nb - 1; q++) {
+                        if (cum + mine[q] > rank) break;
+                        cum += mine[q];
+                    }
+                    const int b = tid * per + q;
+                    sh_pre[slot] = (slot ? p1 : p0) | ((uint64_t)b << shift);
+                    sh_rank[slot] = rank - cum;
+                    sh_cnt[slot] = g[b];
+                }
+            }
+            __syncthreads();
+        }
+        MSTAMP(3);
+        p0 = sh_pre[0]; p1 = sh_pre[1];
+        rank0 = sh_rank[0]; rank1 = sh_rank[1];
+        fixed_hi = shift;
+        population = sh_pop;
+        const unsigned int c0 = sh_cnt[0], c1 = sh_cnt[1];
+        __syncthreads();
+        if (population <= 0) { result[0] = result[1] = 0; return true; }  // empty: the caller sees population 0
+        if (shift == 0) { result[0] = p0; result[1] = p1; return true; }  // every bit decided
+        // few enough keys share the prefixes: gather and sort.  (A further round costs ~14 us — two passes over LDS and a grid barrier
+        // — and a bitonic sort of 4096 keys ~55 us, of 512 ~10 us: measured, profiles/r04_mad_in_kernel_stamps.txt)
+        if (c0 <= (unsigned int)kMadSortMax && c1 <= (unsigned int)kMadSortMax) break;
+    }
+    // candidates -> global lists (order irrelevant: they are sorted), then every workgroup sorts the same lists
+    const bool same = p0 == p1;
+    for (int64_t k = tid; k < nrows_block; k += kTpThreads) {
+        uint64_t key;
+        if (!key_fn(k, key)) continue;
+        int slot = -1;
+        if (sel_match(key, p0, fixed_hi)) slot = 0;
+        else if (!same && sel_match(key, p1, fixed_hi)) slot = 1;
+        if (slot < 0) continue;
+        const unsigned int pos = atomicAdd(&gcnt[slot], 1u);
+        if (pos < (unsigned int)kSelCap) gcand[(size_t)slot * kSelCap + pos] = key;
+    }
+    MSTAMP(4);
+    if (!grid_sync(ctr, grp, pass++)) return false;
+    MSTAMP(5);
+    for (int slot = 0; slot < 2; slot++) {
+        const int hslot = (slot == 1 && !same) ? 1 : 0;
+        const int m = (int)gcnt[hslot];
+        MSTAMP(100 + m);
+        if (slot == 1 && same) {  // both middles sit in the list that is sorted already
+            const int rk = (int)rank1;
+            result[1] = sortbuf[rk < m ? rk : m - 1];
+            __syncthreads();
+            break;
+        }
+        int len = 64;
+        while (len < m) len <<= 1;
+        __syncthreads();
+        for (int e = tid; e < len; e += kTpThreads) sortbuf[e] = e < m ? gcand[(size_t)hslot * kSelCap + e] : ~0ull;
+        __syncthreads();
+        for (int k2 = 2; k2 <= len; k2 <<= 1)  // bitonic sort, ascending
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int e = tid; e < len; e += kTpThreads) {
+                    const int q = e ^ j;
+                    if (q > e) {
+                        const uint64_t x = sortbuf[e], y = sortbuf[q];
+                        const bool up = (e & k2) == 0;
+                        if ((x > y) == up) { sortbuf[e] = y; sortbuf[q] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        const int rk = (int)(slot ? rank1 : rank0);
+        result[slot] = sortbuf[rk < m ? rk : m - 1];
+        __syncthreads();
+    }
+    MSTAMP(6);
+    return true;
+}
+
+__global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d, FitWork w, double minDisp, MadArgs madargs) {
+    const bool mad = madargs.enabled != 0;
     __shared__ double s_bm[kTpCap], s_y[kTpCap];  // 1 / baseMean and dispGeneEst (NaN = not used for the fit)
     __shared__ double red[kTrendSums][16];
     __shared__ FitScalars st;  // only the trend fields are used
@@ -169,21 +367,26 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
     for (int k = tid; k < ncache; k += kTpThreads) {
         const int64_t i = r0 + k;
         const double y = w.dispGene[i];
-        const bool use = !w.allZero[i] && (y > 100 * minDisp);  // useForFit
         s_bm[k] = 1.0 / w.baseMean[i];
-        s_y[k] = use ? y : NAN;
+        s_y[k] = w.allZero[i] ? NAN : y;  // (useForFit, y > 100 minDisp, is tested per pass: the MAD step below wants y >= 100 minDisp)
     }
     if (tid == 0) trend_init(&st);
     __syncthreads();
     unsigned int *ctr = reinterpret_cast<unsigned int *>(w.barrier), *grp = ctr + 16;  // top counter, then 8 group counters 64 B apart
     double *slots = w.partials;  // [2][gridDim.x][kTrendSums], double-buffered by pass parity
+    const double thr = 100 * minDisp;
+    // scratch of the MAD step (below): zeroed here, by one workgroup; the barriers of the trend passes publish it
+    unsigned int *gscratch = reinterpret_cast<unsigned int *>(w.hist);
+    if (mad && blockIdx.x == 0)
+        for (int k = tid; k < kMadScratchWords; k += kTpThreads) gscratch[k] = 0;
     bool alive = true;
-    for (unsigned int pass = 0; pass < 11 * 27 + 16; pass++) {
+    unsigned int pass = 0;
+    for (; pass < 11 * 27 + 16; pass++) {
         if (st.finished) break;
         double v[kTrendSums] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = tid; k < ncache; k += kTpThreads) {
             const double y = s_y[k];
-            if (y == y) trend_row_dev(&st, s_bm[k], y, v, s_lt);
+            if (y > thr) trend_row_dev(&st, s_bm[k], y, v, s_lt);  // (NaN fails)
         }
         for (int64_t i = r0 + kTpCap + tid; i < r1; i += kTpThreads) {  // rows beyond the LDS cache stream from HBM
             const double y = w.dispGene[i];
@@ -221,6 +424,53 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
         }
         __syncthreads();
     }
+    // ---- MAD of the log residuals around the trend (estimateDispersionsFit's varLogDispEsts), see mad_select above --------
+    double med = NAN, madv = NAN, nres = 0;
+    if (mad && alive) {
+#ifdef CHICDIFF_MAD_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) { g_mad_t0 = __builtin_amdgcn_s_memrealtime(); g_mad_n = 0; }
+#endif
+        const double c0 = st.coefs[0], c1 = st.coefs[1];
+        // residuals as resid_kernel forms them (same expressions: same bits), to w.resid and — cached rows — over y in LDS
+        for (int64_t k = tid; k < nrows; k += kTpThreads) {
+            const int64_t i = r0 + k;
+            const double y = k < ncache ? s_y[k] : (w.allZero[i] ? NAN : w.dispGene[i]);
+            double r = NAN;
+            if (y >= thr) r = log(y) - log(c0 + c1 / w.baseMean[i]);
+            w.resid[i] = r;
+            if (k < ncache) s_y[k] = r;
+        }
+        __syncthreads();
+        MSTAMP(0);
+        // the freed 1 / baseMean cache holds the select's LDS histograms and, afterwards, the candidates being sorted
+        unsigned int *s_a = reinterpret_cast<unsigned int *>(s_bm), *s_b = s_a + kSelBins;
+        uint64_t *sortbuf = reinterpret_cast<uint64_t *>(s_bm);
+        const double *resid_g = w.resid + r0;
+        uint64_t res[2];
+        double pop = 0;
+        auto key_resid = [&](int64_t k, uint64_t &key) {
+            const double x = k < ncache ? s_y[k] : resid_g[k];
+            if (x != x) return false;
+            key = key_of(x);
+            return true;
+        };
+        alive = mad_select(key_resid, nrows, 0, gscratch, s_a, s_b, sortbuf, ctr, grp, pass, res, pop);
+        if (alive) {
+            nres = pop;
+            med = pop > 0 ? (value_of(res[0]) + value_of(res[1])) / 2.0 : NAN;  // R median(): mean of the two middles
+            const double m0 = med;
+            auto key_absdev = [&](int64_t k, uint64_t &key) {
+                double x = k < ncache ? s_y[k] : resid_g[k];
+                if (x != x) return false;
+                x = fabs(x - m0);
+                if (x != x) return false;
+                key = key_of(x);
+                return true;
+            };
+            alive = mad_select(key_absdev, nrows, 1, gscratch, s_a, s_b, sortbuf, ctr, grp, pass, res, pop);
+            if (alive) madv = 1.4826 * (pop > 0 ? (value_of(res[0]) + value_of(res[1])) / 2.0 : NAN);  // R mad(): constant 1.4826
+        }
+    }
     if (blockIdx.x == 0 && tid == 0) {
         FitScalars *sc = w.sc;
         sc->coefs[0] = st.coefs[0]; sc->coefs[1] = st.coefs[1];
@@ -230,6 +480,15 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
         sc->conv = st.conv;
         sc->failed = alive ? (st.finished ? st.failed : 2) : 3;  // 3: grid barrier timed out
         sc->finished = 1;
+#ifdef CHICDIFF_MAD_STAMPS
+        for (int q = 0; q < g_mad_n; q++) printf("  mad stamp %3d %8.2f us\n", g_mad_lab[q], (double)(g_mad_t[q] - g_mad_t0) / 100.0);
+#endif
+        if (mad && alive) {
+            sc->med = med;
+            sc->nres = nres;
+            sc->mad = madv;
+            if (!madargs.by_simulation) prior_var(sc, madargs.S, madargs.p, madargs.prior_in);  // (else prior_mc_kernel follows)
+        }
     }
 }
 // sharded fits: this rank's slice of the rows the trend is fitted to, written into the all-ranks arrays (zero elsewhere; the
@@ -265,7 +524,7 @@ void launch_poke(int32_t *p, int32_t v, hipStream_t st) { poke_kernel<<<1, 1, 0,
 __global__ void flag_to_double_kernel(const int32_t *flag, double *out) { *out = *flag ? 1.0 : 0.0; }
 void launch_flag_to_double(const int32_t *flag, double *out, hipStream_t st) { flag_to_double_kernel<<<1, 1, 0, st>>>(flag, out); }
 int trend_persistent_blocks() { return kTpBlocks; }
-void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
+void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st, bool with_mad) {
     // (the barrier counters were zeroed with the fit's scalars; the trend runs once per fit)
     // as few workgroups as keep every row LDS-resident: the pass time is the grid barrier plus the all-partials sum,
     // both of which grow with the number of workgroups (small fits are latency-bound by these ~20 passes)
@@ -277,7 +536,13 @@ void launch_trend_persistent(FitDims d, FitWork w, Opts o, hipStream_t st) {
     // fewer on request: several fits sharing one GPU (the one-GPU rehearsal of a sharded fit) must keep ALL their trend kernels'
     // workgroups resident at once, or the grid barriers time out; rows beyond the LDS cache stream from HBM / L2
     if (o.trend_blocks > 0 && blocks > o.trend_blocks) blocks = o.trend_blocks;
-    trend_persistent_kernel<<<(unsigned)blocks, kTpThreads, 0, st>>>(d, w, o.minDisp);
+    MadArgs m{};
+    m.enabled = with_mad ? 1 : 0;
+    m.S = d.S;
+    m.p = d.p;
+    m.prior_in = o.dispPriorVarIn;
+    m.by_simulation = (!(o.dispPriorVarIn == o.dispPriorVarIn) && d.S - d.p <= 3 && d.S > d.p) ? 1 : 0;
+    trend_persistent_kernel<<<(unsigned)blocks, kTpThreads, 0, st>>>(d, w, o.minDisp, m);
 }
 
 void launch_trend_init(FitDims, FitWork w, Opts, hipStream_t st) { trend_init_kernel<<<1, 1, 0, st>>>(w); }

@@ -427,6 +427,27 @@ __device__ __forceinline__ double trim_scale(int n) { return n <= 3 ? 2.04 : (n 
 __device__ __forceinline__ double cell_trimmed_mean(const double *s_q, int T, int tid, int S, uint64_t gmask, int c,
                                                     int nc, int lo, bool sq, double cm) {
     double sum = 0;
+    if (lo == 1) {
+        // cells of 3 .. 7 samples (every design up to 7 v 7): one value dropped at each end.  The element of rank 0 is the smallest
+        // value, lowest index among equals; the element of rank nc - 1 the largest, highest index among equals: two linear passes
+        // instead of nc^2 comparisons, and the kept values are added in index order as below — the same bits
+        int imin = -1, imax = -1;
+        double vmin = INFINITY, vmax = -INFINITY;
+        for (int j = 0; j < S; j++) {
+            if ((int)((gmask >> j) & 1) != c) continue;
+            double vj = s_q[j * T + tid];
+            if (sq) vj = (vj - cm) * (vj - cm);
+            if (vj < vmin) { vmin = vj; imin = j; }
+            if (vj >= vmax) { vmax = vj; imax = j; }
+        }
+        for (int j = 0; j < S; j++) {
+            if ((int)((gmask >> j) & 1) != c || j == imin || j == imax) continue;
+            double vj = s_q[j * T + tid];
+            if (sq) vj = (vj - cm) * (vj - cm);
+            sum += vj;
+        }
+        return sum / (nc - 2);
+    }
     for (int j = 0; j < S; j++) {
         if ((int)((gmask >> j) & 1) != c) continue;
         double vj = s_q[j * T + tid];

@@ -93,6 +93,8 @@ int32_t chicdiff_hip_last_refits(const chicdiff_hip_ctx *ctx);
  *   "trend_persistent_blocks"   0 (default: one workgroup per CU), 1 .. 256: cap on the workgroups of the single-launch trend
  *                               kernel, for fits that share one GPU (its grid barrier needs all of them resident at once); the
  *                               coefficients then differ in summation order only (1e-13)
+ *   "trend_mad_in_kernel"       1 (default) | 0: the single-launch trend kernel goes on to the residuals, their exact median and MAD
+ *                               and the closed-form prior variance; 0 = separate launches (residuals, two radix selects): same bits
  *   "fault_inject"              0 (default); test hook, one-shot bits consumed by the next call: 1 = this rank reports a select
  *                               overflow in its next fit, 2 = a grid-barrier timeout of its trend kernel, 4 = an overflow of its
  *                               next size-factor select — to prove that all ranks of a sharded fit refit together
