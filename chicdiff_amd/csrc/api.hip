@@ -1570,9 +1570,13 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         l->opt_trend_gather = c->opt_trend_gather;
         l->opt_select_rounds = c->opt_select_rounds;
         l->opt_trend_multilaunch = c->opt_trend_multilaunch;
-        l->opt_trend_blocks = c->opt_trend_blocks;
         l->opt_mad_in_kernel = c->opt_mad_in_kernel;
-        l->no_persistent_trend = true;  // a grid barrier needs its workgroups co-resident: not guaranteed beside other fits
+        l->opt_trend_blocks = c->opt_trend_blocks;
+        // a grid barrier needs its workgroups co-resident: not guaranteed beside other fits.  (Measured, round 4: the lanes' trend as
+        // the single-launch kernel capped at 16 / 32 / 64 workgroups — 2 M x 8, five thetas: 2 lanes 16.5 -> 18.2 ms, 3 lanes 17.2 ->
+        // 17.9, 5 lanes 16.3 ms -> 5-13 SECONDS: the kernel's workgroups wait for LDS that the other lanes' line-search workgroups
+        // hold until their launch ends, and the barrier spins meanwhile.  One launch per IRLS pass it stays.)
+        l->no_persistent_trend = true;
         workers.emplace_back([=, &lane_rc]() {
             int r = CHICDIFF_OK;
             if (hipSetDevice(l->device) != hipSuccess || hipStreamWaitEvent(l->stream, ready, 0) != hipSuccess) r = CHICDIFF_E_HIP;
