@@ -905,10 +905,34 @@ static int gathered_trend(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
     return CHICDIFF_OK;
 }
 
+// Per-row workspace columns the caller wants back are written where the caller wants them (round 3 copied them out when the fit
+// ended: two 16 MB device copies per bench step): for the duration of one fit the workspace pointers point into the caller's
+// buffers; restored on every way out.
+struct WorkRedirect {
+    chicdiff_hip_ctx *c;
+    FitWork saved;
+    WorkRedirect(chicdiff_hip_ctx *c_, const chicdiff_nbglm_out *o) : c(c_), saved(c_->w) {
+        if (!o) return;
+        FitWork &w = c->w;
+        if (o->baseMean) w.baseMean = o->baseMean;
+        if (o->baseVar) w.baseVar = o->baseVar;
+        if (o->dispGeneEst) w.dispGene = o->dispGeneEst;
+        if (o->dispFit) w.dispFit = o->dispFit;
+        if (o->dispMAP) w.dispMAP = o->dispMAP;
+        if (o->dispersion) w.disp = o->dispersion;
+        if (o->dispGeneIter) w.geneIter = o->dispGeneIter;
+        if (o->dispIter) w.mapIter = o->dispIter;
+        if (o->dispOutlier) w.outlier = o->dispOutlier;
+        if (o->allZero) w.allZero = o->allZero;
+    }
+    ~WorkRedirect() { c->w = saved; }
+};
+
 static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const double *d_nf, FitDims d, Opts o,
                         const chicdiff_nbglm_out *d_out, chicdiff_nbglm_scalars *scalars) {
     int rc;
     hipStream_t st = c->stream;
+    WorkRedirect redirect(c, d_out);
     FitWork &w = c->w;
     c->tg_total = 0;
     // the scalars, the queue heads and the barrier counters sit next to each other in the workspace: one fill
@@ -1090,24 +1114,15 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         Scope t(c, "wald_intercept");
         launch_wald_intercept(d_counts, d_nf, d, w, o, out, st);
     }
-    launch_dev_sum_finish(d, w, c->d_carry, st);
+    launch_dev_sum_finish(d, w, c->d_carry, c->d_sf, st);
     // deviance sum, non-converged rows, all-zero rows, then four verdicts as rank counts: trend kernel timed out, negative / NA count,
     // a select's candidate list overflowed in this fit, ... in the size-factor select the caller ran before it
-    if ((rc = do_allreduce(c, sums_of(w), 7))) return rc;
-    // copy the per-row workspace columns the caller asked for
-    const size_t nb = sizeof(double) * (size_t)d.n, ib = sizeof(int32_t) * (size_t)d.n;
-#define CPY(dst, src, bytes) \
-    if (out.dst) HIPCHK(c, hipMemcpyAsync(out.dst, src, bytes, hipMemcpyDeviceToDevice, st))
-    CPY(baseMean, w.baseMean, nb); CPY(baseVar, w.baseVar, nb); CPY(dispGeneEst, w.dispGene, nb);
-    CPY(dispFit, w.dispFit, nb); CPY(dispMAP, w.dispMAP, nb); CPY(dispersion, w.disp, nb);
-    CPY(dispGeneIter, w.geneIter, ib); CPY(dispIter, w.mapIter, ib); CPY(dispOutlier, w.outlier, ib);
-    CPY(allZero, w.allZero, ib);
-#undef CPY
-    double hs[7];
+    if ((rc = do_allreduce(c, w.sc->final_sums, 7))) return rc;
+    // one read brings the scalars, the sums and the size factors back (the per-row columns the caller asked for were written in place)
     HIPCHK(c, hipMemcpyAsync(c->h_sc, w.sc, sizeof(FitScalars), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hs, sums_of(w), sizeof hs, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
+    const double *hs = c->h_sc->final_sums;
     // hs[4] is all-reduced like the other sums: a negative / NA count on ANY rank has entered everybody's size factors, trend and
     // prior, so every rank refuses the fit together (and none goes on to the retry below, whose collectives the others would miss)
     if (hs[4] > 0)
@@ -1327,8 +1342,9 @@ int chicdiff_hip_nbglm_fit(chicdiff_hip_ctx *c, const int32_t *counts, const dou
 // the fit does not clear), from where the fit's last all-reduce — or sf_overflow_consensus — makes it every rank's verdict.
 static int size_factors_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, int64_t n, int32_t S) {
     Scope t(c, "size_factors");
-    HIPCHK(c, hipMemsetAsync(&c->w.sc->sel_overflow, 0, sizeof(int32_t), c->stream));  // (a fit clears it too, but none may have run yet)
-    launch_row_ratio(d_counts, n, S, c->d_nf_tmp, c->stream);  // the offsets buffer is free until the size factors exist
+    // (the offsets buffer is free until the size factors exist; the same kernel clears the select's overflow flag, c->d_carry — a
+    // device word the fit does not clear: the fit's last kernel carries it into the all-reduced verdicts)
+    launch_row_ratio(d_counts, n, S, c->d_nf_tmp, c->d_carry, c->stream);
     SelArgs sa{};
     sa.mode = SEL_SIZEFACTOR;
     sa.ncol = S;
@@ -1336,13 +1352,13 @@ static int size_factors_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, int64
     sa.ratio = c->d_nf_tmp;
     sa.S = S;
     sa.sf_out = c->d_sf;  // the finishing step of the select writes the size factors there
+    sa.overflow_out = c->d_carry;
     const int rc = run_select(c, sa);
     if (rc) return rc;
     if (c->opt_fault & 4) {  // test hook: this rank's size-factor select "could not fit its candidate list"
         c->opt_fault &= ~4;
-        launch_poke(&c->w.sc->sel_overflow, 1, c->stream);
+        launch_poke(c->d_carry, 1, c->stream);
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_carry, &c->w.sc->sel_overflow, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     return CHICDIFF_OK;
 }
 
@@ -1418,8 +1434,7 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
                 Scope t(c, "offsets");
                 launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, c->d_nf_tmp, c->stream);
             }
-            HIPCHK(c, hipMemcpyAsync(c->h_sf, c->d_sf, sizeof(double) * S, hipMemcpyDeviceToHost, c->stream));  // pinned: no stall
-            r = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(c, opts, S), d_out, scalars);  // ends with a stream sync
+            r = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(c, opts, S), d_out, scalars);  // ends with a stream sync; the size factors come back with its scalars
             // the sharded size-factor select ran without a host look at its candidate lists: one that did not fit on ANY rank (massive
             // ties) shows in the fit's last all-reduce, on every rank alike, and the call is repeated with every histogram round
             if (r || !c->sf_overflow_seen || c->opt_select_rounds) return r;
@@ -1433,9 +1448,9 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
     timing_collect(c);
     if (rc) return rc;
     for (int j = 0; j < S; j++) {
-        if (!(c->h_sf[j] == c->h_sf[j]))
+        if (!(c->h_sc->final_sf[j] == c->h_sc->final_sf[j]))
             return fail(c, CHICDIFF_E_NUMERIC, "every gene contains at least one zero, cannot compute log geometric means");
-        if (sf_host) sf_host[j] = c->h_sf[j];
+        if (sf_host) sf_host[j] = c->h_sc->final_sf[j];
     }
     return CHICDIFF_OK;
 }

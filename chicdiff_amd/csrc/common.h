@@ -125,7 +125,9 @@ void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWo
                        const chicdiff_nbglm_out &out, hipStream_t st);
 void launch_wald_intercept(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                            const chicdiff_nbglm_out &out, hipStream_t st);
-void launch_dev_sum_finish(FitDims d, FitWork w, const int32_t *carry, hipStream_t st);  // carry: the size-factor select's overflow flag (may be NULL)
+// the fit's last kernel: deviance / row-count sums and this rank's verdicts into sc->final_sums, the size factors into sc->final_sf;
+// carry: overflow flag of the size-factor select the caller ran before the fit (may be NULL); sf_dev: its size factors (may be NULL)
+void launch_dev_sum_finish(FitDims d, FitWork w, const int32_t *carry, const double *sf_dev, hipStream_t st);
 
 // radix select over keys produced on the fly; `mode` (SelMode, fit_driver.h) picks the key generator
 struct SelArgs {
@@ -137,6 +139,7 @@ struct SelArgs {
     int S;
     int shift;              // bit position of the current digit
     double *sf_out;         // SEL_SIZEFACTOR: where the size factors go as well (device, may be NULL)
+    int32_t *overflow_out;  // sharded shortcut: set to 1 when a candidate list does not fit (NULL = sc->sel_overflow)
 };
 void launch_sel_hist(SelArgs a, FitWork w, hipStream_t st);     // digit histograms for the live prefixes
 void launch_sel_step(SelArgs a, FitWork w, hipStream_t st);     // pick bins, extend prefixes
@@ -148,7 +151,7 @@ void launch_sel_gather_counts(SelArgs a, FitWork w, int world, int rank, hipStre
 void launch_sel_gather_place(SelArgs a, FitWork w, int world, int rank, hipStream_t st);
 void launch_sel_gather_finish(SelArgs a, FitWork w, int world, int rank, hipStream_t st);
 
-void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, hipStream_t st);  // keys of the size-factor medians
+void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, int32_t *clear_flag, hipStream_t st);  // keys of the size-factor medians (+ *clear_flag = 0)
 void launch_offsets(const double *fullMean, const double *sf_dev, int64_t n, int S, double theta, int mix,
                     double *out, hipStream_t st);
 void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfrag, int S, const int64_t *rptr,

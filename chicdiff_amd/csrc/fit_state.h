@@ -56,6 +56,12 @@ struct FitScalars {
     // sharded selects run optimistically (no host look at sel_fast_done): a candidate list that did not fit (massive ties)
     // leaves this set, the host sees it with the fit's final scalars and refits with every histogram round
     int32_t sel_overflow, _pad3;
+    // what the host reads when a fit ends, gathered here by the fit's last kernel so that ONE copy brings everything back:
+    // [0] deviance sum, [1] non-converged rows, [2] all-zero rows, then four verdicts of this rank (all seven summed over the ranks
+    // of a sharded fit): [3] trend kernel's grid barrier timed out, [4] negative / NA count, [5] a select's candidate list overflowed
+    // in this fit, [6] ... in the size-factor select the caller ran before it; and the size factors of that select
+    double final_sums[8];
+    double final_sf[kMaxS];
 };
 
 // order-preserving map double -> uint64 (NaN never passed in)

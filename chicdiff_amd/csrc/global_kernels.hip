@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(256) void sel_gfinish_kernel(SelArgs a, FitWork w, 
     FitScalars *sc = w.sc;
     const int nq = 2 * a.ncol;
     if (!sel_gather_fits(w.selcnt, world, nq)) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) sc->sel_overflow = 1;  // the host refits with every histogram round (api.hip)
+        if (blockIdx.x == 0 && threadIdx.x == 0) *(a.overflow_out ? a.overflow_out : &sc->sel_overflow) = 1;  // the host refits with every histogram round (api.hip)
         return;
     }
     const int col = blockIdx.x;
@@ -1122,7 +1122,8 @@ void launch_sel_gather_finish(SelArgs a, FitWork w, int world, int rank, hipStre
 // a finite log geometric mean, and only positive counts), NaN otherwise.  The select passes then stream
 // 8 B per element instead of recomputing a log.
 __global__ __launch_bounds__(256) void row_ratio_kernel(const int32_t *__restrict__ counts, int64_t n, int S,
-                                                        double *__restrict__ ratio) {
+                                                        double *__restrict__ ratio, int32_t *clear_flag) {
+    if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double s = 0;
         for (int j = 0; j < S; j++) {
@@ -1136,7 +1137,8 @@ __global__ __launch_bounds__(256) void row_ratio_kernel(const int32_t *__restric
     }
 }
 __global__ __launch_bounds__(256) void row_ratio16_kernel(const int32_t *__restrict__ counts, int64_t n, int S,
-                                                          double *__restrict__ ratio) {
+                                                          double *__restrict__ ratio, int32_t *clear_flag) {
+    if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;  // (the select that follows may set it)
     __shared__ LogEntry s_lt[64];
     log_table_to_lds(s_lt);
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -1157,9 +1159,9 @@ __global__ __launch_bounds__(256) void row_ratio16_kernel(const int32_t *__restr
             if (j < S) ratio[(int64_t)j * n + i] = use ? l[j] - lg : NAN;
     }
 }
-void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, hipStream_t st) {
-    if (S <= 16) row_ratio16_kernel<<<kRedBlocks * 2, 256, 0, st>>>(counts, n, S, ratio);
-    else row_ratio_kernel<<<kRedBlocks, 256, 0, st>>>(counts, n, S, ratio);
+void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, int32_t *clear_flag, hipStream_t st) {
+    if (S <= 16) row_ratio16_kernel<<<kRedBlocks * 2, 256, 0, st>>>(counts, n, S, ratio, clear_flag);
+    else row_ratio_kernel<<<kRedBlocks, 256, 0, st>>>(counts, n, S, ratio, clear_flag);
 }
 
 // a4: offsets.  One thread per row.  For S <= 16 the row lives in registers (one HBM read, one write);

@@ -645,11 +645,12 @@ __global__ __launch_bounds__(256) void wald_intercept_kernel(const int32_t *__re
             (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-// partials (kRedBlocks x 3) -> sums[0..7): deviance sum, non-converged rows, all-zero rows, and four verdicts of this rank (1 = yes):
-// trend-barrier timeout, negative counts, select overflow in this fit, select overflow in the size-factor select before it
-__global__ void dev_sum_kernel(FitWork w, const int32_t *carry) {
+// partials (kRedBlocks x 3) -> sc->final_sums[0..7): deviance sum, non-converged rows, all-zero rows, and four verdicts of this
+// rank (1 = yes): trend-barrier timeout, negative counts, select overflow in this fit, select overflow in the size-factor select
+// before it; plus the size factors of that select -> sc->final_sf, so that one read of the scalars brings everything to the host
+__global__ void dev_sum_kernel(FitWork w, const int32_t *carry, const double *sf_dev, int S) {
     __shared__ double red[256];
-    double *sums = w.partials + (size_t)kRedBlocks * 72;
+    double *sums = w.sc->final_sums;
     for (int k = 0; k < 3; k++) {
         double acc = 0;
         for (int b = threadIdx.x; b < kRedBlocks; b += 256) acc += w.partials[(size_t)b * 3 + k];
@@ -669,7 +670,9 @@ __global__ void dev_sum_kernel(FitWork w, const int32_t *carry) {
         sums[4] = w.sc->neg_counts ? 1.0 : 0.0;  // a rank that saw a negative / NA count: every rank must refuse the fit (api.hip)
         sums[5] = w.sc->sel_overflow ? 1.0 : 0.0;  // a candidate list of a sharded select did not fit: every rank refits (api.hip)
         sums[6] = (carry && *carry) ? 1.0 : 0.0;
+        sums[7] = 0.0;
     }
+    if (sf_dev && (int)threadIdx.x < S) w.sc->final_sf[threadIdx.x] = sf_dev[threadIdx.x];
 }
 
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
@@ -705,6 +708,8 @@ void launch_wald_intercept(const int32_t *counts, const double *nf, FitDims d, F
                            const chicdiff_nbglm_out &out, hipStream_t st) {
     wald_intercept_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w, out);
 }
-void launch_dev_sum_finish(FitDims, FitWork w, const int32_t *carry, hipStream_t st) { dev_sum_kernel<<<1, 256, 0, st>>>(w, carry); }
+void launch_dev_sum_finish(FitDims d, FitWork w, const int32_t *carry, const double *sf_dev, hipStream_t st) {
+    dev_sum_kernel<<<1, 256, 0, st>>>(w, carry, sf_dev, d.S);
+}
 
 }  // namespace cd
