@@ -35,11 +35,11 @@ def rel(a, b):
     return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
 
 
-def _scenario(c, rank, world, ref_dir):
+def _scenario(c, rank, world, ref_dir, n_rows=N_ROWS, S=S, legs=None):
     """One rank's part: the plain sharded fit, then the three forced refits; each compared with this rank's slice of the
     single-rank reference the parent saved under `ref_dir`.  Returns a small report."""
     from chicdiff_amd.dist import shard_bounds
-    lo, hi = shard_bounds(N_ROWS, world, rank)
+    lo, hi = shard_bounds(n_rows, world, rank)
     d = synth.make(hi - lo, S, start=lo)
     dk = c.to_device(d["counts"], np.int32)
     dF = c.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)
@@ -47,7 +47,7 @@ def _scenario(c, rank, world, ref_dir):
     ref = {k: np.load(os.path.join(ref_dir, k + ".npy"), mmap_mode="r")[lo:hi] for k in WANT}
     ref_sc = np.load(os.path.join(ref_dir, "scalars.npy"))
     report = dict(rank=rank, rows=hi - lo, legs={})
-    for name, fault, want_refits in LEGS:
+    for name, fault, want_refits in (legs or LEGS):
         if fault is not None and rank == (fault[0] % world):
             c.set_option("fault_inject", fault[1])
         c.enable_timing(1 if name == "plain" else 0)
@@ -77,30 +77,30 @@ def _scenario(c, rank, world, ref_dir):
     return report
 
 
-def _check_reports(reports, world):
+def _check_reports(reports, world, legs=None, n_rows=N_ROWS):
     assert sorted(r["rank"] for r in reports) == list(range(world))
-    for name, fault, want_refits in LEGS:
-        legs = [r["legs"][name] for r in sorted(reports, key=lambda r: r["rank"])]
-        refits = [leg["refits"] for leg in legs]
-        print(f"world {world} / {name}: refits per rank {refits}, scalars identical {[l['scalars_identical'] for l in legs]}, "
-              f"rows identical {[l['rows_identical'] for l in legs]}, worst rel {max(l['rows_max_rel'] for l in legs):.2e}")
+    for name, fault, want_refits in (legs or LEGS):
+        legs_ = [r["legs"][name] for r in sorted(reports, key=lambda r: r["rank"])]
+        refits = [leg["refits"] for leg in legs_]
+        print(f"world {world} / {name}: refits per rank {refits}, scalars identical {[l['scalars_identical'] for l in legs_]}, "
+              f"rows identical {[l['rows_identical'] for l in legs_]}, worst rel {max(l['rows_max_rel'] for l in legs_):.2e}")
         assert refits == [want_refits] * world, (name, refits)   # every rank re-entered, once — or nobody did
-        assert all(l["nan_pattern_equal"] for l in legs), name
-        assert len({tuple(l["trendCoef"]) for l in legs}) == 1, name  # the same trend on every rank
+        assert all(l["nan_pattern_equal"] for l in legs_), name
+        assert len({tuple(l["trendCoef"]) for l in legs_}) == 1, name  # the same trend on every rank
         if name != "trend_barrier_timeout_on_rank_0":
             # same rows, same order, same kernels as the single-rank fit: the same bits
-            assert all(l["scalars_identical"] for l in legs), (name, [l["scalars_max_rel"] for l in legs])
-            assert all(l["rows_identical"] for l in legs), (name, [l["rows_max_rel"] for l in legs])
+            assert all(l["scalars_identical"] for l in legs_), (name, [l["scalars_max_rel"] for l in legs_])
+            assert all(l["rows_identical"] for l in legs_), (name, [l["rows_max_rel"] for l in legs_])
         else:
             # the refit runs the trend with one launch + one all-reduce per IRLS pass: the same sums in another order, coefficients
             # ~1e-13 apart.  This is a check of the refit's plumbing, not of parity: what a 1e-13 shift of the prior mean does to
             # DESeq2's line search is the algorithm's own business (its Armijo and `change < 1e-6` tests have no margin on rows
             # with flat likelihoods: the single-rank fit against ITSELF with the trend sums in another order moves 1e-4 of the
             # rows beyond 1e-9 — printed by the `reference` fixture).  Counted here, bounded at 2 rows in 10 000 beyond 1e-6
-            n_off = sum(l["rows_off_1e-6"] for l in legs)
-            print(f"world {world} / {name}: scalars max rel {max(l['scalars_max_rel'] for l in legs):.2e}, rows beyond 1e-6: {n_off} of {N_ROWS}")
-            assert max(l["scalars_max_rel"] for l in legs) < 1e-10, name
-            assert n_off <= 2e-4 * N_ROWS, (name, n_off)
+            n_off = sum(l["rows_off_1e-6"] for l in legs_)
+            print(f"world {world} / {name}: scalars max rel {max(l['scalars_max_rel'] for l in legs_):.2e}, rows beyond 1e-6: {n_off} of {n_rows}")
+            assert max(l["scalars_max_rel"] for l in legs_) < 1e-10, name
+            assert n_off <= 2e-4 * n_rows, (name, n_off)
     coll = [r["legs"]["plain"]["collectives"] for r in sorted(reports, key=lambda r: r["rank"])]
     print(f"world {world}: collectives of one sharded fit on rank 0: {coll[0]}")
     for cst in coll:
@@ -239,10 +239,9 @@ class _ThreadTransport:
             self.gather_fns.append(g)
 
 
-def test_world8_ranks_sharing_the_gpu_at_2Mx8_equal_the_single_rank_fit(reference):
+def _run_thread_ranks(world, ref_dir, n_rows=N_ROWS, S=S, legs=None):
     import torch
     from chicdiff_amd import hip
-    world = 8
     tr = _ThreadTransport(world, torch, torch.device("cuda", 0))
     ctxs = [hip.HipContext(0, use_torch_stream=False) for _ in range(world)]  # own non-blocking stream each
     reports, errors = [None] * world, [None] * world
@@ -252,7 +251,7 @@ def test_world8_ranks_sharing_the_gpu_at_2Mx8_equal_the_single_rank_fit(referenc
             c = ctxs[rank]
             c._check(c.lib.chicdiff_hip_set_allreduce(c.h, tr.reduce_fns[rank], None, world, rank))
             c._check(c.lib.chicdiff_hip_set_allgather(c.h, tr.gather_fns[rank], None))
-            reports[rank] = _scenario(c, rank, world, reference[world])
+            reports[rank] = _scenario(c, rank, world, ref_dir, n_rows=n_rows, S=S, legs=legs)
         except Exception as e:  # noqa: BLE001
             errors[rank] = e
             tr.barrier.abort()  # the peers' collectives fail instead of waiting for this rank for ever
@@ -264,9 +263,40 @@ def test_world8_ranks_sharing_the_gpu_at_2Mx8_equal_the_single_rank_fit(referenc
         t.join(900)
     assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
     assert all(e is None for e in errors) and tr.error is None, (errors, tr.error)
-    _check_reports(reports, world)
     for c in ctxs:
         c.close()
+    return reports
+
+
+def test_world8_ranks_sharing_the_gpu_at_2Mx8_equal_the_single_rank_fit(reference):
+    _check_reports(_run_thread_ranks(8, reference[8]), 8)
+
+
+def test_world8_ranks_at_20Mx16_equal_the_single_rank_fit(tmp_path):
+    """BASELINE.json configs[4]'s matrix (20 M interactions x 16 samples, 8 v 8) sharded over eight ranks — 2.5 M rows each, on the one
+    GPU of the box (threads transport) — against the single-rank fit of the whole matrix: bit for bit, one all-gather of 2 x 2.5 M
+    doubles per rank for the trend rows.  (The forced-refit legs run at 2 M x 8 above.)"""
+    import gc
+    import torch
+    from chicdiff_amd import hip
+    n_rows, S16, world = 20_000_000, 16, 8
+    c = hip.HipContext(0)
+    c.set_option("trend_persistent_blocks", 256 // world)
+    d = synth.make(n_rows, S16)
+    dk = c.to_device(d["counts"], np.int32)
+    dF = c.to_device(d["nf"] * (d["mu"][:, None] / S16), np.float64)
+    group = d["group"]
+    del d
+    gc.collect()
+    out, sc = c.wald_test(dk, dF, group, theta=0.5, want=WANT)
+    for k in WANT:
+        np.save(os.path.join(tmp_path, k + ".npy"), out[k].cpu().numpy())
+    np.save(os.path.join(tmp_path, "scalars.npy"), np.array(list(sc["trendCoef"]) + [sc["varLogDispEsts"], sc["dispPriorVar"]] + list(sc["sizeFactors"])))
+    del out, dk, dF
+    c.close()
+    torch.cuda.empty_cache()
+    legs = [LEGS[0]]
+    _check_reports(_run_thread_ranks(world, str(tmp_path), n_rows=n_rows, S=S16, legs=legs), world, legs=legs, n_rows=n_rows)
 
 
 def test_option_select_all_rounds_survives_an_overflow_refit(reference):
