@@ -575,7 +575,6 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
     }
     MARK("row:table_end");
     Acc acc;
-#pragma unroll
     for (int j = 0; j < S; j++) {
         const int yi = s_y[j * 64 + slot];
         const int n = yi < c.nr ? yi : c.nr;
@@ -681,9 +680,7 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
     MARK("spread:pickup_end");
 }
 
-// SC: the number of samples when known at compile time (the loops over samples unroll: no loop control, LDS operands at immediate
-// offsets, their loads hoisted), 0 = taken from the arguments
-template <bool MAP, int MINW, int SC = 0>
+template <bool MAP, int MINW>
 __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     extern __shared__ double smem[];
     __shared__ LogEntry s_logtab[64];
@@ -691,7 +688,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     exp_table_to_lds(s_exptab);
     log_table_to_lds(s_logtab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int S = SC ? SC : A.d.S;
+    const int S = A.d.S;
     const int64_t n = A.d.n;
     // per wave: 22*64 doubles (prefix table) + S*64 doubles (nf) + S*64 ints (counts)
     double *s_tab = smem + (size_t)wave * (22 * 64 + S * 96);
@@ -1116,10 +1113,7 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
 #endif
     const int variant = o.min_waves;
 #define LAUNCH(M, W) disp_fit_kernel<M, W><<<(unsigned)blocks, threads, lds, st>>>(A)
-    if (d.S == 8 && variant <= 2 && getenv("CHICDIFF_UNROLL_S8")) {
-        if (map) disp_fit_kernel<true, 2, 8><<<(unsigned)blocks, threads, lds, st>>>(A);
-        else disp_fit_kernel<false, 2, 8><<<(unsigned)blocks, threads, lds, st>>>(A);
-    } else if (map) {
+    if (map) {
         if (variant >= 4) LAUNCH(true, 4); else if (variant == 3) LAUNCH(true, 3); else LAUNCH(true, 2);
     } else {
         if (variant >= 4) LAUNCH(false, 4); else if (variant == 3) LAUNCH(false, 3); else LAUNCH(false, 2);
