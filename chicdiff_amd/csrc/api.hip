@@ -1590,7 +1590,10 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         // a grid barrier needs its workgroups co-resident: not guaranteed beside other fits.  (Measured, round 4: the lanes' trend as
         // the single-launch kernel capped at 16 / 32 / 64 workgroups — 2 M x 8, five thetas: 2 lanes 16.5 -> 18.2 ms, 3 lanes 17.2 ->
         // 17.9, 5 lanes 16.3 ms -> 5-13 SECONDS: the kernel's workgroups wait for LDS that the other lanes' line-search workgroups
-        // hold until their launch ends, and the barrier spins meanwhile.  One launch per IRLS pass it stays.)
+        // hold until their launch ends, and the barrier spins meanwhile.  With the uncapped kernel and a host mutex so that only one
+        // lane's trend kernel is in flight at a time: 5 lanes 16.2 -> 18.1 ms.  A kernel trace of the grid (tools/theta_grid_trace.py)
+        // shows why nothing small overlaps: while a line-search launch is resident, the other streams' small kernels do not start at
+        // all — they run in the gaps between the big launches.  One launch per IRLS pass it stays.)
         l->no_persistent_trend = true;
         workers.emplace_back([=, &lane_rc]() {
             int r = CHICDIFF_OK;

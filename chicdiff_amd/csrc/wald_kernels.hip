@@ -584,10 +584,17 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
     }
 }
 
-// design ~1: fitNbinomGLMs' intercept-only shortcut (no IRLS)
+// design ~1: fitNbinomGLMs' intercept-only shortcut (no IRLS).  This is the Wald stage of every theta-grid fit (chicdiff.R:1641-1647),
+// where nothing overlaps it (the line-search launches of the other thetas fill the chip: small kernels wait for them), so it is
+// written as lean as wald_prep: log y! from the table, table-driven logarithms, one reciprocal per offset instead of two divisions
+// (round 3: IEEE divisions, polynomial logs, a second Stirling evaluation for log y!: 0.33 ms per fit at 2 M x 8).
 __global__ __launch_bounds__(256) void wald_intercept_kernel(const int32_t *__restrict__ counts,
                                                              const double *__restrict__ nf, FitDims d, FitWork w,
                                                              chicdiff_nbglm_out out) {
+    __shared__ double s_logfact[kLogFactN];
+    __shared__ LogEntry s_lt[64];
+    for (int k = threadIdx.x; k < kLogFactN; k += 256) s_logfact[k] = w.logfact[k];
+    log_table_to_lds(s_lt);  // (ends with the barrier)
     const int64_t n = d.n;
     const int S = d.S;
     double v[3] = {0, 0, 0};
@@ -596,21 +603,44 @@ __global__ __launch_bounds__(256) void wald_intercept_kernel(const int32_t *__re
         const bool az = w.allZero[i];
         if (!az) {
             const double alpha = w.disp[i], size = rcp(alpha);
+            // the row is read ONCE (S <= 16: counts and offsets stay in registers between the two passes over the samples; round 3 read
+            // both matrices twice: 384 MB at 2 M x 8, which is what the kernel's 0.33 ms were)
+            double f[16];
+            int yv[16];
             double bm = 0;
-            for (int j = 0; j < S; j++) bm += (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i];
+            if (S <= 16) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    f[j] = 1.0;
+                    yv[j] = 0;
+                    if (j < S) {
+                        yv[j] = counts[(int64_t)j * n + i];
+                        f[j] = nf[(int64_t)j * n + i];
+                        bm += (double)yv[j] / f[j];  // (as prep: the same baseMean)
+                    }
+                }
+            } else {
+                for (int j = 0; j < S; j++) bm += (double)counts[(int64_t)j * n + i] / nf[(int64_t)j * n + i];
+            }
             bm /= S;
             B0 = log2(bm);
             const double e = exp2(B0);
             const LgrCtx cs = lgr_make(size), c1 = lgr_one();
-            const double la = flog(alpha);
+            const double la = tlog(alpha, s_lt);
             double ll = 0, xtwx = 0;
-            for (int j = 0; j < S; j++) {
-                const double mu = nf[(int64_t)j * n + i] * e;
-                const int yi = counts[(int64_t)j * n + i];
+            auto sample = [&](double nfj, int yi) {
+                const double mu = nfj * e;
                 const double y = (double)yi, ma = alpha * mu, t = 1.0 + ma, rt = rcp(t);
-                ll -= (size + y) * flog1p_from(ma, t, rt);
-                if (yi > 0) ll += lgr_eval(cs, yi) - lgr_eval(c1, yi) + y * (la + flog(mu));
+                ll -= (size + y) * tlog1p_from(ma, t, rt, s_lt);
+                if (yi > 0) ll += lgr_eval(cs, yi) - (yi < kLogFactN ? s_logfact[yi] : lgr_eval(c1, yi)) + y * (la + tlog(mu, s_lt));
                 xtwx += mu * rt;
+            };
+            if (S <= 16) {
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (j < S) sample(f[j], yv[j]);
+            } else {
+                for (int j = 0; j < S; j++) sample(nf[(int64_t)j * n + i], counts[(int64_t)j * n + i]);
             }
             s0 = kLog2e * sqrt(1.0 / xtwx);
             st = B0 / s0;
