@@ -189,6 +189,8 @@ def main():
 
     S = args.samples
     ctx = hip.HipContext(local_rank)
+    if share_gpu and world > 1:  # rehearsal: all ranks' persistent trend kernels must be resident on the ONE GPU at the same time
+        ctx.set_option("trend_persistent_blocks", max(1, 256 // world))
     collectives, comm_ranks = "none (single rank)", 1
     if dist is not None:
         comm_ranks = dist.get_world_size()
