@@ -60,33 +60,6 @@ struct Opts {
     int32_t trend_blocks = 0;  // persistent trend kernel: at most this many workgroups (0 = one per CU); option "trend_persistent_blocks"
 };
 
-// one row of FitWork::rowpack -> the wave's LDS slice ([sample][lane]); 16-byte loads when S is a multiple of four
-__device__ __forceinline__ void load_row(const char *rowpack, int64_t r, int S, double *s_nf, int *s_y, int lane, double (&hdr)[4]) {
-    const char *row = rowpack + r * row_stride(S);
-    {
-        const double2 h0 = reinterpret_cast<const double2 *>(row)[0], h1 = reinterpret_cast<const double2 *>(row)[1];
-        hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
-    }
-    row += kRowHdr;
-    if ((S & 3) == 0) {
-        const double2 *pf = reinterpret_cast<const double2 *>(row);
-        const int4 *py = reinterpret_cast<const int4 *>(row + 8 * S);
-        for (int j = 0; j < S; j += 4) {
-            const double2 a = pf[j >> 1], b = pf[(j >> 1) + 1];
-            const int4 y = py[j >> 2];
-            s_nf[j * 64 + lane] = a.x; s_nf[(j + 1) * 64 + lane] = a.y; s_nf[(j + 2) * 64 + lane] = b.x; s_nf[(j + 3) * 64 + lane] = b.y;
-            s_y[j * 64 + lane] = y.x; s_y[(j + 1) * 64 + lane] = y.y; s_y[(j + 2) * 64 + lane] = y.z; s_y[(j + 3) * 64 + lane] = y.w;
-        }
-    } else {
-        const double *pf = reinterpret_cast<const double *>(row);
-        const int *py = reinterpret_cast<const int *>(row + 8 * S);
-        for (int j = 0; j < S; j++) {
-            s_nf[j * 64 + lane] = pf[j];
-            s_y[j * 64 + lane] = py[j];
-        }
-    }
-}
-
 // ---- launchers (defined in the .hip files; all enqueue on `st` and never synchronise) -------
 void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
 void launch_prep_finish(FitDims d, FitWork w, double *slot, hipStream_t st);  // partials -> colsum, nnz (slot: as (hi, lo) pairs into this rank's slot instead)

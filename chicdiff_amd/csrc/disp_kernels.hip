@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
             g0 /= d.nA;
             if (d.p == 2) g1 /= d.nB;
             row[0] = (uint32_t)__double2loint(g0);  // first half of the header: the group means
-            row[1] = (uint32_t)__double2hiint(g0);
+            row[1] = (uint32_t)__double2hiint(g0) | (tot == 0 ? 0x80000000u : 0u);  // sign bit of the (never negative) mean: the row is all zero — the row-queue kernels read the flag with the record
             row[2] = (uint32_t)__double2loint(g1);
             row[3] = (uint32_t)__double2hiint(g1);
             s_live[tid] = tot != 0;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const int32_t *__restrict__ c
         const double bm = s / S;
         g0 /= d.nA;
         if (d.p == 2) g1 /= d.nB;
-        reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, S))[0] = make_double2(g0, g1);  // first half of the row's header
+        reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, S))[0] = make_double2(tot == 0 ? -0.0 : g0, g1);  // first half of the row's header; sign bit = all-zero row
         const double m0 = fmax(1.0, g0), m1 = fmax(1.0, g1);
         double v = 0, est = 0;
         for (int j = 0; j < S; j++) {
@@ -416,6 +416,66 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
 constexpr int kChunk = 64;   // rows a wave takes from the global queue per atomic
 enum Phase : int { PH_NEED = 0, PH_INIT = 1, PH_SEARCH = 2, PH_GRID1 = 3, PH_GRID2 = 4, PH_DONE = 5 };
 
+// One row of FitWork::rowpack -> the lane's LDS column, with mu_j = max(nf_j * groupmean_g, minmu) formed on the way (what the
+// line search needs of nf_j).  All of the record's 16-byte loads are in flight before the first is used (S a multiple of four up
+// to 16: one round trip instead of one per four samples), and the all-zero flag comes with the record (sign bit of the first header
+// word, set by prep) instead of from a load of its own in front of it.  Returns false for an all-zero row.
+__device__ __forceinline__ double max_num(double x, double m) {  // fmax() without the canonicalising copies of its operands
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
+    return r;
+}
+template <int Q>  // S = 4 Q
+__device__ __forceinline__ bool load_row_mu_fixed(const char *row, double *s_nf, int *s_y, int lane, uint64_t gmask, double minmu,
+                                                  double (&hdr)[4]) {
+    const double2 *p = reinterpret_cast<const double2 *>(row);
+    const int4 *py = reinterpret_cast<const int4 *>(row + kRowHdr + 32 * Q);
+    const double2 h0 = p[0], h1 = p[1];
+    double2 f[2 * Q];
+    int4 y[Q];
+#pragma unroll
+    for (int k = 0; k < 2 * Q; k++) f[k] = p[2 + k];
+#pragma unroll
+    for (int k = 0; k < Q; k++) y[k] = py[k];
+    hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
+    // (no branch on the flag here: an all-zero row's values go to the lane's LDS column like any other's and are never used —
+    // with a branch the compiler moves the loads behind it, i.e. behind the wait for the header.)  The sample's group is a bit
+    // of a wave-uniform word; it is taken from a copy the compiler cannot see through, or it builds all S lane masks outside
+    // the launch's main loop and spills them.
+    uint32_t gbits = (uint32_t)gmask;
+    asm volatile("" : "+s"(gbits));
+#pragma unroll
+    for (int k = 0; k < 2 * Q; k++) {
+        s_nf[(2 * k) * 64 + lane] = max_num(f[k].x * (((gbits >> (2 * k)) & 1u) ? h0.y : h0.x), minmu);
+        s_nf[(2 * k + 1) * 64 + lane] = max_num(f[k].y * (((gbits >> (2 * k + 1)) & 1u) ? h0.y : h0.x), minmu);
+    }
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        s_y[(4 * k) * 64 + lane] = y[k].x; s_y[(4 * k + 1) * 64 + lane] = y[k].y;
+        s_y[(4 * k + 2) * 64 + lane] = y[k].z; s_y[(4 * k + 3) * 64 + lane] = y[k].w;
+    }
+    return __double2hiint(h0.x) >= 0;
+}
+__device__ __forceinline__ bool load_row_mu(const char *row, int S, double *s_nf, int *s_y, int lane, uint64_t gmask, double minmu,
+                                            double (&hdr)[4]) {
+    if (S == 8) return load_row_mu_fixed<2>(row, s_nf, s_y, lane, gmask, minmu, hdr);
+    if (S == 4) return load_row_mu_fixed<1>(row, s_nf, s_y, lane, gmask, minmu, hdr);
+    if (S == 16) return load_row_mu_fixed<4>(row, s_nf, s_y, lane, gmask, minmu, hdr);
+    if (S == 12) return load_row_mu_fixed<3>(row, s_nf, s_y, lane, gmask, minmu, hdr);
+    {
+        const double2 h0 = reinterpret_cast<const double2 *>(row)[0], h1 = reinterpret_cast<const double2 *>(row)[1];
+        hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
+    }
+    if (__double2hiint(hdr[0]) < 0) return false;
+    const double *pf = reinterpret_cast<const double *>(row + kRowHdr);
+    const int *py = reinterpret_cast<const int *>(row + kRowHdr + 8 * S);
+    for (int j = 0; j < S; j++) {
+        s_nf[j * 64 + lane] = max_num(pf[j] * (((gmask >> j) & 1) ? hdr[1] : hdr[0]), minmu);
+        s_y[j * 64 + lane] = py[j];
+    }
+    return true;
+}
+
 struct DispArgs {
     const int32_t *counts;
     const double *nf;
@@ -437,7 +497,7 @@ struct DispArgs {
 #endif
 #ifdef CHICDIFF_DIAG
 #define DIAG(...) __VA_ARGS__
-constexpr int kStampSlots = 12;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
+constexpr int kStampSlots = 16;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
 #else
 #define DIAG(...)
 #endif
@@ -687,7 +747,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     __shared__ ExpEntry s_exptab[64];
     exp_table_to_lds(s_exptab);
     log_table_to_lds(s_logtab);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (tells the compiler it is wave-uniform: what derives from it — LDS bases, the wave's place in the deal — stays in scalar registers)
     const int S = A.d.S;
     const int64_t n = A.d.n;
     // per wave: 22*64 doubles (prefix table) + S*64 doubles (nf) + S*64 ints (counts)
@@ -714,62 +775,74 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     constexpr unsigned long long kHeads = MAP ? 8ull : 1ull;
 
     int phase = PH_NEED, iter = 0, iacc = 0, gt = 0, gbi = 0;
-    int64_t row = -1;
+    int row = -1;
     double a = 0, lp = 0, dlp = 0, kappa = 0, init_lp = 0, a0 = 0, prior_mean = 0;
     double gbest = 0, ghat = 0, dgene = 0, a_new = 0, alpha_cur = 0;
     int is_outlier = 0;
     bool queue_empty = false;
-    unsigned long long chunk_next = 0, chunk_end = 0;
+    // the open chunk (wave-uniform): entries [chunk_pos, chunk_len) of it are still to be handed out; lane l holds the row of entry l
+    uint32_t chunk_base = 0, chunk_pos = 0, chunk_len = 0;
+    int ord_reg = 0;
+    bool touch = false;
+    const int64_t rstride = row_stride(S);
     // schedule (gene-wise launch): positions [0, nA) of order[] are dealt out statically — group g of kSchedDeal entries
     // belongs to wave g mod W — the positions [nA, nTot) go through the queue; without a schedule the queue covers rows 0..n-1
     const int32_t *__restrict__ order = MAP ? nullptr : A.order;
-    const unsigned long long nA = order ? (unsigned long long)sc->ord_na : 0ull;
-    const unsigned long long nTot = order ? (unsigned long long)sc->ord_n : (unsigned long long)n;
-    const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
-    const unsigned long long mywave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave;
-    unsigned long long a_k = 0;
+    // (32-bit positions: n < 2^31 — api.hip refuses more —, and a head's counter overshoots the end by a few chunks per wave at most;
+    // the scalar unit has no ordered 64-bit compare, with 64-bit positions the whole bookkeeping moves to the vector unit)
+    const uint32_t nA = order ? (uint32_t)sc->ord_na : 0u;
+    const uint32_t nTot = order ? (uint32_t)sc->ord_n : (uint32_t)n;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t mywave = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
+    uint32_t a_k = 0;
     bool a_done = nA == 0;
     unsigned int pf_val = 0, pf_acc = 0;
     // entries per group of the deal: eight while every wave gets several groups (neighbouring rows, neighbouring lanes), down to
     // one when rows are few, so that the likely-long rows spread evenly over the waves
-    unsigned long long deal = A.deal > 0 ? (unsigned long long)A.deal : nA / (4ull * nwaves);
-    deal = deal < 1 ? 1 : (deal > (unsigned long long)kSchedDeal ? (unsigned long long)kSchedDeal : deal);
+    uint32_t deal = A.deal > 0 ? (uint32_t)A.deal : nA / (4u * nwaves);
+    deal = deal < 1 ? 1 : (deal > (uint32_t)kSchedDeal ? (uint32_t)kSchedDeal : deal);
     DIAG(const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;)
-    DIAG(bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
+    DIAG(unsigned long long cy_sec[5] = {0, 0, 0, 0, 0}; bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
          if (A.stamps && lane == 0) A.stamps[gwave * kStampSlots + 0] = __builtin_amdgcn_s_memrealtime();)
 
     for (;;) {
         MARK("tick:begin");
+        DIAG(const bool sec_on = !queue_empty; const unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();)
         // ---- refill: lanes without a row pull the next ones from the queue -----------------
+        // (Round 4: this part was a quarter of a tick's time in the bulk of the launch — in-kernel section timers, tools/stamps.py —,
+        // most of it instruction issue: the chunk bookkeeping ran in vector registers behind divergent-looking branches, every row cost
+        // three dependent loads (schedule entry, all-zero flag, record, the record in two trips) and the offsets were turned into
+        // means by a read-modify-write loop over LDS.  Now: chunk state is wave-uniform (scalar registers, scalar branches); a chunk's
+        // schedule entries are read once, when it opens, one per lane, and handed out with a lane permute; the all-zero flag comes
+        // with the record; the record's loads are all in flight at once and the means are formed on the way into LDS.)
+        unsigned long long needmask = __ballot(phase == PH_NEED);
 #pragma unroll 1
-        for (int attempt = 0; attempt < (MAP ? 4 : 10); attempt++) {
-            const unsigned long long needmask = __ballot(phase == PH_NEED);
-            if (!needmask) break;
-            // rows come from a wave-private chunk: one atomic on the global head per kChunk rows
-            // (a single hot word saturates near 90 dequeues/us, which one atomic per tick per wave hit)
-            if (chunk_next >= chunk_end) {
+        for (int attempt = 0; needmask != 0ull && attempt < (MAP ? 4 : 10); attempt++) {
+            if (chunk_pos >= chunk_len) {
                 if (queue_empty) {
                     if (phase == PH_NEED) phase = PH_DONE;
                     break;
                 }
+                uint32_t b, e;
                 if (!a_done) {  // this wave's next group of the static deal
-                    const unsigned long long start = (a_k * nwaves + mywave) * deal;
+                    b = (a_k * nwaves + mywave) * deal;
                     a_k++;
-                    if (start >= nA) {
+                    if (b >= nA) {
                         a_done = true;
                         continue;
                     }
-                    chunk_next = start;
-                    chunk_end = start + deal < nA ? start + deal : nA;
+                    e = b + deal < nA ? b + deal : nA;
                 } else {
                     if (heads_left == 0u) {
                         queue_empty = true;
                         continue;
                     }
-                    unsigned long long kq = 0;
-                    if (lane == 0) kq = atomicAdd(heads + 8 * cur_head, 1ull);
-                    kq = __shfl(kq, 0);
-                    const unsigned long long b = nA + (kq * kHeads + (unsigned long long)cur_head) * (unsigned long long)kChunk;
+                    // one atomic on the global head per kChunk rows (a single hot word saturates near 90 dequeues/us, which one
+                    // atomic per tick per wave hit)
+                    unsigned int kq = 0;
+                    if (lane == 0) kq = (unsigned int)atomicAdd(heads + 8 * cur_head, 1ull);
+                    kq = __builtin_amdgcn_readfirstlane(kq);
+                    b = nA + (kq * (uint32_t)kHeads + (uint32_t)cur_head) * (uint32_t)kChunk;
                     if (b >= nTot) {  // this head is dry: on to the next one that is not known to be (uses up one attempt)
                         heads_left &= ~(1u << cur_head);
                         if (MAP)
@@ -779,21 +852,29 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                             }
                         continue;
                     }
-                    chunk_next = b;
-                    chunk_end = b + kChunk < nTot ? b + kChunk : nTot;
+                    e = b + kChunk < nTot ? b + kChunk : nTot;
                 }
+                chunk_base = b;
+                chunk_len = e - b;
+                chunk_pos = 0;
+                ord_reg = (int)chunk_base + lane;
+                if (order && (uint32_t)lane < chunk_len) ord_reg = order[chunk_base + lane];
+                touch = true;
             }
-            const int cnt = __popcll(needmask);
-            const unsigned long long base = chunk_next;
-            const unsigned long long avail = chunk_end - chunk_next;
-            const int take = (unsigned long long)cnt < avail ? cnt : (int)avail;
-            chunk_next += (unsigned long long)take;
-            if (phase == PH_NEED) {
-                const int rank = __popcll(needmask & ((1ull << lane) - 1ull));
-                const int64_t r = rank >= take ? 0 : (order ? (int64_t)order[base + rank] : (int64_t)base + rank);
-                if (rank >= take) {
-                    // chunk ran out: stay in PH_NEED, the next attempt opens a new chunk
-                } else if (A.w.allZero[r]) {
+            const uint32_t cnt = (uint32_t)__popcll(needmask), avail = chunk_len - chunk_pos;
+            const uint32_t take = cnt < avail ? cnt : avail;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(needmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needmask, 0u));
+            const int r = MAP ? (int)(chunk_base + chunk_pos + rank) : __shfl(ord_reg, (int)((chunk_pos + rank) & 63u));
+            chunk_pos += take;
+            if (phase == PH_NEED && rank < take) {
+                double hdr[4];
+                double dg = 0;
+                int ol = 0;
+                if (MAP) {
+                    dg = A.w.dispGene[r];
+                    ol = A.w.outlier[r];
+                }
+                if (!load_row_mu(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, o.minmu, hdr)) {
                     if (!MAP) {
                         A.w.dispGene[r] = NAN;
                         A.w.geneIter[r] = 0;
@@ -806,32 +887,31 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     }
                 } else {
                     row = r;
-                    double hdr[4];
-                    load_row(A.w.rowpack, r, S, s_nf, s_y, lane, hdr);
-                    for (int j = 0; j < S; j++)  // nf_j -> mu_j, once per row
-                        s_nf[j * 64 + lane] = fmax(s_nf[j * 64 + lane] * (((gmask >> j) & 1) ? hdr[1] : hdr[0]), o.minmu);
                     if (!MAP) {  // start values come from disp_init_kernel
                         a0 = hdr[2];
                         a = hdr[3];
                     } else {
                         a = hdr[2];
                         prior_mean = hdr[3];
-                        dgene = A.w.dispGene[r];
-                        is_outlier = A.w.outlier[r];
+                        dgene = dg;
+                        is_outlier = ol;
                     }
                     phase = PH_INIT;
                 }
             }
+            needmask = __ballot(phase == PH_NEED);
         }
         if (__ballot(phase != PH_DONE) == 0ull) break;
         MARK("tick:refill_end");
-        // warm the lines of the rows this wave hands out next (its private chunk continues at chunk_next): the load is consumed one
-        // tick later (pf_acc), long after it has landed, so the next refill finds its rows in the cache instead of in HBM
-        pf_acc ^= pf_val;
-        pf_val = 0;
-        if (A.prefetch && chunk_next + lane < chunk_end) {
-            const int64_t rn = order ? (int64_t)order[chunk_next + lane] : (int64_t)(chunk_next + lane);
-            pf_val = *reinterpret_cast<const unsigned int *>(A.w.rowpack + rn * row_stride(S));
+        DIAG(const unsigned long long sec_t1 = __builtin_amdgcn_s_memtime();)
+        // warm the lines of the rows this wave hands out next (the rest of the chunk it has just opened): the load is consumed when
+        // the next chunk opens, long after it has landed, so the coming refills find their rows in the cache instead of in HBM
+        if (touch) {
+            touch = false;
+            pf_acc ^= pf_val;
+            pf_val = 0;
+            if (A.prefetch && (uint32_t)lane >= chunk_pos && (uint32_t)lane < chunk_len)
+                pf_val = *reinterpret_cast<const unsigned int *>(A.w.rowpack + (int64_t)ord_reg * rstride);
         }
         DIAG(if (A.stamps && queue_empty && !stamped) {
             stamped = true;
@@ -914,6 +994,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                 else { tk_row++; tk_kind = 0; }
             }
         })
+        DIAG(const unsigned long long sec_t2 = __builtin_amdgcn_s_memtime();)
         if (lg_t >= 0) {
             eval_point_spread(s_nf, s_y, s_tab, lane, S, lg_t, gmask, p2, actmask, active, a_eval, MAP,
                               prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab, s_exptab);
@@ -922,6 +1003,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                        dl_new, alpha_new, s_logtab, s_exptab);
         }
         MARK("tick:evaluate_end");
+        DIAG(const unsigned long long sec_t3 = __builtin_amdgcn_s_memtime();)
         bool burst_done = false;  // this lane owns the burst: l_new / hk now describe the best of the 20 points
         if (burst_owner >= 0) {
             const bool part = helper || lane == burst_owner;
@@ -1038,6 +1120,10 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             phase = PH_NEED;
         }
         MARK("tick:state_machine_end");
+        DIAG(if (sec_on) {
+            const unsigned long long sec_t4 = __builtin_amdgcn_s_memtime();
+            cy_sec[0] += sec_t1 - sec_t0; cy_sec[1] += sec_t2 - sec_t1; cy_sec[2] += sec_t3 - sec_t2; cy_sec[3] += sec_t4 - sec_t3; cy_sec[4]++;
+        })
     }
     if (A.prefetch == 0x7fffffff) A.w.queue[8 + (pf_acc & 7)] = pf_acc;  // (never: keeps the warming loads alive)
     DIAG(if (A.stamps && lane == 0) {
@@ -1049,6 +1135,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         A.stamps[gwave * kStampSlots + 8] = cy_row;
         A.stamps[gwave * kStampSlots + 9] = cy_spread;
         A.stamps[gwave * kStampSlots + 10] = cy_burst;
+        for (int q = 0; q < 5; q++) A.stamps[gwave * kStampSlots + 11 + q] = cy_sec[q];
     })
 }
 

@@ -131,6 +131,68 @@ __device__ __noinline__ bool optim_row(const int32_t *y_, const double *f_, int6
     return converged;
 }
 
+// One row of FitWork::rowpack -> the lane's LDS column for the IRLS (offsets as they are), with the two groups' count sums formed
+// on the way.  As load_row_mu() of disp_kernels.hip: every 16-byte load of the record in flight before the first is used, the
+// all-zero flag read with the record (sign bit of the first header word: prep writes it, wald_prep leaves such rows' headers alone).
+template <int Q>  // S = 4 Q
+__device__ __forceinline__ bool load_row_sums_fixed(const char *row, double *s_nf, int *s_y, int lane, uint64_t gmask, double (&hdr)[4],
+                                                    int &iyA, int &iyB) {
+    const double2 *p = reinterpret_cast<const double2 *>(row);
+    const int4 *py = reinterpret_cast<const int4 *>(row + kRowHdr + 32 * Q);
+    const double2 h0 = p[0], h1 = p[1];
+    double2 f[2 * Q];
+    int4 y[Q];
+#pragma unroll
+    for (int k = 0; k < 2 * Q; k++) f[k] = p[2 + k];
+#pragma unroll
+    for (int k = 0; k < Q; k++) y[k] = py[k];
+    hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
+    uint32_t gbits = (uint32_t)gmask;
+    asm volatile("" : "+s"(gbits));  // (a copy the compiler cannot see through: it would build all S lane masks outside the main loop)
+#pragma unroll
+    for (int k = 0; k < 2 * Q; k++) {
+        s_nf[(2 * k) * 64 + lane] = f[k].x;
+        s_nf[(2 * k + 1) * 64 + lane] = f[k].y;
+    }
+    int all = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int v[4] = {y[k].x, y[k].y, y[k].z, y[k].w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            s_y[(4 * k + t) * 64 + lane] = v[t];
+            all += v[t];
+            b += ((gbits >> (4 * k + t)) & 1u) ? v[t] : 0;
+        }
+    }
+    iyB = b;
+    iyA = all - b;
+    return __double2hiint(h0.x) >= 0;
+}
+__device__ __forceinline__ bool load_row_sums(const char *row, int S, double *s_nf, int *s_y, int lane, uint64_t gmask, double (&hdr)[4],
+                                              int &iyA, int &iyB) {
+    if (S == 8) return load_row_sums_fixed<2>(row, s_nf, s_y, lane, gmask, hdr, iyA, iyB);
+    if (S == 4) return load_row_sums_fixed<1>(row, s_nf, s_y, lane, gmask, hdr, iyA, iyB);
+    if (S == 16) return load_row_sums_fixed<4>(row, s_nf, s_y, lane, gmask, hdr, iyA, iyB);
+    if (S == 12) return load_row_sums_fixed<3>(row, s_nf, s_y, lane, gmask, hdr, iyA, iyB);
+    {
+        const double2 h0 = reinterpret_cast<const double2 *>(row)[0], h1 = reinterpret_cast<const double2 *>(row)[1];
+        hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
+    }
+    const double *pf = reinterpret_cast<const double *>(row + kRowHdr);
+    const int *py = reinterpret_cast<const int *>(row + kRowHdr + 8 * S);
+    int a = 0, b = 0;
+    for (int j = 0; j < S; j++) {
+        const int yi = py[j];
+        s_nf[j * 64 + lane] = pf[j];
+        s_y[j * 64 + lane] = yi;
+        if ((gmask >> j) & 1) b += yi; else a += yi;
+    }
+    iyA = a;
+    iyB = b;
+    return __double2hiint(hdr[0]) >= 0;
+}
+
 struct WaldArgs {
     const int32_t *counts;
     const double *nf;
@@ -155,7 +217,8 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
     __shared__ ExpEntry s_exptab[64];
     exp_table_to_lds(s_exptab);
     log_table_to_lds(s_logtab);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform, and the compiler knows)
     const int S = A.d.S;
     const int64_t n = A.d.n;
     double *s_nf = smem + (size_t)wave * S * 96;
@@ -164,7 +227,7 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
     const Opts o = A.o;
     const double lambda = 1e-6 / (0.69314718055994530942 * 0.69314718055994530942);
     const int32_t *__restrict__ order = A.order;
-    const unsigned long long nTot = order ? (unsigned long long)A.w.sc->ord_n : (unsigned long long)n;
+    const uint32_t nTot = order ? (uint32_t)A.w.sc->ord_n : (uint32_t)n;  // (n < 2^31: 32-bit positions keep the bookkeeping on the scalar unit)
     // Eight queue heads, 64 bytes apart: chunk c = 8 k + h is the k-th chunk taken from head h.  One head is one hot word
     // (~90 dequeues per us for the whole GPU) and an IRLS row lasts ~6 us, which had forced chunks of 128 rows; eight heads
     // take 64-row chunks without queueing up, and the waves' ends balance better.  A wave starts at the head of its XCD
@@ -172,69 +235,73 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
     unsigned long long *heads = A.w.queue + 32;
     int cur_head = blockIdx.x & 7;
     unsigned int heads_left = 0xffu;
-    const unsigned long long nchunks = (nTot + (unsigned long long)A.chunk - 1ull) / (unsigned long long)A.chunk;
+    const uint32_t nchunks = (nTot + (uint32_t)A.chunk - 1u) / (uint32_t)A.chunk;
+    const int64_t rstride = row_stride(S);
 
     int spread_lg = A.spread ? 1 : -1;  // log2(lanes per row) of the samples-across-lanes layout; -1 = never
     while (spread_lg >= 0 && (1 << spread_lg) < S) spread_lg++;
 
     bool need = true, done = false, queue_empty = false;
-    unsigned long long chunk_next = 0, chunk_end = 0;
-    int64_t row = -1;
+    // the open chunk (wave-uniform): entries [chunk_pos, chunk_len) are still to be handed out; lane l holds the row of entry l
+    uint32_t chunk_pos = 0, chunk_len = 0, rest_base = 0, rest_end = 0;  // [rest_base, rest_end): what is left of the last dequeue behind them
+    int ord_reg = 0;
+    int row = -1;
     int k = 0;
     double b0 = 0, b1 = 0, alpha = 0, size = 0, crow = 0, dev_old = 0, syA = 0, syB = 0;
 
     for (;;) {
-        for (int attempt = 0; attempt < 4; attempt++) {
-            const unsigned long long needmask = __ballot(need && !done);
-            if (!needmask) break;
-            if (chunk_next >= chunk_end) {  // wave-private chunk exhausted: one atomic per A.chunk rows
-                if (queue_empty) {
-                    if (need) done = true;
-                    break;
-                }
-                if (heads_left == 0u) {
-                    queue_empty = true;
-                    continue;
-                }
-                unsigned long long kq = 0;
-                if (lane == 0) kq = atomicAdd(heads + 8 * cur_head, 1ull);
-                kq = __shfl(kq, 0);
-                const unsigned long long cq = kq * 8ull + (unsigned long long)cur_head;
-                if (cq >= nchunks) {  // this head is dry: on to the next one that is not known to be (uses up one attempt)
-                    heads_left &= ~(1u << cur_head);
-                    for (int t = 1; t <= 8; t++) {
-                        const int hn = (cur_head + t) & 7;
-                        if (heads_left & (1u << hn)) { cur_head = hn; break; }
+        // refill (the scheme of disp_fit_kernel's: scalar chunk bookkeeping, a chunk's schedule entries read once and handed out by
+        // lane permute, the all-zero flag and the whole record in one round trip)
+        unsigned long long needmask = __ballot(need && !done);
+#pragma unroll 1
+        for (int attempt = 0; needmask != 0ull && attempt < 4; attempt++) {
+            if (chunk_pos >= chunk_len) {  // the lanes' entries are used up ...
+                if (rest_base >= rest_end) {  // ... and nothing left of the last dequeue: one atomic per A.chunk rows
+                    if (queue_empty) {
+                        if (need) done = true;
+                        break;
                     }
-                    continue;
+                    if (heads_left == 0u) {
+                        queue_empty = true;
+                        continue;
+                    }
+                    unsigned int kq = 0;
+                    if (lane == 0) kq = (unsigned int)atomicAdd(heads + 8 * cur_head, 1ull);
+                    kq = __builtin_amdgcn_readfirstlane(kq);
+                    const uint32_t cq = kq * 8u + (uint32_t)cur_head;
+                    if (cq >= nchunks) {  // this head is dry: on to the next one that is not known to be (uses up one attempt)
+                        heads_left &= ~(1u << cur_head);
+                        for (int t = 1; t <= 8; t++) {
+                            const int hn = (cur_head + t) & 7;
+                            if (heads_left & (1u << hn)) { cur_head = hn; break; }
+                        }
+                        continue;
+                    }
+                    rest_base = cq * (uint32_t)A.chunk;
+                    rest_end = rest_base + (uint32_t)A.chunk < nTot ? rest_base + (uint32_t)A.chunk : nTot;
                 }
-                const unsigned long long b = cq * (unsigned long long)A.chunk;
-                chunk_next = b;
-                chunk_end = b + A.chunk < nTot ? b + A.chunk : nTot;
+                // the next (up to) 64 entries of the dequeued run: one per lane
+                const uint32_t b = rest_base;
+                chunk_len = rest_end - rest_base < 64u ? rest_end - rest_base : 64u;
+                rest_base += chunk_len;
+                chunk_pos = 0;
+                ord_reg = (int)b + lane;
+                if (order && (uint32_t)lane < chunk_len) ord_reg = order[b + lane];
             }
-            const int cnt = __popcll(needmask);
-            const unsigned long long base = chunk_next;
-            const unsigned long long avail = chunk_end - chunk_next;
-            const int take = (unsigned long long)cnt < avail ? cnt : (int)avail;
-            chunk_next += (unsigned long long)take;
-            if (need && !done) {
-                const int rank = __popcll(needmask & ((1ull << lane) - 1ull));
-                const int64_t r = rank >= take ? 0 : (order ? (int64_t)order[base + rank] : (int64_t)base + rank);
-                if (rank >= take) {
-                    // chunk ran out: keep `need`, the next attempt opens a new chunk
-                } else if (A.w.allZero[r]) {
+            const uint32_t cnt = (uint32_t)__popcll(needmask), avail = chunk_len - chunk_pos;
+            const uint32_t take = cnt < avail ? cnt : avail;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(needmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needmask, 0u));
+            const int r = __shfl(ord_reg, (int)((chunk_pos + rank) & 63u));
+            chunk_pos += take;
+            if (need && !done && rank < take) {
+                int iyA = 0, iyB = 0;
+                double hdr[4];
+                if (!load_row_sums(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, hdr, iyA, iyB)) {
                     A.w.beta0[r] = NAN;
                     A.w.beta1[r] = NAN;
                     A.w.betaIter[r] = 0;
                 } else {
                     row = r;
-                    int iyA = 0, iyB = 0;
-                    double hdr[4];
-                    load_row(A.w.rowpack, r, S, s_nf, s_y, lane, hdr);
-                    for (int j = 0; j < S; j++) {
-                        const int yi = s_y[j * 64 + lane];
-                        if ((gmask >> j) & 1) iyB += yi; else iyA += yi;
-                    }
                     syA = (double)iyA;
                     syB = (double)iyB;
                     alpha = hdr[0];
@@ -247,6 +314,7 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                     need = false;
                 }
             }
+            needmask = __ballot(need && !done);
         }
         if (__ballot(!done) == 0ull) break;
         const bool active = !need && !done;

@@ -17,7 +17,7 @@ dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64
 ctx.nbglm_fit(dk, dn, d["group"])
 raw = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64)
 pos = 0
-K = 12
+K = 16
 while pos < len(raw):
     kind, nw = int(raw[pos]), int(raw[pos + 1]); pos += 2
     st = raw[pos:pos + nw * K].reshape(nw, K).astype(np.int64); pos += nw * K
@@ -46,3 +46,7 @@ while pos < len(raw):
     print("  s_memtime cycles per tick (tick start to next tick start): row-per-lane %.0f, spread %.0f, burst %.0f  (100 MHz clock? ratio to us: %.1f)" % (*per, np.nansum(cy) / max(dr.sum(), 1e-9)))
     bulk = us(st[qe, 1]) / np.maximum(st[qe, 7] - tot, 1)
     print("  us per tick before q-empty: med %.2f; total ticks per wave: med %d" % (np.median(bulk), np.median(st[qe, 7])))
+    sec = st[qe, 11:16].astype(float)
+    tot_sec = sec[:, :4].sum()
+    print("  bulk ticks (queue not empty), s_memtime cycles per tick: refill %.0f, choose point %.0f, evaluate %.0f, state machine %.0f (of %.0f); shares %.1f / %.1f / %.1f / %.1f %%" % (
+        *(sec[:, :4].sum(0) / max(sec[:, 4].sum(), 1)), tot_sec / max(sec[:, 4].sum(), 1), *(100 * sec[:, :4].sum(0) / max(tot_sec, 1))))
