@@ -497,7 +497,7 @@ struct DispArgs {
 #endif
 #ifdef CHICDIFF_DIAG
 #define DIAG(...) __VA_ARGS__
-constexpr int kStampSlots = 16;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
+constexpr int kStampSlots = 29;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
 #else
 #define DIAG(...)
 #endif
@@ -615,25 +615,36 @@ __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c,
 __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int slot, int S, uint64_t gmask,
                                            bool p2, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
-                                           double &lp, double &dlp, double &alpha_out, const LogEntry *lt, const ExpEntry *et) {
+                                           double &lp, double &dlp, double &alpha_out, const LogEntry *lt, const ExpEntry *et
+                                           DIAG(, unsigned long long *tm)) {
     MARK("row:begin");
+    DIAG(tm[0] = __builtin_amdgcn_s_memtime();)
     const RowConsts c = row_consts(a, lt, et);
     alpha_out = c.alpha;
     MARK("row:row_consts_end");
+    DIAG(tm[1] = __builtin_amdgcn_s_memtime();)
     // per-tick table (LDS, [entry][lane]): P_n and H_n for n = 0..nr
+    // (All ten steps in every lane, no trip count: entries beyond a lane's nr are never read, and a loop that stops at the lane's
+    // own nr runs — in SIMD — to the wave's largest, which is 9 or 10 on nearly every tick; worse, the compiler unrolled it by
+    // eight with a remainder loop, so a wave holding nr = 10 and nr = 7 ran 8 + 7 steps.  In-kernel timers, round 4: 2 200 of a
+    // bulk tick's 16 000 cycles were spent here.  r < 6e30 keeps r^10 finite.)
     {
         double P = 1.0, H = 0.0, zz = c.r;
         s_tab[lane] = 1.0;
         s_tab[11 * 64 + lane] = 0.0;
-        for (int i = 1; i <= c.nr; i++) {
-            P *= zz;
-            H += rcp(zz);
-            zz += 1.0;
-            s_tab[i * 64 + lane] = P;
-            s_tab[(11 + i) * 64 + lane] = H;
+        if (__ballot(c.nr > 0) != 0ull) {
+#pragma unroll
+            for (int i = 1; i <= 10; i++) {
+                P *= zz;
+                H += rcp(zz);
+                zz += 1.0;
+                s_tab[i * 64 + lane] = P;
+                s_tab[(11 + i) * 64 + lane] = H;
+            }
         }
     }
     MARK("row:table_end");
+    DIAG(tm[2] = __builtin_amdgcn_s_memtime();)
     Acc acc;
     for (int j = 0; j < S; j++) {
         const int yi = s_y[j * 64 + slot];
@@ -642,8 +653,10 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
         accumulate(acc, sample_values(c, s_nf[j * 64 + slot], yi, s_tab[n * 64 + lane], s_tab[(11 + n) * 64 + lane], lt), g);
     }
     MARK("row:samples_end");
+    DIAG(tm[3] = __builtin_amdgcn_s_memtime();)
     finish_point(acc, c, p2, use_prior, prior_mean, prior_isig, lp, dlp, lt);
     MARK("row:finish_end");
+    DIAG(tm[4] = __builtin_amdgcn_s_memtime();)
 }
 
 // Samples-across-lanes evaluation for the end of the launch.  Once the queue is empty every wave is left
@@ -663,21 +676,31 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
 __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int *s_y, double *s_x, int lane, int S, int lg, uint64_t gmask,
                                                   bool p2, unsigned long long actmask, bool active, double a_eval,
                                                   bool use_prior, double prior_mean, double prior_isig,
-                                                  double &lp, double &dlp, double &alpha_out, const LogEntry *lt, const ExpEntry *et) {
+                                                  double &lp, double &dlp, double &alpha_out, const LogEntry *lt, const ExpEntry *et
+                                                  DIAG(, unsigned long long *tm)) {
+    DIAG(tm[0] = __builtin_amdgcn_s_memtime();)
     // lanes per row L = 2^lg: one sample per lane when L >= S (at most 64 / L rows), else samples jj, jj + L, ... per lane — the
     // layout also serves 9 .. 32 live rows (S = 8: four or two lanes per row), where a row-per-lane tick would still walk all S
     // samples in every lane
     const int L = 1 << lg, grp = lane >> lg, jj = lane & (L - 1), R = 64 >> lg;
-    // owner of group g = the g-th live lane (wave-uniform walk over the set bits)
-    int owner = 0, nact = 0;
-    for (unsigned long long m = actmask; m; m &= m - 1ull, nact++)
-        if (grp == nact) owner = __ffsll((long long)m) - 1;
+    // owner of group g = the g-th live lane: every live lane leaves its number at its rank among the live lanes, group g reads entry
+    // g (one LDS round trip instead of a walk over the set bits: ~50 instructions per tick of a launch's latency-bound end)
+    const int nact = __popcll(actmask);
+    const int myrank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(actmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)actmask, 0u));
+    int *s_own = reinterpret_cast<int *>(s_x + 4 * 256) + 256;  // behind the exchange area
+    if (active) s_own[myrank] = lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const bool has = grp < nact;
+    const int owner = has ? s_own[grp] : 0;
     MARK("spread:owner_walk_end");
+    DIAG(tm[1] = __builtin_amdgcn_s_memtime();)
     const double a_o = __shfl(a_eval, owner);
     const double pm_o = use_prior ? __shfl(prior_mean, owner) : 0.0;
     const RowConsts c = row_consts(a_o, lt, et);
     MARK("spread:row_consts_end");
+    DIAG(tm[2] = __builtin_amdgcn_s_memtime();)
     // the five values of every sample pass through the wave's prefix-table area (idle in this layout), [value][sample R + group]:
     // each lane then reads its group's S samples — four samples' loads in flight at a time, same address within a group (a
     // broadcast), neighbouring banks across groups — and folds them in sample order.  (Round 2 fetched them with nine
@@ -708,6 +731,7 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
         s_xe[e] = v.pe;
     }
     MARK("spread:exchange_store_end");
+    DIAG(tm[3] = __builtin_amdgcn_s_memtime();)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -729,15 +753,18 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
     }
     __builtin_amdgcn_wave_barrier();  // (the area is written again only after every lane has read it)
     MARK("spread:fold_end");
+    DIAG(tm[4] = __builtin_amdgcn_s_memtime();)
     double lp_g, dlp_g;
     finish_point(acc, c, p2, use_prior, pm_o, prior_isig, lp_g, dlp_g, lt);
     MARK("spread:finish_end");
+    DIAG(tm[5] = __builtin_amdgcn_s_memtime();)
     // an active lane's group is its rank among the active lanes
-    const int src = (active ? __popcll(actmask & ((1ull << lane) - 1ull)) : 0) << lg;
+    const int src = (active ? myrank : 0) << lg;
     lp = __shfl(lp_g, src);
     dlp = __shfl(dlp_g, src);
     alpha_out = __shfl(c.alpha, src);
     MARK("spread:pickup_end");
+    DIAG(tm[6] = __builtin_amdgcn_s_memtime();)
 }
 
 template <bool MAP, int MINW>
@@ -802,7 +829,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     uint32_t deal = A.deal > 0 ? (uint32_t)A.deal : nA / (4u * nwaves);
     deal = deal < 1 ? 1 : (deal > (uint32_t)kSchedDeal ? (uint32_t)kSchedDeal : deal);
     DIAG(const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;)
-    DIAG(unsigned long long cy_sec[5] = {0, 0, 0, 0, 0}; bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
+    DIAG(unsigned long long cy_sp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_t6 = 0; bool sp_on = false; unsigned long long cy_ev[4] = {0, 0, 0, 0}; unsigned long long cy_sec[5] = {0, 0, 0, 0, 0}; bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
          if (A.stamps && lane == 0) A.stamps[gwave * kStampSlots + 0] = __builtin_amdgcn_s_memrealtime();)
 
     for (;;) {
@@ -824,14 +851,25 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     break;
                 }
                 uint32_t b, e;
-                if (!a_done) {  // this wave's next group of the static deal
-                    b = (a_k * nwaves + mywave) * deal;
-                    a_k++;
-                    if (b >= nA) {
+                if (!a_done) {
+                    // this wave's next 64 / deal groups of the static deal in one go: lane l reads entry l % deal of group a_k + l / deal
+                    // (positions grow with the lane, so the entries inside [0, nA) are the first lanes).  One group per chunk meant a
+                    // dependent load of 1 .. 8 schedule entries per attempt: at 250 k rows a refill of the launch's first 0.1 ms took
+                    // 7 900 cycles of a 20 800-cycle tick (in-kernel timers, round 4).
+                    const uint32_t per = 64u / deal, gq = (uint32_t)lane / deal, go = (uint32_t)lane - gq * deal;
+                    const uint32_t pos = ((a_k + gq) * nwaves + mywave) * deal + go;
+                    const bool valid = gq < per && pos < nA;
+                    const unsigned long long vm = __ballot(valid);
+                    a_k += per;
+                    if (vm == 0ull) {
                         a_done = true;
                         continue;
                     }
-                    e = b + deal < nA ? b + deal : nA;
+                    chunk_base = 0;
+                    chunk_len = (uint32_t)__popcll(vm);
+                    chunk_pos = 0;
+                    ord_reg = valid ? order[pos] : 0;
+                    touch = true;
                 } else {
                     if (heads_left == 0u) {
                         queue_empty = true;
@@ -853,13 +891,13 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                         continue;
                     }
                     e = b + kChunk < nTot ? b + kChunk : nTot;
+                    chunk_base = b;
+                    chunk_len = e - b;
+                    chunk_pos = 0;
+                    ord_reg = (int)chunk_base + lane;
+                    if (order && (uint32_t)lane < chunk_len) ord_reg = order[chunk_base + lane];
+                    touch = true;
                 }
-                chunk_base = b;
-                chunk_len = e - b;
-                chunk_pos = 0;
-                ord_reg = (int)chunk_base + lane;
-                if (order && (uint32_t)lane < chunk_len) ord_reg = order[chunk_base + lane];
-                touch = true;
             }
             const uint32_t cnt = (uint32_t)__popcll(needmask), avail = chunk_len - chunk_pos;
             const uint32_t take = cnt < avail ? cnt : avail;
@@ -996,11 +1034,15 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         })
         DIAG(const unsigned long long sec_t2 = __builtin_amdgcn_s_memtime();)
         if (lg_t >= 0) {
+            DIAG(unsigned long long tms[7];)
             eval_point_spread(s_nf, s_y, s_tab, lane, S, lg_t, gmask, p2, actmask, active, a_eval, MAP,
-                              prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab, s_exptab);
+                              prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab, s_exptab DIAG(, tms));
+            DIAG(for (int q = 0; q < 6; q++) cy_sp[q] += tms[q + 1] - tms[q]; cy_sp[6] += tms[0] - sec_t0; cy_sp[7]++; sp_t6 = tms[6]; sp_on = true;)
         } else if (active || helper) {
+            DIAG(unsigned long long tm[5];)
             eval_point(s_nf, s_y, s_tab, lane, slot, S, gmask, p2, a_eval, MAP, pm_e, prior_isig, l_new,
-                       dl_new, alpha_new, s_logtab, s_exptab);
+                       dl_new, alpha_new, s_logtab, s_exptab DIAG(, tm));
+            DIAG(if (sec_on) for (int q = 0; q < 4; q++) cy_ev[q] += tm[q + 1] - tm[q];)
         }
         MARK("tick:evaluate_end");
         DIAG(const unsigned long long sec_t3 = __builtin_amdgcn_s_memtime();)
@@ -1120,6 +1162,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             phase = PH_NEED;
         }
         MARK("tick:state_machine_end");
+        DIAG(if (sp_on) { cy_sp[8] += __builtin_amdgcn_s_memtime() - sp_t6; sp_on = false; })
         DIAG(if (sec_on) {
             const unsigned long long sec_t4 = __builtin_amdgcn_s_memtime();
             cy_sec[0] += sec_t1 - sec_t0; cy_sec[1] += sec_t2 - sec_t1; cy_sec[2] += sec_t3 - sec_t2; cy_sec[3] += sec_t4 - sec_t3; cy_sec[4]++;
@@ -1136,6 +1179,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         A.stamps[gwave * kStampSlots + 9] = cy_spread;
         A.stamps[gwave * kStampSlots + 10] = cy_burst;
         for (int q = 0; q < 5; q++) A.stamps[gwave * kStampSlots + 11 + q] = cy_sec[q];
+        for (int q = 0; q < 4; q++) A.stamps[gwave * kStampSlots + 16 + q] = cy_ev[q];
+        for (int q = 0; q < 9; q++) A.stamps[gwave * kStampSlots + 20 + q] = cy_sp[q];
     })
 }
 

@@ -17,7 +17,7 @@ dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64
 ctx.nbglm_fit(dk, dn, d["group"])
 raw = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64)
 pos = 0
-K = 16
+K = 29
 while pos < len(raw):
     kind, nw = int(raw[pos]), int(raw[pos + 1]); pos += 2
     st = raw[pos:pos + nw * K].reshape(nw, K).astype(np.int64); pos += nw * K
@@ -50,3 +50,9 @@ while pos < len(raw):
     tot_sec = sec[:, :4].sum()
     print("  bulk ticks (queue not empty), s_memtime cycles per tick: refill %.0f, choose point %.0f, evaluate %.0f, state machine %.0f (of %.0f); shares %.1f / %.1f / %.1f / %.1f %%" % (
         *(sec[:, :4].sum(0) / max(sec[:, 4].sum(), 1)), tot_sec / max(sec[:, 4].sum(), 1), *(100 * sec[:, :4].sum(0) / max(tot_sec, 1))))
+    ev = st[qe, 16:20].astype(float)
+    print("    inside evaluate (row per lane): row constants %.0f, prefix table %.0f, samples %.0f, finish %.0f cycles per tick" % tuple(ev.sum(0) / max(sec[:, 4].sum(), 1)))
+    sp = st[qe, 20:29].astype(float)
+    nsp = max(sp[:, 7].sum(), 1)
+    print("    samples-across-lanes ticks (%d per wave), cycles per tick: tick start -> evaluate %.0f | owner walk %.0f, row constants %.0f, prefix + sample + exchange store %.0f, fold %.0f, finish %.0f, pick-up %.0f | evaluate end -> tick end %.0f" % (
+        nsp / max(qe.sum(), 1), sp[:, 6].sum() / nsp, *(sp[:, :6].sum(0) / nsp), sp[:, 8].sum() / nsp))
