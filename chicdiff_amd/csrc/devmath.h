@@ -34,6 +34,9 @@ __device__ __forceinline__ double rcp(double x) {
     return fma(r, e, r);
 }
 
+// 1/x with IEEE behaviour outside rcp()'s range (zero, denormal, huge, infinite, NaN, negative: the division)
+__device__ __forceinline__ double rcp_or_div(double x) { return (x > 1e-300 && x < 1e300) ? rcp(x) : 1.0 / x; }
+
 // log(x) for positive, finite, normal x.  fdlibm's reduction (x = 2^k (1+f), s = f/(2+f)) with
 // the division done by rcp(): ~35 instructions against ~55 for the device-library log.  <= 1 ulp.
 __device__ __forceinline__ double flog(double x) {

@@ -536,6 +536,10 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
                                                          const double *__restrict__ nf, FitDims d, FitWork w, Opts o,
                                                          chicdiff_nbglm_out out) {
     extern __shared__ double s_q[];  // [S][blockDim.x] normalised counts of this thread's row
+    __shared__ LogEntry s_lt[64];
+    __shared__ ExpEntry s_et[64];
+    exp_table_to_lds(s_et);
+    log_table_to_lds(s_lt);  // (ends with the barrier)
     const int T = blockDim.x, tid = threadIdx.x;
     const int64_t n = d.n;
     const int S = d.S;
@@ -553,8 +557,10 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
             // rows the IRLS gave up on went through the optim fallback, which left 1 (reached the mode) or 0 there; -1 = IRLS converged
             const int oc = biter < o.betaMaxit ? -1 : w.optimConv[i];
             bconv = (biter < o.betaMaxit) || oc == 1;
-            const double E0 = exp(b0), E1 = exp(b0 + b1);
-            const double la = flog(alpha);
+            // (round 4: table-driven exp / log as in the IRLS, reciprocals where a quotient is not part of a decision — the kernel was
+            // 2 400 instructions per row, a third of them IEEE divisions and polynomial logarithms)
+            const double E0 = texp(b0, s_et), E1 = texp(b0 + b1, s_et);
+            const double la = tlog(alpha, s_lt);
             double wA = 0, wB = 0, ll = w.crow[i], m = 0;
             for (int j = 0; j < S; j++) {
                 const bool g = (d.gmask >> j) & 1;
@@ -568,8 +574,8 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
                 // path evaluates it after flooring mu, the IRLS path before
                 const double mul = oc >= 0 ? mu : muf;
                 const double ma = alpha * mul, t = 1.0 + ma;
-                ll -= (size + y) * flog1p_from(ma, t, rcp(t));
-                if (y > 0) ll += y * (la + flog(mul));
+                ll -= (size + y) * tlog1p_from(ma, t, rcp(t), s_lt);
+                if (y > 0) ll += y * (la + tlog(mul, s_lt));
                 if (want_cooks) {
                     const double q = y / nfj;
                     s_q[j * T + tid] = q;
@@ -577,7 +583,8 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
                 }
             }
             const double m00 = wA + wB + lambda, m01 = wB, m11 = wB + lambda, det = m00 * m11 - m01 * m01;
-            const double i00 = m11 / det, i01 = -m01 / det, i11 = m00 / det;
+            const double idet = rcp_or_div(det);
+            const double i00 = m11 * idet, i01 = -m01 * idet, i11 = m00 * idet;
             const double a00 = wA + wB, a01 = wB, a11 = wB;
             const double t00 = i00 * a00 + i01 * a01, t01 = i00 * a01 + i01 * a11;
             const double t10 = i01 * a00 + i11 * a01, t11 = i01 * a01 + i11 * a11;
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
                     const double wj = mu * rcp(fma(alpha, mu, 1.0));
                     const double h = wj * (g ? (i00 + 2 * i01 + i11) : i00);
                     const double V = muf + arob * muf * muf;
-                    const double ck = (yc - muf) * (yc - muf) / V / 2.0 * h / ((1 - h) * (1 - h));
+                    const double ck = ((yc - muf) * (yc - muf) * 0.5 * h) * rcp_or_div(V * ((1 - h) * (1 - h)));  // (y - mu)^2 / V / 2 h / (1 - h)^2
                     if (ck > call) { call = ck; amax = j; }
                     if ((g ? d.nB : d.nA) >= 3 && ck > mc) mc = ck;
                 }
