@@ -112,6 +112,31 @@ def test_fit_parity_two_groups(ctx, oracle, n, S):
     assert np.isnan(sc["sumDeviance"]) == bool((~nz).any())
 
 
+@pytest.mark.parametrize("S", [5, 12])
+def test_all_zero_rows_reach_the_row_queue_kernels_as_a_flag_in_the_record(ctx, oracle, S):
+    """The line searches and the IRLS learn that a row is all zero from the sign bit prep leaves in the row record's header
+    (round 4; before: a load of its own per row).  Rows zeroed at the positions that matter to a wave — first and last of the
+    matrix, either side of a 64-row chunk boundary, a run longer than a chunk — at S = 12 (record read by the 16-byte loader,
+    three quads) and S = 5 (the generic loader): NaN results and zero step counts exactly there, every other row against the
+    oracle as in every parity test."""
+    n = 4000
+    d = synth.make(n, S)
+    counts = d["counts"].copy()
+    zero = np.zeros(n, bool)
+    zero[[0, 1, 63, 64, 65, 127, n - 1]] = True
+    zero[1000:1100] = True
+    counts[zero] = 0
+    got, sc = run_fit(ctx, dict(d, counts=counts), d["group"])
+    az = counts.sum(1) == 0
+    assert zero[az].sum() == zero.sum() and np.array_equal(got["allZero"] != 0, az)
+    for k in ("dispGeneEst", "dispFit", "dispMAP", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue"):
+        assert np.all(np.isnan(got[k][az])), k
+        assert not np.any(np.isnan(got[k][~az])), k
+    for k in ("dispGeneIter", "dispIter", "betaIter"):
+        assert np.all(got[k][az] == 0) and np.all(got[k][~az] > 0), k
+    explain_fit(f"{n} x {S} with rows zeroed", oracle, counts, d["nf"], d["group"], got, sc)
+
+
 def test_fit_parity_2v2_with_prior(ctx, oracle):
     d = synth.make(20000, 4)
     got, sc = run_fit(ctx, d, d["group"], dispPriorVar=0.8)
@@ -981,7 +1006,19 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
         e = run()
     finally:
         ctx.set_option("line_search_schedule", 1)
+    # the static deal hands a wave 64 schedule entries at a time, 64 / deal groups of `deal` entries each (1 .. 8; lanes beyond
+    # the last whole group stay empty when 64 is not a multiple): every group size gives the same bits
+    deals = {}
+    for deal in (1, 3, 8):
+        ctx.set_option("line_search_deal", deal)
+        try:
+            deals[deal] = run()
+        finally:
+            ctx.set_option("line_search_deal", 0)
     assert (a["dispGeneIter"] >= 100).sum() > 10  # the stragglers this is about are present
+    for deal, f in deals.items():
+        for k in a:
+            assert np.array_equal(a[k], f[k], equal_nan=True), f"{k}: deal {deal} differs"
     if n >= 300000:
         assert (a["betaIter"] >= 20).sum() > 0  # ... and the IRLS's
     for k in a:
