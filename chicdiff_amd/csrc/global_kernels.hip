@@ -154,6 +154,32 @@ __device__ __forceinline__ bool grid_sync(unsigned int *top, unsigned int *group
     __syncthreads();
     return ok != 0;
 }
+// (Measured and dropped, round 4: a barrier by flags — workgroup b publishes `pass + 1` in flags[b], thread t of every workgroup
+// polls flags[t]; no read-modify-write, no chain of arrivals.  Slower: 4.6-5.4 us per barrier instead of 3.3-3.8 at 122 workgroups,
+// 12.8 instead of 5-6 at 256 — 256 x 256 polling loads per round trip swamp the path to the flags' home.  And the counters
+// without the top level — arrivals by an atomic add nobody waits for, lanes 0..7 of every workgroup polling the eight group
+// counters, so that no arrival depends on a returned count: workgroup 0 passes the barriers of the trend passes in 2.2 instead of
+// 3.6 us (250 k rows) and 3.7 instead of 5-6 (2 M), but the barriers of the MAD's histogram rounds, where every workgroup arrives
+// in a burst behind its global atomics, get slower by as much: launch 0.190 -> 0.188 ms at 250 k, 0.365 -> 0.380 at 2 M.)
+
+// Sum over the 64 lanes of a wave, result in lane 63, by DPP row shifts and row broadcasts (an inclusive scan: fixed order, no
+// LDS round trips).  The eight sums of a trend pass through ds_bpermute shuffles were 48 dependent LDS trips per wave — with 16
+// waves per workgroup 4-6 us of a 12-20 us pass (same stamps).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return x + __hiloint2double(hi, lo);  // lanes without a source (or masked out) add +0.0
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double x) {
+    x = dpp_add<0x111, 0xf>(x);  // row_shr:1
+    x = dpp_add<0x112, 0xf>(x);  // row_shr:2
+    x = dpp_add<0x114, 0xf>(x);  // row_shr:4
+    x = dpp_add<0x118, 0xf>(x);  // row_shr:8   -> lane 15 of every row of 16: the row's sum
+    x = dpp_add<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+    x = dpp_add<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3 -> lane 63: everything
+    return x;
+}
 
 // ---- MAD of the log residuals inside the persistent trend kernel ------------------------------------------------------
 // Round 3 followed the trend kernel with resid_kernel and two radix selects — 14 dependent launches and 4 fills that move 16 MB
@@ -183,6 +209,13 @@ __device__ unsigned long long g_mad_t0, g_mad_t[64];
 __device__ int g_mad_lab[64], g_mad_n;
 #else
 #define MSTAMP(label)
+#endif
+#ifdef CHICDIFF_TREND_STAMPS  // diagnostic build only: where a pass of the persistent trend kernel spends its time (workgroup 0)
+#define TSTAMP(label) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_tr_n < 160) { g_tr_lab[g_tr_n] = (label); g_tr_t[g_tr_n++] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+__device__ unsigned long long g_tr_t[160];
+__device__ int g_tr_lab[160], g_tr_n;
+#else
+#define TSTAMP(label)
 #endif
 // wave-aggregated histogram update: lanes that hold the same digit add once (the first digit — sign and exponent — is shared by
 // almost every key of a column, and 64 lanes adding 1 to one LDS word serialise)
@@ -381,8 +414,13 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
         for (int k = tid; k < kMadScratchWords; k += kTpThreads) gscratch[k] = 0;
     bool alive = true;
     unsigned int pass = 0;
+#ifdef CHICDIFF_TREND_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_tr_n = 0;
+#endif
+    TSTAMP(9);
     for (; pass < 11 * 27 + 16; pass++) {
         if (st.finished) break;
+        TSTAMP(10);
         double v[kTrendSums] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = tid; k < ncache; k += kTpThreads) {
             const double y = s_y[k];
@@ -392,11 +430,11 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
             const double y = w.dispGene[i];
             if (!w.allZero[i] && (y > 100 * minDisp)) trend_row_dev(&st, 1.0 / w.baseMean[i], y, v, s_lt);
         }
+        TSTAMP(11);
 #pragma unroll
         for (int k = 0; k < kTrendSums; k++) {
-            double x = v[k];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-            if (lane == 0) red[k][wave] = x;
+            const double x = wave_sum_to_lane63(v[k]);
+            if (lane == 63) red[k][wave] = x;
         }
         __syncthreads();
         double *mine = slots + ((size_t)(pass & 1) * gridDim.x + blockIdx.x) * kTrendSums;
@@ -405,7 +443,9 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
             for (int q = 0; q < kTpThreads / 64; q++) acc += red[tid][q];
             mine[tid] = acc;
         }
+        TSTAMP(12);
         alive = grid_sync(ctr, grp, pass);
+        TSTAMP(13);
         if (!alive) break;
         // every workgroup: fixed-order sum of all partials (wave k sums quantity k: 64 lanes x strided
         // partials, then a shuffle tree — the same order in every workgroup), then the same state-machine step
@@ -413,17 +453,20 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
         if (wave < kTrendSums) {
             double acc = 0;
             for (unsigned int b = lane; b < gridDim.x; b += 64) acc += all[(size_t)b * kTrendSums + wave];
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-            if (lane == 0) red[wave][0] = acc;
+            acc = wave_sum_to_lane63(acc);
+            if (lane == 63) red[wave][0] = acc;
         }
         __syncthreads();
+        TSTAMP(14);
         if (tid == 0) {
             double sums[kTrendSums];
             for (int k = 0; k < kTrendSums; k++) sums[k] = red[k][0];
             trend_step(&st, sums);
         }
         __syncthreads();
+        TSTAMP(15);
     }
+    TSTAMP(16);
     // ---- MAD of the log residuals around the trend (estimateDispersionsFit's varLogDispEsts), see mad_select above --------
     double med = NAN, madv = NAN, nres = 0;
     if (mad && alive) {
@@ -480,6 +523,9 @@ __global__ __launch_bounds__(kTpThreads) void trend_persistent_kernel(FitDims d,
         sc->conv = st.conv;
         sc->failed = alive ? (st.finished ? st.failed : 2) : 3;  // 3: grid barrier timed out
         sc->finished = 1;
+#ifdef CHICDIFF_TREND_STAMPS
+        for (int q = 0; q < g_tr_n; q++) printf("  trend stamp %3d %8.2f us\n", g_tr_lab[q], (double)(g_tr_t[q] - g_tr_t[0]) / 100.0);
+#endif
 #ifdef CHICDIFF_MAD_STAMPS
         for (int q = 0; q < g_mad_n; q++) printf("  mad stamp %3d %8.2f us\n", g_mad_lab[q], (double)(g_mad_t[q] - g_mad_t0) / 100.0);
 #endif
