@@ -193,6 +193,12 @@ __device__ __forceinline__ bool load_row_sums(const char *row, int S, double *s_
     return __double2hiint(hdr[0]) >= 0;
 }
 
+#ifdef CHICDIFF_DIAG
+#define WDIAG(...) __VA_ARGS__
+__device__ unsigned long long g_irls_cy[8];  // s_memtime cycles summed over all waves: refill / evaluate / rest / ticks, while the queue has rows and after
+#else
+#define WDIAG(...)
+#endif
 struct WaldArgs {
     const int32_t *counts;
     const double *nf;
@@ -249,7 +255,9 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
     int k = 0;
     double b0 = 0, b1 = 0, alpha = 0, size = 0, crow = 0, dev_old = 0, syA = 0, syB = 0;
 
+    WDIAG(unsigned long long cyw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_eval_end = 0;)
     for (;;) {
+        WDIAG(const int sec = queue_empty ? 4 : 0; const unsigned long long wt0 = __builtin_amdgcn_s_memtime();)
         // refill (the scheme of disp_fit_kernel's: scalar chunk bookkeeping, a chunk's schedule entries read once and handed out by
         // lane permute, the all-zero flag and the whole record in one round trip)
         unsigned long long needmask = __ballot(need && !done);
@@ -280,7 +288,10 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                     rest_base = cq * (uint32_t)A.chunk;
                     rest_end = rest_base + (uint32_t)A.chunk < nTot ? rest_base + (uint32_t)A.chunk : nTot;
                 }
-                // the next (up to) 64 entries of the dequeued run: one per lane
+                // the next (up to) 64 entries of the dequeued run: one per lane.  (Measured and dropped, round 4: the 64 entries after
+                // them read at the same time and every record's first line touched a piece ahead, as the line search warms its rows:
+                // the refill's 5 600 cycles of an IRLS tick's 16 500 — in-kernel timers, make DIAG=1 + CHICDIFF_IRLS_STAMPS — stayed
+                // 5 300, the launch 0.349 ms: the refill is not waiting for cold lines.)
                 const uint32_t b = rest_base;
                 chunk_len = rest_end - rest_base < 64u ? rest_end - rest_base : 64u;
                 rest_base += chunk_len;
@@ -317,6 +328,7 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
             needmask = __ballot(need && !done);
         }
         if (__ballot(!done) == 0ull) break;
+        WDIAG(const unsigned long long wt1 = __builtin_amdgcn_s_memtime();)
         const bool active = !need && !done;
         const unsigned long long actmask = __ballot(active);
         double wA = 0, wB = 0, uA = 0, uB = 0, Dl = 0, zcA = 0, zcB = 0, Dc = 0;
@@ -428,6 +440,7 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                     Dc = fma(-y, de, Dc);  // log mu_j = log nf_j + eta_group + de
                 }
             }
+            WDIAG(const unsigned long long wt2 = __builtin_amdgcn_s_memtime(); cyw[sec + 0] += wt1 - wt0; cyw[sec + 1] += wt2 - wt1; cyw[sec + 3]++; wt_eval_end = wt2;)
             const double zA = fma(etaA - 1.0, wA, uA) + zcA, zB = fma(etaB - 1.0, wB, uB) + zcB;
             const double D = (Dl - fma(etaA, syA, etaB * syB)) + Dc;  // `crow` carries the per-row constant
             bool stop = false;
@@ -472,7 +485,9 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                 need = true;
             }
         }
+        WDIAG(if (wt_eval_end) { cyw[sec + 2] += __builtin_amdgcn_s_memtime() - wt_eval_end; wt_eval_end = 0; })
     }
+    WDIAG(if (lane == 0) for (int q = 0; q < 8; q++) atomicAdd(&g_irls_cy[q], cyw[q]);)
 }
 
 // (Measured and dropped, round 2: the same IRLS with the row held in registers — exec-masked refill loads, 64-row chunks,
@@ -802,7 +817,26 @@ void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWor
     // 0.377 ms at 2 M x 8 (S = 4: 0.37 / 0.34 / 0.32; S = 16: - / 0.56 / 0.54), 500 k x 8: 0.217 / 0.195 / 0.210
     const int64_t per_wave = d.n / (blocks * (threads / 64));
     A.chunk = per_wave >= 256 ? 128 : 64;
+#ifdef CHICDIFF_DIAG
+    const bool stamps = getenv("CHICDIFF_IRLS_STAMPS") != nullptr;  // diagnostic build only: blocking, never timed
+    if (stamps) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_irls_cy), z, sizeof z);
+    }
+#endif
     wald_irls_kernel<<<(unsigned)blocks, threads, lds, st>>>(A);
+#ifdef CHICDIFF_DIAG
+    if (stamps) {
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[8];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_irls_cy), sizeof h);
+        for (int q = 0; q < 2; q++) {
+            const double t = h[4 * q + 3] ? (double)h[4 * q + 3] : 1.0;
+            printf("  IRLS ticks %s: %.0f per wave; s_memtime cycles per tick: refill %.0f, evaluate %.0f, solve + state %.0f\n",
+                   q ? "after the queue ran dry" : "while the queue has rows", t / (double)(blocks * (threads / 64)), h[4 * q] / t, h[4 * q + 1] / t, h[4 * q + 2] / t);
+        }
+    }
+#endif
 }
 void launch_wald_final(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                        const chicdiff_nbglm_out &out, hipStream_t st) {
