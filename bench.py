@@ -134,6 +134,37 @@ def theta_grid_time(ctx, torch, dk, dfm, S):
     return {"ms": round(float(np.median(ts)), 3), "thetas": len(grid), "runs_ms": [round(t, 3) for t in ts]}
 
 
+def theta_grid_replicas_time(hip, synth, torch, dist, local_rank, n_global, S):
+    """a8 with N > 1 ranks as a REPLICA problem (chicdiff_amd.dist.theta_grid_replicas): every rank holds all `n_global` rows on
+    its own GPU in a context WITHOUT a process group, fits its share of the 5 grid points, one all-gather of 5 doubles follows.
+    Wall clock between barriers, max over ranks."""
+    from chicdiff_amd.dist import theta_grid_replicas, theta_replica_plan
+    c2 = hip.HipContext(local_rank)
+    try:
+        d = synth.make(n_global, S)
+        dk = c2.to_device(d["counts"], np.int32)
+        dfm = c2.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)
+        sf = c2.size_factors(dk)
+        grid = [0.0, 0.25, 0.5, 0.75, 1.0]
+        theta_grid_replicas(c2, dk, dfm, sf, grid)
+        ts = []
+        for _ in range(3):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            theta_grid_replicas(c2, dk, dfm, sf, grid)
+            torch.cuda.synchronize()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            ts.append(float(dt.item()) * 1e3)
+        world = dist.get_world_size()
+        return {"ms": round(float(np.median(ts)), 3), "thetas": len(grid), "runs_ms": [round(t, 3) for t in ts], "rows_per_rank": n_global,
+                "points_per_rank": [len(x) for x in theta_replica_plan(len(grid), world)],
+                "what": "every rank holds all rows and fits theta k for k = rank mod world; one all-gather of 5 doubles (max over ranks)"}
+    finally:
+        c2.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +386,8 @@ def main():
         result["other_scaling"] = {"scaling": other, "value": round(mo["n_global"] / (mo["elapsed"] / args.steps), 1), "unit": "interactions/s",
                                    "ms_per_step": round(mo["elapsed"] / args.steps * 1e3, 3), "rows_per_gpu": mo["n"], "global_rows": mo["n_global"],
                                    "steps": args.steps, "warmup": args.warmup}
+    if world > 1 and not args.no_hbm_kernels:  # (every rank takes part; rank 0 reports)
+        result["theta_grid_replicas"] = theta_grid_replicas_time(hip, synth, torch, dist, local_rank, args.rows, S)
     if rank == 0 and world == 1 and not args.no_hbm_kernels:
         result["hbm_kernels"] = hbm_kernels(ctx, torch, n, S)
         result["theta_grid"] = theta_grid_time(ctx, torch, dk, dfm, S)

@@ -29,6 +29,47 @@ def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+def theta_replica_plan(ntheta: int, world: int) -> list[list[int]]:
+    """Which grid points each rank fits in replica mode: point k goes to rank k mod world (round robin, so that with
+    world >= ntheta every rank fits at most one)."""
+    if world < 1 or ntheta < 0:
+        raise ValueError("bad world/ntheta")
+    return [[k for k in range(ntheta) if k % world == r] for r in range(world)]
+
+
+def theta_grid_replicas(ctx, d_counts, d_fullmean, size_factors, thetas, group=None, opts=None) -> np.ndarray:
+    """The theta grid of DESeq2Wrap (chicdiff.R:1641-1647: one design-~1 fit per mixing parameter, the total deviance of each)
+    as a REPLICA problem: every rank holds ALL rows (`d_counts`, `d_fullmean` are the complete matrices on its own GPU), rank r
+    fits the points k = r, r + world, ... on its own, and ONE all-gather of ntheta doubles puts every total on every rank.
+    With world >= len(thetas) the grid costs one fit instead of len(thetas).
+
+    `ctx` must be a context WITHOUT a process group attached (its fits are complete, nothing is sharded); the fits are the ones
+    `ctx.theta_grid` makes, so the totals are bit for bit those of the single-process grid.  The alternative when rows ARE
+    sharded — len(thetas) sharded fits one after the other on a context with `set_process_group` — needs no copy of the rows and
+    is what `DESeq2Wrap` uses; this function is for callers whose ranks hold the whole interaction set."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    thetas = [float(t) for t in thetas]
+    mine = theta_replica_plan(len(thetas), world)[rank]
+    part = np.zeros(len(thetas), dtype=np.float64)
+    if mine:
+        part[mine] = ctx.theta_grid(d_counts, d_fullmean, size_factors, [thetas[k] for k in mine], opts=opts)
+    # every point is fitted by exactly one rank: gather the ranks' vectors and pick each point from its owner (a sum of zero-filled
+    # vectors would do as well, but a NaN total — a region with zero counts in every sample — must arrive as NaN, not poison the rest)
+    backend = dist.get_backend(group)
+    t = torch.from_numpy(part)
+    if backend == "nccl":
+        t = t.to(d_counts.device)
+    got = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(got, t, group=group)
+    out = np.empty(len(thetas), dtype=np.float64)
+    for k in range(len(thetas)):
+        out[k] = float(got[k % world][k])
+    return out
+
+
 class _RawDevice:
     """Raw device pointer exposed to torch through __cuda_array_interface__."""
 

@@ -217,3 +217,59 @@ def test_allgather_hook_lays_the_ranks_blocks_out_in_rank_order():
     for rank, rc, err, recv, gathers, doubles in res:
         assert rc == 0 and err == "None", (rank, err)
         assert np.array_equal(np.array(recv), want) and gathers == 1 and doubles == 1000
+
+
+class _StubGrid:
+    """Stands in for HipContext.theta_grid: a 'total deviance' that is a known function of theta, NaN at theta = 0.75, and a record
+    of what this rank was asked to fit."""
+
+    def __init__(self):
+        self.asked = []
+
+    def theta_grid(self, d_counts, d_fullmean, size_factors, thetas, opts=None):
+        self.asked.append(list(thetas))
+        return np.array([np.nan if t == 0.75 else 1000.0 + 7.0 * t * t - 3.0 * t for t in thetas])
+
+
+def _replica_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from chicdiff_amd.dist import theta_grid_replicas
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        stub = _StubGrid()
+        dummy = torch.zeros(2, 2)
+        out = theta_grid_replicas(stub, dummy, dummy, [1.0, 1.0], [0.0, 0.25, 0.5, 0.75, 1.0])
+        q.put((rank, out.tolist(), stub.asked))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_theta_grid_replicas_every_point_once_and_every_total_everywhere():
+    """theta grid in replica mode (chicdiff_amd.dist.theta_grid_replicas, world_size 2 over gloo, the fit replaced by a stub):
+    point k is fitted by rank k mod world and by nobody else, one all-gather puts every total — a NaN one included, as NaN —
+    on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    from chicdiff_amd.dist import theta_replica_plan
+    assert theta_replica_plan(5, 2) == [[0, 2, 4], [1, 3]] and theta_replica_plan(5, 8) == [[0], [1], [2], [3], [4], [], [], []]
+    assert theta_replica_plan(5, 1) == [[0, 1, 2, 3, 4]]
+    ctx = mp.get_context("spawn")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    want = [1000.0, 1000.0 + 7.0 / 16 - 0.75, 1000.0 + 7.0 / 4 - 1.5, float("nan"), 1004.0]
+    assert res[0][2] == [[0.0, 0.5, 1.0]] and res[1][2] == [[0.25, 0.75]]
+    for rank, out, _ in res:
+        assert np.array_equal(np.array(out), np.array(want), equal_nan=True), (rank, out)

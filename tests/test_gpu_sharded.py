@@ -358,3 +358,73 @@ def test_option_select_all_rounds_survives_an_overflow_refit(reference):
     assert user_forced_refits == 0 and user_forced_calls == user_calls == user_after_calls and user_calls > base_calls
     assert np.array_equal(p0, p3, equal_nan=True) and np.array_equal(p0, p4, equal_nan=True)
     c.close()
+
+
+def _replica_worker(rank, world, port, n_rows, thetas, q):
+    import torch.distributed as dist
+    from chicdiff_amd import hip
+    from chicdiff_amd.dist import theta_grid_replicas
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = hip.HipContext(0)  # no process group on the context: every replica's fits are complete
+        d = synth.make(n_rows, S)
+        keep = d["counts"].sum(1) > 0  # (DESeq2Wrap hands the grid regions with counts; an all-zero one makes the total NA)
+        dk = c.to_device(d["counts"][keep], np.int32)
+        dF = c.to_device((d["nf"] * (d["mu"][:, None] / S))[keep], np.float64)
+        sf = c.size_factors(dk)
+        dev = theta_grid_replicas(c, dk, dF, sf, thetas)
+        q.put((rank, dev.tolist(), [float(x) for x in sf]))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_theta_grid_replicas_two_processes_equal_the_single_process_grid():
+    """theta grid as a replica problem (chicdiff_amd.dist.theta_grid_replicas): two processes sharing GPU 0, each holding all
+    400 k rows; rank 0 fits theta = 0, 0.5, 1, rank 1 fits 0.25, 0.75, one all-gather (gloo) puts the five total deviances on
+    both — the five totals of the single-process grid (every point is the same design-~1 fit whoever makes it), and the same
+    argmin."""
+    import torch.multiprocessing as mp
+    n_rows, thetas, world = 400_000, [0.0, 0.25, 0.5, 0.75, 1.0], 2
+    from chicdiff_amd import hip
+    d = synth.make(n_rows, S)
+    keep = d["counts"].sum(1) > 0
+    ctx = hip.HipContext(0)
+    try:
+        dk = ctx.to_device(d["counts"][keep], np.int32)
+        dF = ctx.to_device((d["nf"] * (d["mu"][:, None] / S))[keep], np.float64)
+        sf = ctx.size_factors(dk)
+        ref = ctx.theta_grid(dk, dF, sf, thetas)
+        del dk, dF
+    finally:
+        ctx.close()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_replica_worker, args=(r, world, port, n_rows, thetas, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=600) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    print("single process:", ref.tolist(), "rows:", int(keep.sum()))
+    assert np.all(np.isfinite(ref))
+    for rank, dev, sf_r in res:
+        dev = np.array(dev)
+        print(f"rank {rank}:", dev.tolist())
+        assert np.array_equal(np.array(sf_r), np.array(sf))
+        assert np.array_equal(np.isnan(dev), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.allclose(dev[ok], ref[ok], rtol=1e-10, atol=0), (rank, dev, ref)
+        if ok.all():
+            assert int(np.argmin(dev)) == int(np.argmin(ref))
+    assert res[0][1] == res[1][1] or np.array_equal(np.array(res[0][1]), np.array(res[1][1]), equal_nan=True)
