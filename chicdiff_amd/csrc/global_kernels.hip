@@ -238,7 +238,7 @@ __device__ __forceinline__ void hist_add(unsigned int *h, bool valid, unsigned i
 template <class KeyFn>
 __device__ bool mad_select(KeyFn key_fn, int64_t nrows_block, int sel, unsigned int *gscratch, unsigned int *s_a, unsigned int *s_b,
                            uint64_t *sortbuf, unsigned int *ctr, unsigned int *grp, unsigned int &pass, uint64_t (&result)[2], double &population) {
-    __shared__ uint64_t sh_pre[2];
+    __shared__ uint64_t sh_pre[2], sh_res[2];
     __shared__ double sh_rank[2], sh_pop;
     __shared__ unsigned int sh_cnt[2];
     __shared__ double sh_scan[kTpThreads / 64];
@@ -350,19 +350,45 @@ __device__ bool mad_select(KeyFn key_fn, int64_t nrows_block, int sel, unsigned 
     MSTAMP(4);
     if (!grid_sync(ctr, grp, pass++)) return false;
     MSTAMP(5);
+    // The order statistics wanted, read off each list by COUNTING instead of sorting it (round 4: a bitonic sort of ~100 keys cost
+    // 4 us — 28 rounds of compare-exchange with a workgroup barrier each — and there are up to four lists per MAD): the list goes
+    // to LDS, P = 1024 / (its length rounded up to a power of two) threads share one candidate, each counts the keys that come
+    // before it (smaller, or equal with a lower index) in its slice of the list, the P counts are added by shuffles, and the
+    // candidate whose count is the wanted rank is the answer.  Lists longer than 512 keep the sort.
     for (int slot = 0; slot < 2; slot++) {
         const int hslot = (slot == 1 && !same) ? 1 : 0;
         const int m = (int)gcnt[hslot];
         MSTAMP(100 + m);
-        if (slot == 1 && same) {  // both middles sit in the list that is sorted already
-            const int rk = (int)rank1;
-            result[1] = sortbuf[rk < m ? rk : m - 1];
+        if (slot == 1 && same) break;  // (both middles were read off the one list below)
+        const int rkA = (int)(slot ? rank1 : rank0), rkB = same ? (int)rank1 : -1;
+        const int wantA = rkA < m ? rkA : m - 1, wantB = rkB < 0 ? -1 : (rkB < m ? rkB : m - 1);
+        __syncthreads();
+        if (m <= kMadSortMax) {
+            int mp = 64;
+            while (mp < m) mp <<= 1;
+            const int P = kTpThreads / mp;  // 2 .. 16 threads per candidate, neighbouring lanes
+            for (int e = tid; e < m; e += kTpThreads) sortbuf[e] = gcand[(size_t)hslot * kSelCap + e];
             __syncthreads();
-            break;
+            const int e = tid / P, part = tid - e * P;
+            int before = 0;
+            const uint64_t mine = e < m ? sortbuf[e] : 0ull;
+            if (e < m)
+                for (int j = part; j < m; j += P) {
+                    const uint64_t o = sortbuf[j];
+                    before += (o < mine || (o == mine && j < e)) ? 1 : 0;
+                }
+            for (int off = 1; off < P; off <<= 1) before += __shfl_xor(before, off);
+            if (e < m && part == 0) {  // (ranks are distinct: exactly one candidate has each)
+                if (before == wantA) sh_res[0] = mine;
+                if (before == wantB) sh_res[1] = mine;
+            }
+            __syncthreads();
+            result[slot] = sh_res[0];
+            if (wantB >= 0) result[1] = sh_res[1];
+            continue;
         }
         int len = 64;
         while (len < m) len <<= 1;
-        __syncthreads();
         for (int e = tid; e < len; e += kTpThreads) sortbuf[e] = e < m ? gcand[(size_t)hslot * kSelCap + e] : ~0ull;
         __syncthreads();
         for (int k2 = 2; k2 <= len; k2 <<= 1)  // bitonic sort, ascending
@@ -377,8 +403,8 @@ __device__ bool mad_select(KeyFn key_fn, int64_t nrows_block, int sel, unsigned 
                 }
                 __syncthreads();
             }
-        const int rk = (int)(slot ? rank1 : rank0);
-        result[slot] = sortbuf[rk < m ? rk : m - 1];
+        result[slot] = sortbuf[wantA];
+        if (wantB >= 0) result[1] = sortbuf[wantB];
         __syncthreads();
     }
     MSTAMP(6);
