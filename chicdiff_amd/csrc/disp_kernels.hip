@@ -250,7 +250,7 @@ __global__ void xim_kernel(FitDims d, FitWork w, const double *slots, int world)
 }
 
 constexpr int kColsumBlocks = 512;  // per column; (S+1) x 512 partials fit the 1024 x 72 partials buffer for S <= 64
-static int prep16_blocks(int S) { return row_stride(S) > 128 ? 1536 : 768; }  // (S + 1) x 1536 partials fit as well
+static int prep16_blocks(int) { return 1024; }  // four workgroups per CU — what their LDS tiles (34-38 KB) allow at once: one full round, no tail (768: 0.148 -> 0.127 ms at 2 M x 8, 1280: 0.163; S = 16: 1536 -> 1024: 0.40 -> 0.32, 2048: 0.33; round 4); (S + 1) x 1024 partials
 void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts, hipStream_t st) {
     if (d.S <= 16) {  // one resident round: 3 workgroups of 256 per CU; the LDS tile stays under 34 KB; the column sums ride along
         const int T = row_stride(d.S) > 128 ? 128 : 256;
