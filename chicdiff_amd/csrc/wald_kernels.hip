@@ -47,9 +47,15 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
         }
         const LgrCtx cs = lgr_make(rcp(alpha)), c1 = lgr_one();
         double lA = 0, lB = 0, c = 0, cst = 0;
+        int yi_next = counts[i];
+        double nf_next = nf[i];
         for (int j = 0; j < S; j++) {
-            const int yi = counts[(int64_t)j * n + i];
-            const double nfj = nf[(int64_t)j * n + i];
+            const int yi = yi_next;
+            const double nfj = nf_next;
+            if (j + 1 < S) {  // the next sample's loads are in flight while this one is worked on
+                yi_next = counts[(int64_t)(j + 1) * n + i];
+                nf_next = nf[(int64_t)(j + 1) * n + i];
+            }
             const double l = tlog((double)yi / nfj + 0.1, s_lt);
             if ((d.gmask >> j) & 1) lB += l; else lA += l;
             if (yi > 0) {
@@ -577,10 +583,16 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
             const double E0 = texp(b0, s_et), E1 = texp(b0 + b1, s_et);
             const double la = tlog(alpha, s_lt);
             double wA = 0, wB = 0, ll = w.crow[i], m = 0;
+            int y_next = counts[i];
+            double nf_next = nf[i];
             for (int j = 0; j < S; j++) {
                 const bool g = (d.gmask >> j) & 1;
-                const double y = (double)counts[(int64_t)j * n + i];
-                const double nfj = nf[(int64_t)j * n + i];
+                const double y = (double)y_next;
+                const double nfj = nf_next;
+                if (j + 1 < S) {  // the next sample's loads are in flight while this one is worked on
+                    y_next = counts[(int64_t)(j + 1) * n + i];
+                    nf_next = nf[(int64_t)(j + 1) * n + i];
+                }
                 const double muf = nfj * (g ? E1 : E0);  // no floor for the likelihood
                 const double mu = fmax(muf, o.minmu);
                 const double wj = mu * rcp(fma(alpha, mu, 1.0));
@@ -627,10 +639,16 @@ __global__ __launch_bounds__(256) void wald_final_kernel(const int32_t *__restri
                 const double arob = fmax((vmax - m) / (m * m), 0.04);
                 mc = -INFINITY;
                 double call = -INFINITY;  // which.max(cooks[i, ]) runs over ALL samples
+                int yc_next = counts[i];
+                double nfc_next = nf[i];
                 for (int j = 0; j < S; j++) {
                     const bool g = (d.gmask >> j) & 1;
-                    const double nfj = nf[(int64_t)j * n + i];
-                    const double yc = (double)counts[(int64_t)j * n + i];
+                    const double nfj = nfc_next;
+                    const double yc = (double)yc_next;
+                    if (j + 1 < S) {
+                        yc_next = counts[(int64_t)(j + 1) * n + i];
+                        nfc_next = nf[(int64_t)(j + 1) * n + i];
+                    }
                     const double muf = nfj * (g ? E1 : E0);
                     const double mu = fmax(muf, o.minmu);
                     const double wj = mu * rcp(fma(alpha, mu, 1.0));
