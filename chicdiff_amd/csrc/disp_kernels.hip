@@ -383,8 +383,32 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
     const int64_t lo = tile > 0 ? (int64_t)blockIdx.x * tile : (int64_t)blockIdx.x * 256;
     const int64_t hi = tile > 0 ? (lo + tile < d.n ? lo + tile : d.n) : d.n;
     const int64_t step = tile > 0 ? 256 : (int64_t)gridDim.x * 256;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += step) {
-        if (w.allZero[i]) {
+    // (the next row's inputs are loaded before the current row is worked on: a thread walks ~8 rows, and with the loads issued
+    // only when their row's turn came every row cost a full memory round trip)
+    struct In { int az; double bm, a, b, g0, g1; };
+    auto load_in = [&](int64_t i) {
+        In r;
+        r.az = w.allZero[i];
+        r.bm = w.baseMean[i];
+        if (!MAP) {
+            r.a = w.baseVar[i];
+            r.b = w.rough[i];
+            r.g0 = w.gm0[i];
+            r.g1 = w.gm1[i];
+        } else {
+            r.a = w.dispGene[i];
+            r.b = sc->trend_local ? w.dispFit[i] : 0.0;
+            r.g0 = r.g1 = 0.0;
+        }
+        return r;
+    };
+    int64_t i = lo + threadIdx.x;
+    In nxt{};
+    if (i < hi) nxt = load_in(i);
+    for (; i < hi; i += step) {
+        const In cur = nxt;
+        if (i + step < hi) nxt = load_in(i + step);
+        if (cur.az) {
             if (!MAP) {  // not scheduled at all (order_*): the line search never sees the row
                 w.cls[i] = 255;
                 w.dispGene[i] = NAN;
@@ -392,18 +416,18 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
             }
             continue;
         }
-        const double bm = w.baseMean[i];
+        const double bm = cur.bm;
         if (!MAP) {
-            const double moments = (w.baseVar[i] - xim * bm) / (bm * bm);
-            const double a0 = fmin(fmax(o.minDisp, fmin(w.rough[i], moments)), o.maxDisp);
-            const double g0 = w.gm0[i], g1 = w.gm1[i];
+            const double moments = (cur.a - xim * bm) / (bm * bm);
+            const double a0 = fmin(fmax(o.minDisp, fmin(cur.b, moments)), o.maxDisp);
+            const double g0 = cur.g0, g1 = cur.g1;
             reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, d.S))[1] = make_double2(a0, log(a0));  // what the search reads with the row (the means are there since prep)
             const int c = sched_class(a0, d.p == 2 ? fmin(g0, g1) : g0, o.minDisp);
             w.cls[i] = (uint8_t)c;
 #pragma unroll
             for (int k = 0; k < kSchedClasses; k++) mine[k] += (c == k);
         } else {
-            const double dg = w.dispGene[i], df = sc->trend_local ? w.dispFit[i] : c0 + c1 / bm;
+            const double dg = cur.a, df = sc->trend_local ? cur.b : c0 + c1 / bm;
             const double ldf = log(df);
             w.dispFit[i] = df;
             reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, d.S))[1] = make_double2(dg > 0.1 * df ? log(dg) : ldf, ldf);  // start value, prior mean

@@ -1213,11 +1213,23 @@ __global__ __launch_bounds__(256) void row_ratio16_kernel(const int32_t *__restr
     if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;  // (the select that follows may set it)
     __shared__ LogEntry s_lt[64];
     log_table_to_lds(s_lt);
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t step = (int64_t)gridDim.x * 256;
+    int32_t kn[16];  // the next row's counts are loaded before the current row is worked on
+    int64_t i = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 16; j++) kn[j] = (j < S && i < n) ? counts[(int64_t)j * n + i] : 1;
+    for (; i < n; i += step) {
         double l[16];
+        int32_t kc[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) kc[j] = kn[j];
+        if (i + step < n) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) kn[j] = j < S ? counts[(int64_t)j * n + i + step] : 1;
+        }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const int32_t k = j < S ? counts[(int64_t)j * n + i] : 1;
+            const int32_t k = kc[j];
             l[j] = k > 0 ? tlog((double)k, s_lt) : (k == 0 ? -INFINITY : NAN);  // log(0) = -Inf drops the row, as in R
         }
         double s = 0;
