@@ -834,6 +834,18 @@ __device__ __forceinline__ bool sel_key(const SelArgs &a, const FitScalars *sc, 
     return true;
 }
 
+// the element behind sel_key() as it sits in memory (NaN = excluded), and the key of a loaded element: the row loops below load
+// four elements before they work on the first, so that a thread has four loads in flight instead of one
+__device__ __forceinline__ double sel_raw(const SelArgs &a, int col, int64_t i) {
+    return a.mode == SEL_SIZEFACTOR ? a.ratio[(int64_t)col * a.n + i] : a.resid[i];
+}
+__device__ __forceinline__ bool sel_key_of_raw(const SelArgs &a, const FitScalars *sc, double x, uint64_t &key) {
+    if (x != x) return false;
+    if (a.mode == SEL_ABSDEV) x = fabs(x - sc->med);
+    key = key_of(x);
+    return true;
+}
+
 // histograms of the current digit for the two live prefixes of column blockIdx.y
 __global__ __launch_bounds__(256) void sel_hist_kernel(SelArgs a, FitWork w, int bits) {
     __shared__ unsigned int h[2][kSelBins];
@@ -853,18 +865,25 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(SelArgs a, FitWork w, int
     // equal digits at once (order-free sums: the histogram is the same).
     int cur = -1;
     unsigned cnt = 0;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
-        if (!sel_key(a, sc, col, i, key)) continue;
-        const unsigned dig = (unsigned)((key >> a.shift) & mask);
-        int bin;
-        if (sel_match(key, p0, hi)) bin = (int)dig;
-        else if (!same && sel_match(key, p1, hi)) bin = (int)(kSelBins + dig);
-        else continue;
-        if (bin == cur) cnt++;
-        else {
-            if (cnt) atomicAdd(&(&h[0][0])[cur], cnt);
-            cur = bin;
-            cnt = 1;
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < a.n; i0 += 4 * step) {
+        double x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = i0 + u * step < a.n ? sel_raw(a, col, i0 + u * step) : NAN;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // (a thread's elements in the order of the one-by-one loop: the same runs)
+            if (!sel_key_of_raw(a, sc, x[u], key)) continue;
+            const unsigned dig = (unsigned)((key >> a.shift) & mask);
+            int bin;
+            if (sel_match(key, p0, hi)) bin = (int)dig;
+            else if (!same && sel_match(key, p1, hi)) bin = (int)(kSelBins + dig);
+            else continue;
+            if (bin == cur) cnt++;
+            else {
+                if (cnt) atomicAdd(&(&h[0][0])[cur], cnt);
+                cur = bin;
+                cnt = 1;
+            }
         }
     }
     if (cnt) atomicAdd(&(&h[0][0])[cur], cnt);
@@ -943,14 +962,21 @@ __global__ __launch_bounds__(256) void sel_compact_kernel(SelArgs a, FitWork w) 
     const bool same = p0 == p1;
     uint64_t *cand = reinterpret_cast<uint64_t *>(w.hist) + (size_t)col * 2 * kSelCap;
     uint64_t key;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
-        if (!sel_key(a, sc, col, i, key)) continue;
-        int slot = -1;
-        if (sel_match(key, p0, 40)) slot = 0;
-        else if (!same && sel_match(key, p1, 40)) slot = 1;
-        if (slot < 0) continue;
-        const unsigned pos = atomicAdd(&sc->sel_cnt[2 * col + slot], 1u);
-        if (pos < (unsigned)kSelCap) cand[(size_t)slot * kSelCap + pos] = key;
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < a.n; i0 += 4 * step) {
+        double x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = i0 + u * step < a.n ? sel_raw(a, col, i0 + u * step) : NAN;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!sel_key_of_raw(a, sc, x[u], key)) continue;
+            int slot = -1;
+            if (sel_match(key, p0, 40)) slot = 0;
+            else if (!same && sel_match(key, p1, 40)) slot = 1;
+            if (slot < 0) continue;
+            const unsigned pos = atomicAdd(&sc->sel_cnt[2 * col + slot], 1u);
+            if (pos < (unsigned)kSelCap) cand[(size_t)slot * kSelCap + pos] = key;
+        }
     }
 }
 __device__ __forceinline__ void sel_tail_rounds(const SelArgs &a, FitScalars *sc, int col, unsigned int *h);
