@@ -451,7 +451,8 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
     const size_t selcnt = align256(sizeof(double) * (size_t)kSelMaxWorld * kMaxS * 2);
     const size_t rowpack = align256((size_t)row_stride(S) * (size_t)n);
-    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + 2 * hist + selcnt + align256(sizeof(FitScalars)) + kQueueBytes + 1024 + nfbytes + rowpack;
+    const size_t start4 = align256(sizeof(double) * 4 * (size_t)n);
+    const size_t total = nd * n_double_arrays + ni * n_int_arrays + partials + 2 * hist + selcnt + align256(sizeof(FitScalars)) + kQueueBytes + 1024 + nfbytes + rowpack + start4;
     hipError_t e = hipMalloc(&c->ws, total);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "workspace of %zu bytes: %s", total, hipGetErrorString(e));
     c->ws_bytes = total;
@@ -474,7 +475,8 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     w.queue = (unsigned long long *)p; p += kQueueBytes;
     w.barrier = (unsigned int *)p; p += 1024;
     c->d_nf_tmp = (double *)p; p += nfbytes;
-    w.rowpack = p;
+    w.rowpack = p; p += rowpack;
+    w.start = (double *)p;
     c->cap_n = n;
     c->cap_S = S;
     // scalars, queue heads and barrier counters start from zero: size_factors_impl runs before any fit has cleared them, and a
@@ -1522,7 +1524,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
     // opt_grid_lanes at once, each driven by its own host thread: one fit's straggler tail and its latency-bound
     // global steps (trend barriers, selects) overlap with the other fits' line searches.  Sharded: one after the other
     // (every rank must issue its collectives in the same order).
-    const size_t ws_per_lane = sizeof(double) * (size_t)n * (22 + S) + (size_t)row_stride(S) * (size_t)n + (64u << 20);
+    const size_t ws_per_lane = sizeof(double) * (size_t)n * (26 + S) + (size_t)row_stride(S) * (size_t)n + (64u << 20);
     int lanes = c->allreduce ? 1 : (ntheta < c->opt_grid_lanes ? ntheta : c->opt_grid_lanes);
     bool squeezed = false;  // the lanes' workspaces do not fit: their memory is given back before the thetas are fitted one after the other
     if (lanes > 1) {

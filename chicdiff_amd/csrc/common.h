@@ -27,6 +27,10 @@ struct FitWork {
     char *rowpack;                // row-major copy of the fit's inputs, row i at rowpack + i * row_stride(S): a 32-byte header (kRowHdr), nf[S]
                                   // doubles, counts[S] int32 (written by prep): the row-queue kernels visit rows out of order, and a row that
                                   // is 32 + 12 S contiguous bytes costs one or two cache lines instead of 2 S + 4
+    double *start;                // 4 doubles per row, dense: what the kernel that visits the rows next needs besides the record — gene-wise
+                                  // search: alpha_init, log alpha_init; MAP search: start value, prior mean; IRLS: alpha, row constant of the
+                                  // deviance, the two start values.  (Rounds 3-4 kept them in the second half of the record's header: 16-byte
+                                  // stores 128 bytes apart, which cost disp_init 50 of its 74 us at 2 M rows.)
     double *partials;             // kRedBlocks x 72 doubles
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
     double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut
@@ -39,9 +43,8 @@ struct FitWork {
 constexpr int kLogFactN = 1024;
 constexpr int kQueueBytes = 2048;  // FitWork::queue
 // bytes between rows of FitWork::rowpack: 12 S rounded up so that a row never straddles more 128-byte lines than it must
-constexpr int kRowHdr = 32;  // four doubles in front of every row: what the kernel that visits the rows next needs besides the data —
-                             // gene-wise search: group mean A, group mean B, alpha_init, log alpha_init; MAP search: the means, start
-                             // value, prior mean; IRLS: alpha, row constant of the deviance, the two start values
+constexpr int kRowHdr = 32;  // four doubles in front of every row: group mean A (its sign bit set: the row is all zero), group mean B, two
+                             // spare (the per-stage start values moved to FitWork::start)
 __host__ __device__ inline int64_t row_stride(int S) {
     const int64_t bytes = kRowHdr + (int64_t)S * 12;
     return bytes <= 64 ? 64 : (bytes + 127) / 128 * 128;

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
             const double moments = (cur.a - xim * bm) / (bm * bm);
             const double a0 = fmin(fmax(o.minDisp, fmin(cur.b, moments)), o.maxDisp);
             const double g0 = cur.g0, g1 = cur.g1;
-            reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, d.S))[1] = make_double2(a0, log(a0));  // what the search reads with the row (the means are there since prep)
+            reinterpret_cast<double2 *>(w.start)[2 * i] = make_double2(a0, log(a0));  // what the search reads with the row
             const int c = sched_class(a0, d.p == 2 ? fmin(g0, g1) : g0, o.minDisp);
             w.cls[i] = (uint8_t)c;
 #pragma unroll
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
             const double dg = cur.a, df = sc->trend_local ? cur.b : c0 + c1 / bm;
             const double ldf = log(df);
             w.dispFit[i] = df;
-            reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, d.S))[1] = make_double2(dg > 0.1 * df ? log(dg) : ldf, ldf);  // start value, prior mean
+            reinterpret_cast<double2 *>(w.start)[2 * i] = make_double2(dg > 0.1 * df ? log(dg) : ldf, ldf);  // start value, prior mean
             w.outlier[i] = log(dg) > ldf + out_thr;
         }
     }
@@ -450,18 +450,16 @@ __device__ __forceinline__ double max_num(double x, double m) {  // fmax() witho
     return r;
 }
 template <int Q>  // S = 4 Q
-__device__ __forceinline__ bool load_row_mu_fixed(const char *row, double *s_nf, int *s_y, int lane, uint64_t gmask, double minmu,
-                                                  double (&hdr)[4]) {
+__device__ __forceinline__ bool load_row_mu_fixed(const char *row, double *s_nf, int *s_y, int lane, uint64_t gmask, double minmu) {
     const double2 *p = reinterpret_cast<const double2 *>(row);
     const int4 *py = reinterpret_cast<const int4 *>(row + kRowHdr + 32 * Q);
-    const double2 h0 = p[0], h1 = p[1];
+    const double2 h0 = p[0];  // the two group means; sign bit of the first: all-zero row
     double2 f[2 * Q];
     int4 y[Q];
 #pragma unroll
     for (int k = 0; k < 2 * Q; k++) f[k] = p[2 + k];
 #pragma unroll
     for (int k = 0; k < Q; k++) y[k] = py[k];
-    hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
     // (no branch on the flag here: an all-zero row's values go to the lane's LDS column like any other's and are never used —
     // with a branch the compiler moves the loads behind it, i.e. behind the wait for the header.)  The sample's group is a bit
     // of a wave-uniform word; it is taken from a copy the compiler cannot see through, or it builds all S lane masks outside
@@ -480,15 +478,15 @@ __device__ __forceinline__ bool load_row_mu_fixed(const char *row, double *s_nf,
     }
     return __double2hiint(h0.x) >= 0;
 }
-__device__ __forceinline__ bool load_row_mu(const char *row, int S, double *s_nf, int *s_y, int lane, uint64_t gmask, double minmu,
-                                            double (&hdr)[4]) {
-    if (S == 8) return load_row_mu_fixed<2>(row, s_nf, s_y, lane, gmask, minmu, hdr);
-    if (S == 4) return load_row_mu_fixed<1>(row, s_nf, s_y, lane, gmask, minmu, hdr);
-    if (S == 16) return load_row_mu_fixed<4>(row, s_nf, s_y, lane, gmask, minmu, hdr);
-    if (S == 12) return load_row_mu_fixed<3>(row, s_nf, s_y, lane, gmask, minmu, hdr);
+__device__ __forceinline__ bool load_row_mu(const char *row, int S, double *s_nf, int *s_y, int lane, uint64_t gmask, double minmu) {
+    if (S == 8) return load_row_mu_fixed<2>(row, s_nf, s_y, lane, gmask, minmu);
+    if (S == 4) return load_row_mu_fixed<1>(row, s_nf, s_y, lane, gmask, minmu);
+    if (S == 16) return load_row_mu_fixed<4>(row, s_nf, s_y, lane, gmask, minmu);
+    if (S == 12) return load_row_mu_fixed<3>(row, s_nf, s_y, lane, gmask, minmu);
+    double hdr[2];
     {
-        const double2 h0 = reinterpret_cast<const double2 *>(row)[0], h1 = reinterpret_cast<const double2 *>(row)[1];
-        hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
+        const double2 h0 = reinterpret_cast<const double2 *>(row)[0];
+        hdr[0] = h0.x; hdr[1] = h0.y;
     }
     if (__double2hiint(hdr[0]) < 0) return false;
     const double *pf = reinterpret_cast<const double *>(row + kRowHdr);
@@ -929,14 +927,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             const int r = MAP ? (int)(chunk_base + chunk_pos + rank) : __shfl(ord_reg, (int)((chunk_pos + rank) & 63u));
             chunk_pos += take;
             if (phase == PH_NEED && rank < take) {
-                double hdr[4];
                 double dg = 0;
                 int ol = 0;
                 if (MAP) {
                     dg = A.w.dispGene[r];
                     ol = A.w.outlier[r];
                 }
-                if (!load_row_mu(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, o.minmu, hdr)) {
+                const double2 st = reinterpret_cast<const double2 *>(A.w.start)[2 * (int64_t)r];  // start values (disp_init_kernel)
+                if (!load_row_mu(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, o.minmu)) {
                     if (!MAP) {
                         A.w.dispGene[r] = NAN;
                         A.w.geneIter[r] = 0;
@@ -949,12 +947,12 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     }
                 } else {
                     row = r;
-                    if (!MAP) {  // start values come from disp_init_kernel
-                        a0 = hdr[2];
-                        a = hdr[3];
+                    if (!MAP) {
+                        a0 = st.x;
+                        a = st.y;
                     } else {
-                        a = hdr[2];
-                        prior_mean = hdr[3];
+                        a = st.x;
+                        prior_mean = st.y;
                         dgene = dg;
                         is_outlier = ol;
                     }
@@ -973,7 +971,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             pf_acc ^= pf_val;
             pf_val = 0;
             if (A.prefetch && (uint32_t)lane >= chunk_pos && (uint32_t)lane < chunk_len)
-                pf_val = *reinterpret_cast<const unsigned int *>(A.w.rowpack + (int64_t)ord_reg * rstride);
+                pf_val = *reinterpret_cast<const unsigned int *>(A.w.rowpack + (int64_t)ord_reg * rstride) ^
+                         *reinterpret_cast<const unsigned int *>(A.w.start + 4 * (int64_t)ord_reg);  // (the record's line and the start values')
         }
         DIAG(if (A.stamps && queue_empty && !stamped) {
             stamped = true;

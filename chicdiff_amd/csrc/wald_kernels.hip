@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
         w.binit0[i] = lA;
         w.binit1[i] = lB - lA;
         w.crow[i] = c;
-        double2 *h = reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, S));  // what the IRLS reads with the row
+        double2 *h = reinterpret_cast<double2 *>(w.start) + 2 * i;  // what the IRLS reads with the row
         h[0] = make_double2(alpha, c + cst);
         h[1] = make_double2(lA, lB - lA);
     }
@@ -141,18 +141,16 @@ __device__ __noinline__ bool optim_row(const int32_t *y_, const double *f_, int6
 // on the way.  As load_row_mu() of disp_kernels.hip: every 16-byte load of the record in flight before the first is used, the
 // all-zero flag read with the record (sign bit of the first header word: prep writes it, wald_prep leaves such rows' headers alone).
 template <int Q>  // S = 4 Q
-__device__ __forceinline__ bool load_row_sums_fixed(const char *row, double *s_nf, int *s_y, int lane, uint64_t gmask, double (&hdr)[4],
-                                                    int &iyA, int &iyB) {
+__device__ __forceinline__ bool load_row_sums_fixed(const char *row, double *s_nf, int *s_y, int lane, uint64_t gmask, int &iyA, int &iyB) {
     const double2 *p = reinterpret_cast<const double2 *>(row);
     const int4 *py = reinterpret_cast<const int4 *>(row + kRowHdr + 32 * Q);
-    const double2 h0 = p[0], h1 = p[1];
+    const double2 h0 = p[0];  // (sign bit of the first word: all-zero row)
     double2 f[2 * Q];
     int4 y[Q];
 #pragma unroll
     for (int k = 0; k < 2 * Q; k++) f[k] = p[2 + k];
 #pragma unroll
     for (int k = 0; k < Q; k++) y[k] = py[k];
-    hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
     uint32_t gbits = (uint32_t)gmask;
     asm volatile("" : "+s"(gbits));  // (a copy the compiler cannot see through: it would build all S lane masks outside the main loop)
 #pragma unroll
@@ -175,16 +173,12 @@ __device__ __forceinline__ bool load_row_sums_fixed(const char *row, double *s_n
     iyA = all - b;
     return __double2hiint(h0.x) >= 0;
 }
-__device__ __forceinline__ bool load_row_sums(const char *row, int S, double *s_nf, int *s_y, int lane, uint64_t gmask, double (&hdr)[4],
-                                              int &iyA, int &iyB) {
-    if (S == 8) return load_row_sums_fixed<2>(row, s_nf, s_y, lane, gmask, hdr, iyA, iyB);
-    if (S == 4) return load_row_sums_fixed<1>(row, s_nf, s_y, lane, gmask, hdr, iyA, iyB);
-    if (S == 16) return load_row_sums_fixed<4>(row, s_nf, s_y, lane, gmask, hdr, iyA, iyB);
-    if (S == 12) return load_row_sums_fixed<3>(row, s_nf, s_y, lane, gmask, hdr, iyA, iyB);
-    {
-        const double2 h0 = reinterpret_cast<const double2 *>(row)[0], h1 = reinterpret_cast<const double2 *>(row)[1];
-        hdr[0] = h0.x; hdr[1] = h0.y; hdr[2] = h1.x; hdr[3] = h1.y;
-    }
+__device__ __forceinline__ bool load_row_sums(const char *row, int S, double *s_nf, int *s_y, int lane, uint64_t gmask, int &iyA, int &iyB) {
+    if (S == 8) return load_row_sums_fixed<2>(row, s_nf, s_y, lane, gmask, iyA, iyB);
+    if (S == 4) return load_row_sums_fixed<1>(row, s_nf, s_y, lane, gmask, iyA, iyB);
+    if (S == 16) return load_row_sums_fixed<4>(row, s_nf, s_y, lane, gmask, iyA, iyB);
+    if (S == 12) return load_row_sums_fixed<3>(row, s_nf, s_y, lane, gmask, iyA, iyB);
+    const double h0x = reinterpret_cast<const double *>(row)[0];
     const double *pf = reinterpret_cast<const double *>(row + kRowHdr);
     const int *py = reinterpret_cast<const int *>(row + kRowHdr + 8 * S);
     int a = 0, b = 0;
@@ -196,7 +190,7 @@ __device__ __forceinline__ bool load_row_sums(const char *row, int S, double *s_
     }
     iyA = a;
     iyB = b;
-    return __double2hiint(hdr[0]) >= 0;
+    return __double2hiint(h0x) >= 0;
 }
 
 #ifdef CHICDIFF_DIAG
@@ -312,8 +306,9 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
             chunk_pos += take;
             if (need && !done && rank < take) {
                 int iyA = 0, iyB = 0;
-                double hdr[4];
-                if (!load_row_sums(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, hdr, iyA, iyB)) {
+                const double2 *stp = reinterpret_cast<const double2 *>(A.w.start) + 2 * (int64_t)r;  // (wald_prep_kernel)
+                const double2 st0 = stp[0], st1 = stp[1];
+                if (!load_row_sums(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, iyA, iyB)) {
                     A.w.beta0[r] = NAN;
                     A.w.beta1[r] = NAN;
                     A.w.betaIter[r] = 0;
@@ -321,11 +316,11 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                     row = r;
                     syA = (double)iyA;
                     syB = (double)iyB;
-                    alpha = hdr[0];
+                    alpha = st0.x;
                     size = 1.0 / alpha;
-                    crow = hdr[1];  // row constant + sum_j y_j (log alpha + log nf_j), from wald_prep
-                    b0 = hdr[2];
-                    b1 = hdr[3];
+                    crow = st0.y;  // row constant + sum_j y_j (log alpha + log nf_j), from wald_prep
+                    b0 = st1.x;
+                    b1 = st1.y;
                     k = 0;
                     dev_old = 0;
                     need = false;
