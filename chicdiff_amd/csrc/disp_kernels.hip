@@ -430,8 +430,10 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
             const double dg = cur.a, df = sc->trend_local ? cur.b : c0 + c1 / bm;
             const double ldf = log(df);
             w.dispFit[i] = df;
+            const int is_out = log(dg) > ldf + out_thr;
             reinterpret_cast<double2 *>(w.start)[2 * i] = make_double2(dg > 0.1 * df ? log(dg) : ldf, ldf);  // start value, prior mean
-            w.outlier[i] = log(dg) > ldf + out_thr;
+            reinterpret_cast<double2 *>(w.start)[2 * i + 1] = make_double2(dg, (double)is_out);  // ... and what the search hands through: the gene-wise estimate, the outlier flag
+            w.outlier[i] = is_out;
         }
     }
     if (!MAP && tile > 0) order_hist_store(mine, hist);
@@ -927,13 +929,11 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             const int r = MAP ? (int)(chunk_base + chunk_pos + rank) : __shfl(ord_reg, (int)((chunk_pos + rank) & 63u));
             chunk_pos += take;
             if (phase == PH_NEED && rank < take) {
-                double dg = 0;
-                int ol = 0;
-                if (MAP) {
-                    dg = A.w.dispGene[r];
-                    ol = A.w.outlier[r];
-                }
                 const double2 st = reinterpret_cast<const double2 *>(A.w.start)[2 * (int64_t)r];  // start values (disp_init_kernel)
+                double2 st1 = make_double2(0.0, 0.0);
+                if (MAP) st1 = reinterpret_cast<const double2 *>(A.w.start)[2 * (int64_t)r + 1];  // gene-wise estimate, outlier flag
+                const double dg = st1.x;
+                const int ol = st1.y != 0.0;
                 if (!load_row_mu(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, o.minmu)) {
                     if (!MAP) {
                         A.w.dispGene[r] = NAN;
