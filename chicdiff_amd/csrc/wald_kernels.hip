@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
     const int S = d.S;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         if (w.allZero[i]) {
+            reinterpret_cast<double2 *>(w.start)[2 * i] = make_double2(NAN, 0.0);  // alpha = NaN: how the IRLS learns that the row is all zero
             if (sched) {  // not scheduled (order_*): the IRLS kernel never sees the row
                 w.cls[i] = 255;
                 w.beta0[i] = NAN;
@@ -138,13 +139,12 @@ __device__ __noinline__ bool optim_row(const int32_t *y_, const double *f_, int6
 }
 
 // One row of FitWork::rowpack -> the lane's LDS column for the IRLS (offsets as they are), with the two groups' count sums formed
-// on the way.  As load_row_mu() of disp_kernels.hip: every 16-byte load of the record in flight before the first is used, the
-// all-zero flag read with the record (sign bit of the first header word: prep writes it, wald_prep leaves such rows' headers alone).
+// on the way.  As load_row_mu() of disp_kernels.hip: every 16-byte load of the record in flight before the first is used; whether the
+// row is all zero comes with the start values (alpha = NaN, wald_prep_kernel).
 template <int Q>  // S = 4 Q
-__device__ __forceinline__ bool load_row_sums_fixed(const char *row, double *s_nf, int *s_y, int lane, uint64_t gmask, int &iyA, int &iyB) {
+__device__ __forceinline__ void load_row_sums_fixed(const char *row, double *s_nf, int *s_y, int lane, uint64_t gmask, int &iyA, int &iyB) {
     const double2 *p = reinterpret_cast<const double2 *>(row);
     const int4 *py = reinterpret_cast<const int4 *>(row + kRowHdr + 32 * Q);
-    const double2 h0 = p[0];  // (sign bit of the first word: all-zero row)
     double2 f[2 * Q];
     int4 y[Q];
 #pragma unroll
@@ -171,14 +171,12 @@ __device__ __forceinline__ bool load_row_sums_fixed(const char *row, double *s_n
     }
     iyB = b;
     iyA = all - b;
-    return __double2hiint(h0.x) >= 0;
 }
-__device__ __forceinline__ bool load_row_sums(const char *row, int S, double *s_nf, int *s_y, int lane, uint64_t gmask, int &iyA, int &iyB) {
+__device__ __forceinline__ void load_row_sums(const char *row, int S, double *s_nf, int *s_y, int lane, uint64_t gmask, int &iyA, int &iyB) {
     if (S == 8) return load_row_sums_fixed<2>(row, s_nf, s_y, lane, gmask, iyA, iyB);
     if (S == 4) return load_row_sums_fixed<1>(row, s_nf, s_y, lane, gmask, iyA, iyB);
     if (S == 16) return load_row_sums_fixed<4>(row, s_nf, s_y, lane, gmask, iyA, iyB);
     if (S == 12) return load_row_sums_fixed<3>(row, s_nf, s_y, lane, gmask, iyA, iyB);
-    const double h0x = reinterpret_cast<const double *>(row)[0];
     const double *pf = reinterpret_cast<const double *>(row + kRowHdr);
     const int *py = reinterpret_cast<const int *>(row + kRowHdr + 8 * S);
     int a = 0, b = 0;
@@ -190,7 +188,6 @@ __device__ __forceinline__ bool load_row_sums(const char *row, int S, double *s_
     }
     iyA = a;
     iyB = b;
-    return __double2hiint(h0x) >= 0;
 }
 
 #ifdef CHICDIFF_DIAG
@@ -308,7 +305,8 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                 int iyA = 0, iyB = 0;
                 const double2 *stp = reinterpret_cast<const double2 *>(A.w.start) + 2 * (int64_t)r;  // (wald_prep_kernel)
                 const double2 st0 = stp[0], st1 = stp[1];
-                if (!load_row_sums(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, iyA, iyB)) {
+                load_row_sums(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, iyA, iyB);
+                if (st0.x != st0.x) {  // alpha = NaN: an all-zero row (wald_prep_kernel); its values in the lane's LDS column are never used
                     A.w.beta0[r] = NAN;
                     A.w.beta1[r] = NAN;
                     A.w.betaIter[r] = 0;
