@@ -1618,6 +1618,32 @@ def test_independent_filtering_edge_cases(ctx):
     check(bm1, p, "constant baseMean")
 
 
+def test_row_queue_kernels_at_the_edges_of_their_chunks(ctx, oracle):
+    """The line searches and the IRLS hand rows to lanes in chunks of 64 schedule entries (the static deal in groups of 1-8 entries
+    per wave, 64 lanes per wave): fits of 1 .. 200 rows — fewer rows than a wave has lanes, exactly one chunk, one row more,
+    two chunks and a row — under a pinned trend and prior (so that a handful of rows cannot derail the global steps) against
+    the oracle under the same pins: every row within 1e-6 or refereed, whatever the schedule option."""
+    from chicdiff_amd import hip
+    S = 8
+    big = synth.make(4000, S)
+    pins = dict(trendCoef=(0.06, 2.5), dispPriorVar=0.4)
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 200):
+        # take rows with counts: an all-zero row alone has nothing to fit
+        keep = np.flatnonzero(big["counts"].sum(1) > 0)[:n]
+        d = {"counts": np.ascontiguousarray(big["counts"][keep]), "nf": np.ascontiguousarray(big["nf"][keep]), "group": big["group"]}
+        ref = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], **pins)
+        for sched in (1, 0):
+            ctx.set_option("line_search_schedule", sched)
+            try:
+                got, sc = run_fit(ctx, d, d["group"], **pins)
+            finally:
+                ctx.set_option("line_search_schedule", 1)
+            assert np.array_equal(got["allZero"], ref["allZero"]) and not got["allZero"].any()
+            for k in ("dispGeneEst", "dispMAP", "dispersion", "log2FoldChange", "pvalue"):
+                assert not np.any(np.isnan(got[k])), (n, sched, k)
+            assert_rows_explained(f"{n} rows, schedule {sched}", oracle, d, d["group"], got, ref, pins["dispPriorVar"])
+
+
 def test_fit_fuzz_shapes_and_designs(ctx, oracle):
     """Random sample counts, group splits and row counts (both designs) against the oracle: every configuration must
     agree on the NA pattern and on every row (within the bounds, or refereed: explain_fit)."""
