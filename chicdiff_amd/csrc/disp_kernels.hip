@@ -327,25 +327,37 @@ __global__ __launch_bounds__(256) void order_hist_kernel(const uint8_t *__restri
 __global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t *__restrict__ cls, int64_t n, int64_t tile,
                                                             const unsigned int *__restrict__ hist, int32_t *__restrict__ order,
                                                             FitScalars *sc, int classesA) {
-    __shared__ unsigned long long s_red[4];
     __shared__ unsigned long long s_base[kSchedClasses + 1];
     __shared__ unsigned int s_wcnt[4][kSchedClasses];
     const int nblk = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // s_base[c] = number of schedule entries before this block's class-c rows; s_base[6] (block 0 only): totals
-    for (int c = 0; c <= kSchedClasses + 1; c++) {
-        // c <= 5: prefix up to (c, this block); c == 6: start of class kSchedClassesA (= |A|); c == 7: everything
-        const int target = c < kSchedClasses ? c * nblk + (int)blockIdx.x : (c == kSchedClasses ? classesA * nblk : kSchedClasses * nblk);
-        if (c >= kSchedClasses && blockIdx.x != 0) break;
-        unsigned long long part = 0;
-        for (int e = threadIdx.x; e < target; e += 256) part += hist[e];
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
-        if (lane == 0) s_red[wave] = part;
+    // s_base[c] = number of schedule entries before this block's class-c rows = the sum of hist[0 .. c nblk + blockIdx.x); block 0
+    // also leaves |A| = sum of hist[0 .. classesA nblk) and the total.  ONE pass over the 6 nblk counts for all eight sums (round 4;
+    // before: a pass, a shuffle tree and two workgroup barriers per sum — half of the kernel's 20 us at 1024 tiles).
+    {
+        unsigned long long part[kSchedClasses + 2] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int total = kSchedClasses * nblk, cutA = classesA * nblk;
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const unsigned long long hv = hist[e];
+#pragma unroll
+            for (int c = 0; c < kSchedClasses; c++) part[c] += e < c * nblk + (int)blockIdx.x ? hv : 0ull;
+            part[kSchedClasses] += e < cutA ? hv : 0ull;
+            part[kSchedClasses + 1] += hv;
+        }
+        __shared__ unsigned long long s_part[4][kSchedClasses + 2];
+#pragma unroll
+        for (int c = 0; c < kSchedClasses + 2; c++) {
+            unsigned long long v = part[c];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0) s_part[wave][c] = v;
+        }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-            if (c < kSchedClasses) s_base[c] = tot;
-            else if (c == kSchedClasses) sc->ord_na = (int64_t)tot;
-            else sc->ord_n = (int64_t)tot;
+        if (threadIdx.x < kSchedClasses + 2) {
+            const unsigned long long tot = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+            if (threadIdx.x < kSchedClasses) s_base[threadIdx.x] = tot;
+            else if (blockIdx.x == 0) {
+                if (threadIdx.x == kSchedClasses) sc->ord_na = (int64_t)tot;
+                else sc->ord_n = (int64_t)tot;
+            }
         }
         __syncthreads();
     }
