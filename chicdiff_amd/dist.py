@@ -50,6 +50,9 @@ def theta_grid_replicas(ctx, d_counts, d_fullmean, size_factors, thetas, group=N
     import torch
     import torch.distributed as dist
 
+    if getattr(ctx, "_sharded", False):
+        raise ValueError("theta_grid_replicas needs a context WITHOUT a process group (its fits are complete, every rank holds all rows); "
+                         "on a sharded context call ctx.theta_grid: the grid's fits then run one after the other, each sharded")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     thetas = [float(t) for t in thetas]
     mine = theta_replica_plan(len(thetas), world)[rank]

@@ -232,6 +232,7 @@ class HipContext:
         from .dist import AllReduceHook
 
         self._hook = AllReduceHook(group, memory=memory, device=self.device)
+        self._sharded = True  # (from here on the context's fits are pieces of a sharded fit: dist.theta_grid_replicas refuses it)
         self._check(self.lib.chicdiff_hip_set_allreduce(self.h, self._hook.fn, None, self._hook.world, self._hook.rank))
         if allgather:
             self._check(self.lib.chicdiff_hip_set_allgather(self.h, self._hook.gather_fn, None))
@@ -273,6 +274,7 @@ class HipContext:
             self.lib.chicdiff_hip_set_allreduce(self.h, C.cast(None, ALLREDUCE_FN), None, 1, 0)
             raise ChicdiffHipError(f"ncclCommInitRank did not succeed on every rank ({msg or 'another rank failed'})")
         self._hook = None
+        self._sharded = True
 
     def to_device(self, a, dtype):
         """(n, S) host array -> (S, n) contiguous device tensor (sample-major)."""

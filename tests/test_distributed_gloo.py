@@ -257,6 +257,11 @@ def test_theta_grid_replicas_every_point_once_and_every_total_everywhere():
     from chicdiff_amd.dist import theta_replica_plan
     assert theta_replica_plan(5, 2) == [[0, 2, 4], [1, 3]] and theta_replica_plan(5, 8) == [[0], [1], [2], [3], [4], [], [], []]
     assert theta_replica_plan(5, 1) == [[0, 1, 2, 3, 4]]
+    from chicdiff_amd.dist import theta_grid_replicas
+    sharded = _StubGrid()
+    sharded._sharded = True  # what HipContext.set_process_group / init_rccl leave behind
+    with pytest.raises(ValueError, match="WITHOUT a process group"):
+        theta_grid_replicas(sharded, None, None, [1.0], [0.0, 1.0])
     ctx = mp.get_context("spawn")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
