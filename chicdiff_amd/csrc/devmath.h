@@ -196,6 +196,39 @@ __device__ __forceinline__ LgrCtx lgr_make(double r) {
     c.lP = c.nr ? flog(P) : 0.0;
     return c;
 }
+// the same two with the table-driven logarithms of the fit kernels (LDS table `lt`): ~30 instructions less per sample in wald_prep
+// and wald_intercept, whose every lane runs BOTH branches of lgr_eval (a wave holds small and large counts)
+__device__ __forceinline__ LgrCtx lgr_make_t(double r, const LogEntry *lt) {
+    LgrCtx c;
+    c.r = r;
+    c.nr = r < 10.0 ? (int)ceil(10.0 - r) : 0;
+    double P = 1.0, zz = r;
+    for (int i = 0; i < c.nr; i++) {
+        P *= zz;
+        zz += 1.0;
+    }
+    c.z0 = r + (double)c.nr;
+    c.iz0 = rcp(c.z0);
+    c.lz0m1 = tlog(c.z0, lt) - 1.0;
+    c.tail0 = lg_tail(c.iz0);
+    c.lP = c.nr ? tlog(P, lt) : 0.0;
+    return c;
+}
+__device__ __forceinline__ double lgr_eval_t(const LgrCtx &c, int yi, const LogEntry *lt) {
+    if (yi >= c.nr) {
+        const double d = (double)(yi - c.nr);
+        const double z = c.z0 + d;
+        const double u = d * c.iz0, t = 1.0 + u;
+        const double l1p = tlog1p_from(u, t, rcp(t), lt);
+        return c.lP + fma(z - 0.5, l1p, d * c.lz0m1) + (lg_tail(rcp(z)) - c.tail0);
+    }
+    double P = 1.0, zz = c.r;
+    for (int i = 0; i < yi; i++) {
+        P *= zz;
+        zz += 1.0;
+    }
+    return tlog(P, lt);
+}
 // the context of r = 1, i.e. log(y!) = lgr_eval(lgr_one(), y)
 __device__ __forceinline__ LgrCtx lgr_one() {
     LgrCtx c;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
             const double gmin = fmin(w.gm0[i], w.gm1[i]);
             w.cls[i] = gmin < 0.5 ? 0 : (gmin < 1.0 ? 1 : ((gmin < 2.0 || alpha > 1.5) ? 2 : 3));
         }
-        const LgrCtx cs = lgr_make(rcp(alpha)), c1 = lgr_one();
+        const LgrCtx cs = lgr_make_t(rcp(alpha), s_lt), c1 = lgr_one();
         double lA = 0, lB = 0, c = 0, cst = 0;
         int yi_next = counts[i];
         double nf_next = nf[i];
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
             if ((d.gmask >> j) & 1) lB += l; else lA += l;
             if (yi > 0) {
                 // lgamma(y+size) - lgamma(size) - lgamma(y+1): the mu-independent part of log dnbinom
-                c += lgr_eval(cs, yi) - (yi < kLogFactN ? s_logfact[yi] : lgr_eval(c1, yi));
+                c += lgr_eval_t(cs, yi, s_lt) - (yi < kLogFactN ? s_logfact[yi] : lgr_eval(c1, yi));
                 // sum_j y_j (log alpha + log nf_j): with mu = nf e^eta the rest of sum_j y_j log(alpha mu_j) is
                 // eta_A sum_A y + eta_B sum_B y, so the IRLS ticks need no log(mu)
                 cst = fma((double)yi, la + tlog(nfj, s_lt), cst);
@@ -726,14 +726,14 @@ __global__ __launch_bounds__(256) void wald_intercept_kernel(const int32_t *__re
             bm /= S;
             B0 = log2(bm);
             const double e = exp2(B0);
-            const LgrCtx cs = lgr_make(size), c1 = lgr_one();
+            const LgrCtx cs = lgr_make_t(size, s_lt), c1 = lgr_one();
             const double la = tlog(alpha, s_lt);
             double ll = 0, xtwx = 0;
             auto sample = [&](double nfj, int yi) {
                 const double mu = nfj * e;
                 const double y = (double)yi, ma = alpha * mu, t = 1.0 + ma, rt = rcp(t);
                 ll -= (size + y) * tlog1p_from(ma, t, rt, s_lt);
-                if (yi > 0) ll += lgr_eval(cs, yi) - (yi < kLogFactN ? s_logfact[yi] : lgr_eval(c1, yi)) + y * (la + tlog(mu, s_lt));
+                if (yi > 0) ll += lgr_eval_t(cs, yi, s_lt) - (yi < kLogFactN ? s_logfact[yi] : lgr_eval(c1, yi)) + y * (la + tlog(mu, s_lt));
                 xtwx += mu * rt;
             };
             if (S <= 16) {
