@@ -192,7 +192,7 @@ __device__ __forceinline__ void load_row_sums(const char *row, int S, double *s_
 
 #ifdef CHICDIFF_DIAG
 #define WDIAG(...) __VA_ARGS__
-__device__ unsigned long long g_irls_cy[8];  // s_memtime cycles summed over all waves: refill / evaluate / rest / ticks, while the queue has rows and after
+__device__ unsigned long long g_irls_cy[8], g_irls_open[2];  // s_memtime cycles summed over all waves: refill / evaluate / rest / ticks, while the queue has rows and after
 #else
 #define WDIAG(...)
 #endif
@@ -252,14 +252,15 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
     int k = 0;
     double b0 = 0, b1 = 0, alpha = 0, size = 0, crow = 0, dev_old = 0, syA = 0, syB = 0;
 
-    WDIAG(unsigned long long cyw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_eval_end = 0;)
+    WDIAG(unsigned long long cyw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_eval_end = 0, wr_load_end = 0, g_open_cy = 0, g_open_n = 0;)
     for (;;) {
-        WDIAG(const int sec = queue_empty ? 4 : 0; const unsigned long long wt0 = __builtin_amdgcn_s_memtime();)
+        WDIAG(const int sec = 0; const bool sec_bulk = !queue_empty; const unsigned long long wt0 = __builtin_amdgcn_s_memtime();)
         // refill (the scheme of disp_fit_kernel's: scalar chunk bookkeeping, a chunk's schedule entries read once and handed out by
         // lane permute, the all-zero flag and the whole record in one round trip)
         unsigned long long needmask = __ballot(need && !done);
 #pragma unroll 1
         for (int attempt = 0; needmask != 0ull && attempt < 4; attempt++) {
+            WDIAG(const unsigned long long wo0 = __builtin_amdgcn_s_memtime(); const bool opened = chunk_pos >= chunk_len;)
             if (chunk_pos >= chunk_len) {  // the lanes' entries are used up ...
                 if (rest_base >= rest_end) {  // ... and nothing left of the last dequeue: one atomic per A.chunk rows
                     if (queue_empty) {
@@ -296,16 +297,19 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                 ord_reg = (int)b + lane;
                 if (order && (uint32_t)lane < chunk_len) ord_reg = order[b + lane];
             }
+            WDIAG(if (opened && !queue_empty) { g_open_cy += __builtin_amdgcn_s_memtime() - wo0; g_open_n++; })
             const uint32_t cnt = (uint32_t)__popcll(needmask), avail = chunk_len - chunk_pos;
             const uint32_t take = cnt < avail ? cnt : avail;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(needmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needmask, 0u));
             const int r = __shfl(ord_reg, (int)((chunk_pos + rank) & 63u));
             chunk_pos += take;
+            WDIAG(const unsigned long long wr0 = __builtin_amdgcn_s_memtime();)
             if (need && !done && rank < take) {
                 int iyA = 0, iyB = 0;
                 const double2 *stp = reinterpret_cast<const double2 *>(A.w.start) + 2 * (int64_t)r;  // (wald_prep_kernel)
                 const double2 st0 = stp[0], st1 = stp[1];
                 load_row_sums(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, iyA, iyB);
+                WDIAG(const unsigned long long wr1 = __builtin_amdgcn_s_memtime(); if (!queue_empty) { cyw[4] += wr0 - wt0; cyw[5] += wr1 - wr0; cyw[7]++; } wr_load_end = wr1;)
                 if (st0.x != st0.x) {  // alpha = NaN: an all-zero row (wald_prep_kernel); its values in the lane's LDS column are never used
                     A.w.beta0[r] = NAN;
                     A.w.beta1[r] = NAN;
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                 }
             }
             needmask = __ballot(need && !done);
+            WDIAG(if (wr_load_end) { if (!queue_empty) cyw[6] += __builtin_amdgcn_s_memtime() - wr_load_end; wr_load_end = 0; })
         }
         if (__ballot(!done) == 0ull) break;
         WDIAG(const unsigned long long wt1 = __builtin_amdgcn_s_memtime();)
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
                     Dc = fma(-y, de, Dc);  // log mu_j = log nf_j + eta_group + de
                 }
             }
-            WDIAG(const unsigned long long wt2 = __builtin_amdgcn_s_memtime(); cyw[sec + 0] += wt1 - wt0; cyw[sec + 1] += wt2 - wt1; cyw[sec + 3]++; wt_eval_end = wt2;)
+            WDIAG(const unsigned long long wt2 = __builtin_amdgcn_s_memtime(); if (sec_bulk) { cyw[sec + 0] += wt1 - wt0; cyw[sec + 1] += wt2 - wt1; cyw[sec + 3]++; wt_eval_end = wt2; })
             const double zA = fma(etaA - 1.0, wA, uA) + zcA, zB = fma(etaB - 1.0, wB, uB) + zcB;
             const double D = (Dl - fma(etaA, syA, etaB * syB)) + Dc;  // `crow` carries the per-row constant
             bool stop = false;
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(256, WALD_MINW) void wald_irls_kernel(WaldArgs A) {
         }
         WDIAG(if (wt_eval_end) { cyw[sec + 2] += __builtin_amdgcn_s_memtime() - wt_eval_end; wt_eval_end = 0; })
     }
-    WDIAG(if (lane == 0) for (int q = 0; q < 8; q++) atomicAdd(&g_irls_cy[q], cyw[q]);)
+    WDIAG(if (lane == 0) { for (int q = 0; q < 8; q++) atomicAdd(&g_irls_cy[q], cyw[q]); atomicAdd(&g_irls_open[0], g_open_cy); atomicAdd(&g_irls_open[1], g_open_n); })
 }
 
 // (Measured and dropped, round 2: the same IRLS with the row held in registers — exec-masked refill loads, 64-row chunks,
@@ -833,6 +838,7 @@ void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWor
     if (stamps) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_irls_cy), z, sizeof z);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_irls_open), z, 16);
     }
 #endif
     wald_irls_kernel<<<(unsigned)blocks, threads, lds, st>>>(A);
@@ -841,10 +847,15 @@ void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWor
         (void)hipStreamSynchronize(st);
         unsigned long long h[8];
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_irls_cy), sizeof h);
-        for (int q = 0; q < 2; q++) {
-            const double t = h[4 * q + 3] ? (double)h[4 * q + 3] : 1.0;
-            printf("  IRLS ticks %s: %.0f per wave; s_memtime cycles per tick: refill %.0f, evaluate %.0f, solve + state %.0f\n",
-                   q ? "after the queue ran dry" : "while the queue has rows", t / (double)(blocks * (threads / 64)), h[4 * q] / t, h[4 * q + 1] / t, h[4 * q + 2] / t);
+        {
+            const double t = h[3] ? (double)h[3] : 1.0, r = h[7] ? (double)h[7] : 1.0;
+            printf("  IRLS ticks while the queue has rows (lane 0 of every wave): %.0f per wave; s_memtime cycles per tick: refill %.0f, evaluate %.0f, solve + state %.0f\n",
+                   t / (double)(blocks * (threads / 64)), h[0] / t, h[1] / t, h[2] / t);
+            unsigned long long ho[2];
+            (void)hipMemcpyFromSymbol(ho, HIP_SYMBOL(g_irls_open), sizeof ho);
+            printf("    pieces of the schedule opened: %.1f per wave, %.0f cycles each\n", (double)ho[1] / (double)(blocks * (threads / 64)), ho[1] ? (double)ho[0] / (double)ho[1] : 0.0);
+            printf("    inside a refill that lane 0 took part in (%.0f per wave): tick start -> loads issued %.0f, loads issued -> row in LDS %.0f, -> end of the attempt %.0f cycles\n",
+                   r / (double)(blocks * (threads / 64)), h[4] / r, h[5] / r, h[6] / r);
         }
     }
 #endif
