@@ -1263,7 +1263,10 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     // start late (S = 4: LDS would allow 10 waves per CU, the registers allow 8; 200 k x 4 went from 0.57 to 0.72 ms)
     const int waves_per_block = threads / 64;
     int64_t blocks_per_cu = (int64_t)(160 * 1024 / (lds > 0 ? lds : 1));
-    const int64_t by_regs = (int64_t)(4 * (o.min_waves >= 2 && o.min_waves <= 4 ? o.min_waves : 2)) / waves_per_block;
+    // the 168-register build (three waves per SIMD) pays where LDS lets a third wave in and the launch has no static deal: the MAP
+    // search at S <= 4 (ten waves per CU: 0.73 -> 0.68 ms at 2 M x 4; the gene-wise launch loses 7 % with it, round 4)
+    const int min_waves = (map && o.min_waves == 2 && d.S <= 4) ? 3 : (o.min_waves >= 2 && o.min_waves <= 4 ? o.min_waves : 2);
+    const int64_t by_regs = (int64_t)(4 * min_waves) / waves_per_block;
     if (blocks_per_cu > by_regs) blocks_per_cu = by_regs;
     if (blocks_per_cu > 8) blocks_per_cu = 8;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -1278,7 +1281,7 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
         (void)hipMemsetAsync(A.stamps, 0, stamp_words * 8, st);
     }
 #endif
-    const int variant = o.min_waves;
+    const int variant = min_waves;
 #define LAUNCH(M, W) disp_fit_kernel<M, W><<<(unsigned)blocks, threads, lds, st>>>(A)
     if (map) {
         if (variant >= 4) LAUNCH(true, 4); else if (variant == 3) LAUNCH(true, 3); else LAUNCH(true, 2);
