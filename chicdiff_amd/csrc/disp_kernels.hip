@@ -533,7 +533,7 @@ struct DispArgs {
 #endif
 #ifdef CHICDIFF_DIAG
 #define DIAG(...) __VA_ARGS__
-constexpr int kStampSlots = 29;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
+constexpr int kStampSlots = 33;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
 #else
 #define DIAG(...)
 #endif
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     uint32_t deal = A.deal > 0 ? (uint32_t)A.deal : nA / (4u * nwaves);
     deal = deal < 1 ? 1 : (deal > (uint32_t)kSchedDeal ? (uint32_t)kSchedDeal : deal);
     DIAG(const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;)
-    DIAG(unsigned long long cy_sp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_t6 = 0; bool sp_on = false; unsigned long long cy_ev[4] = {0, 0, 0, 0}; unsigned long long cy_sec[5] = {0, 0, 0, 0, 0}; bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
+    DIAG(unsigned long long rej_spread = 0, srch_spread = 0, rej_bulk = 0, srch_bulk = 0; unsigned long long cy_sp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_t6 = 0; bool sp_on = false; unsigned long long cy_ev[4] = {0, 0, 0, 0}; unsigned long long cy_sec[5] = {0, 0, 0, 0, 0}; bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
          if (A.stamps && lane == 0) A.stamps[gwave * kStampSlots + 0] = __builtin_amdgcn_s_memrealtime();)
 
     for (;;) {
@@ -1133,7 +1133,9 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                 }
             } else {
                 kappa *= 0.5;
+                DIAG(if (lg_t >= 0) rej_spread++; else if (!queue_empty) rej_bulk++;)
             }
+            DIAG(if (lg_t >= 0) srch_spread++; else if (!queue_empty) srch_bulk++;)
             if (!finished && iter >= o.maxit) finished = true;
             if (finished) {
                 bool grid;
@@ -1216,6 +1218,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         for (int q = 0; q < 5; q++) A.stamps[gwave * kStampSlots + 11 + q] = cy_sec[q];
         for (int q = 0; q < 4; q++) A.stamps[gwave * kStampSlots + 16 + q] = cy_ev[q];
         for (int q = 0; q < 9; q++) A.stamps[gwave * kStampSlots + 20 + q] = cy_sp[q];
+    })
+    DIAG({  // rejected / all line-search steps, summed over the wave's lanes: in samples-across-lanes ticks, in bulk ticks
+        unsigned long long v4[4] = {rej_spread, srch_spread, rej_bulk, srch_bulk};
+        for (int q = 0; q < 4; q++) {
+            unsigned long long x = v4[q];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if (A.stamps && lane == 0) A.stamps[gwave * kStampSlots + 29 + q] = x;
+        }
     })
 }
 

@@ -17,7 +17,7 @@ dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64
 ctx.nbglm_fit(dk, dn, d["group"])
 raw = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64)
 pos = 0
-K = 29
+K = 33
 while pos < len(raw):
     kind, nw = int(raw[pos]), int(raw[pos + 1]); pos += 2
     st = raw[pos:pos + nw * K].reshape(nw, K).astype(np.int64); pos += nw * K
@@ -56,3 +56,5 @@ while pos < len(raw):
     nsp = max(sp[:, 7].sum(), 1)
     print("    samples-across-lanes ticks (%d per wave), cycles per tick: tick start -> evaluate %.0f | owner walk %.0f, row constants %.0f, prefix + sample + exchange store %.0f, fold %.0f, finish %.0f, pick-up %.0f | evaluate end -> tick end %.0f" % (
         nsp / max(qe.sum(), 1), sp[:, 6].sum() / nsp, *(sp[:, :6].sum(0) / nsp), sp[:, 8].sum() / nsp))
+    rj = st[:, 29:33].astype(float).sum(0)
+    print("    line-search steps rejected (Armijo): %.1f %% of %d in samples-across-lanes ticks, %.1f %% of %d in bulk ticks" % (100 * rj[0] / max(rj[1], 1), rj[1], 100 * rj[2] / max(rj[3], 1), rj[3]))
