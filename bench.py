@@ -155,7 +155,7 @@ def theta_grid_replicas_time(hip, synth, torch, dist, local_rank, n_global, S):
             t0 = time.perf_counter()
             theta_grid_replicas(c2, dk, dfm, sf, grid)
             torch.cuda.synchronize()
-            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if "nccl" in str(dist.get_backend()) else "cpu")
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             ts.append(float(dt.item()) * 1e3)
         world = dist.get_world_size()

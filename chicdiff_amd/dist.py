@@ -61,9 +61,9 @@ def theta_grid_replicas(ctx, d_counts, d_fullmean, size_factors, thetas, group=N
         part[mine] = ctx.theta_grid(d_counts, d_fullmean, size_factors, [thetas[k] for k in mine], opts=opts)
     # every point is fitted by exactly one rank: gather the ranks' vectors and pick each point from its owner (a sum of zero-filled
     # vectors would do as well, but a NaN total — a region with zero counts in every sample — must arrive as NaN, not poison the rest)
-    backend = dist.get_backend(group)
+    backend = str(dist.get_backend(group))
     t = torch.from_numpy(part)
-    if backend == "nccl":
+    if "nccl" in backend and getattr(d_counts, "is_cuda", False):  # (a mixed "cpu:gloo,cuda:nccl" group carries device tensors over RCCL)
         t = t.to(d_counts.device)
     got = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(got, t, group=group)
