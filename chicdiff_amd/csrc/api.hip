@@ -167,7 +167,7 @@ void chicdiff_hip_default_opts(chicdiff_nbglm_opts *o) {
 int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return CHICDIFF_E_INVALID;
     const std::string k(name);
-    if (k == "line_search_spread" && (value == 0 || value == 1)) c->opt_spread = (int)value;
+    if (k == "line_search_spread" && value >= 0 && value <= 2) c->opt_spread = (int)value;  // 2: samples across lanes without the lean tick of the launch's end (bit-identity tests)
     else if (k == "line_search_min_waves" && value >= 2 && value <= 4) c->opt_min_waves = (int)value;
     else if (k == "line_search_schedule" && (value == 0 || value == 1)) c->opt_schedule = (int)value;
     else if (k == "line_search_deal" && value >= 0 && value <= 64) c->opt_deal = (int)value;

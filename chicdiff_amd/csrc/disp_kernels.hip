@@ -533,7 +533,7 @@ struct DispArgs {
 #endif
 #ifdef CHICDIFF_DIAG
 #define DIAG(...) __VA_ARGS__
-constexpr int kStampSlots = 33;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
+constexpr int kStampSlots = 34;  // start, queue-empty, exit (s_memrealtime), live rows at queue-empty, ticks after queue-empty: row-per-lane / spread / burst, all ticks, s_memtime cycles after queue-empty in row / spread / burst ticks, spare
 #else
 #define DIAG(...)
 #endif
@@ -709,16 +709,22 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
 // Gain at 2 M rows: 1 % of the gene-wise launch at S = 8, 4 % at S = 4, 10 % at S = 16.
 // (Measured and dropped: handing the stragglers to a second, densely packed launch — a wave's tick takes
 // ~5 us alone or with a neighbour on its SIMD, the tail is bound by the ~130 serial ticks, not by issue.)
-__device__ __forceinline__ void eval_point_spread(const double *s_nf, const int *s_y, double *s_x, int lane, int S, int lg, uint64_t gmask,
-                                                  bool p2, unsigned long long actmask, bool active, double a_eval,
-                                                  bool use_prior, double prior_mean, double prior_isig,
-                                                  double &lp, double &dlp, double &alpha_out, const LogEntry *lt, const ExpEntry *et
-                                                  DIAG(, unsigned long long *tm)) {
-    DIAG(tm[0] = __builtin_amdgcn_s_memtime();)
-    // lanes per row L = 2^lg: one sample per lane when L >= S (at most 64 / L rows), else samples jj, jj + L, ... per lane — the
-    // layout also serves 9 .. 32 live rows (S = 8: four or two lanes per row), where a row-per-lane tick would still walk all S
-    // samples in every lane
-    const int L = 1 << lg, grp = lane >> lg, jj = lane & (L - 1), R = 64 >> lg;
+// Which lanes evaluate which live row in a samples-across-lanes tick.  It depends only on the set of live lanes (and, for the MAP
+// search, on the rows' prior means), so the launch's end — tick after tick with the same few rows — builds it once per change of
+// that set (round 5) instead of once per tick.
+struct SpreadMap {
+    unsigned long long mask;  // the live lanes it was built for
+    int lg;                   // log2(lanes per row); -1: the rows do not fit (row-per-lane tick)
+    int owner;                // the lane whose LDS column holds this lane's row
+    int src;                  // first lane of the group that evaluates this lane's own row (live lanes)
+    bool has;                 // this lane's group has a row
+    double pm_o;              // the row's prior mean (MAP)
+};
+__device__ __forceinline__ SpreadMap spread_map(double *s_x, int lane, int lg, unsigned long long actmask, bool active, bool use_prior, double prior_mean) {
+    SpreadMap m;
+    m.mask = actmask;
+    m.lg = lg;
+    const int grp = lane >> lg;
     // owner of group g = the g-th live lane: every live lane leaves its number at its rank among the live lanes, group g reads entry
     // g (one LDS round trip instead of a walk over the set bits: ~50 instructions per tick of a launch's latency-bound end)
     const int nact = __popcll(actmask);
@@ -728,12 +734,29 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const bool has = grp < nact;
-    const int owner = has ? s_own[grp] : 0;
+    m.has = grp < nact;
+    m.owner = m.has ? s_own[grp] : 0;
+    m.src = (active ? myrank : 0) << lg;  // an active lane's group is its rank among the active lanes
+    m.pm_o = use_prior ? __shfl(prior_mean, m.owner) : 0.0;
+    return m;
+}
+__device__ __forceinline__ void eval_point_spread(const double *s_nf, const int *s_y, double *s_x, int lane, int S, const SpreadMap &map, uint64_t gmask,
+                                                  bool p2, double a_eval,
+                                                  bool use_prior, double prior_isig,
+                                                  double &lp, double &dlp, double &alpha_out, const LogEntry *lt, const ExpEntry *et
+                                                  DIAG(, unsigned long long *tm)) {
+    DIAG(tm[0] = __builtin_amdgcn_s_memtime();)
+    // lanes per row L = 2^lg: one sample per lane when L >= S (at most 64 / L rows), else samples jj, jj + L, ... per lane — the
+    // layout also serves 9 .. 32 live rows (S = 8: four or two lanes per row), where a row-per-lane tick would still walk all S
+    // samples in every lane
+    const int lg = map.lg;
+    const int L = 1 << lg, grp = lane >> lg, jj = lane & (L - 1), R = 64 >> lg;
+    const bool has = map.has;
+    const int owner = map.owner;
     MARK("spread:owner_walk_end");
     DIAG(tm[1] = __builtin_amdgcn_s_memtime();)
     const double a_o = __shfl(a_eval, owner);
-    const double pm_o = use_prior ? __shfl(prior_mean, owner) : 0.0;
+    const double pm_o = map.pm_o;
     const RowConsts c = row_consts(a_o, lt, et);
     MARK("spread:row_consts_end");
     DIAG(tm[2] = __builtin_amdgcn_s_memtime();)
@@ -794,8 +817,7 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
     finish_point(acc, c, p2, use_prior, pm_o, prior_isig, lp_g, dlp_g, lt);
     MARK("spread:finish_end");
     DIAG(tm[5] = __builtin_amdgcn_s_memtime();)
-    // an active lane's group is its rank among the active lanes
-    const int src = (active ? myrank : 0) << lg;
+    const int src = map.src;
     lp = __shfl(lp_g, src);
     dlp = __shfl(dlp_g, src);
     alpha_out = __shfl(c.alpha, src);
@@ -865,10 +887,139 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     uint32_t deal = A.deal > 0 ? (uint32_t)A.deal : nA / (4u * nwaves);
     deal = deal < 1 ? 1 : (deal > (uint32_t)kSchedDeal ? (uint32_t)kSchedDeal : deal);
     DIAG(const int gwave = blockIdx.x * (blockDim.x >> 6) + wave;)
-    DIAG(unsigned long long rej_spread = 0, srch_spread = 0, rej_bulk = 0, srch_bulk = 0; unsigned long long cy_sp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_t6 = 0; bool sp_on = false; unsigned long long cy_ev[4] = {0, 0, 0, 0}; unsigned long long cy_sec[5] = {0, 0, 0, 0, 0}; bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
+    DIAG(unsigned long long tk_lean = 0; unsigned long long rej_spread = 0, srch_spread = 0, rej_bulk = 0, srch_bulk = 0; unsigned long long cy_sp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_t6 = 0; bool sp_on = false; unsigned long long cy_ev[4] = {0, 0, 0, 0}; unsigned long long cy_sec[5] = {0, 0, 0, 0, 0}; bool stamped = false; unsigned long long tk_row = 0, tk_spread = 0, tk_burst = 0, tk_all = 0, cy_row = 0, cy_spread = 0, cy_burst = 0, cy_last = 0; int tk_kind = -1;
          if (A.stamps && lane == 0) A.stamps[gwave * kStampSlots + 0] = __builtin_amdgcn_s_memrealtime();)
 
+    // the line search of this lane's row is over: its result, or the grid fallback (A2.7 / A4)
+    auto search_over = [&](double &result, bool &have_result) {
+        bool grid;
+        if (!MAP) {
+            double dd = fmin(alpha_cur, o.maxDisp);
+            if (lp < init_lp + fabs(init_lp) / 1e6) dd = a0;  // noIncrease: keep alpha_init
+            const bool conv = (iter < o.maxit) && (iter != 1);
+            grid = !conv && dd > o.minDisp * 10;
+            result = dd;
+        } else {
+            grid = !(iter < o.maxit);
+            result = alpha_cur;
+        }
+        if (grid) {
+            phase = PH_GRID1;
+            gt = 0;
+            gbest = -INFINITY;
+            gbi = 0;
+        } else {
+            have_result = true;
+        }
+    };
+    auto store_result = [&](double result) {
+        const double dd = fmin(fmax(result, o.minDisp), o.maxDisp);
+        if (!MAP) {
+            A.w.dispGene[row] = dd;
+            A.w.geneIter[row] = iter;
+        } else {
+            A.w.dispMAP[row] = dd;
+            A.w.disp[row] = is_outlier ? dgene : dd;
+            A.w.mapIter[row] = iter;
+        }
+    };
+    const bool lean_on = A.spread == 1;  // (option line_search_spread = 2: samples across lanes, but every tick through the general path)
+    SpreadMap lmap;
+    lmap.mask = 0ull;
+    lmap.lg = -1;
+    lmap.owner = lmap.src = 0;
+    lmap.has = false;
+    lmap.pm_o = 0.0;
+
     for (;;) {
+        // ---- lean tick of the launch's end (round 5) -----------------------------------------------------------------------
+        // Once the queue is empty a wave is left with a few rows that creep along a flat likelihood for ~100 evaluations, one per
+        // tick, in the samples-across-lanes layout: the launch's last 0.3-0.4 ms ARE that chain (250 k x 8: queue empty at 0.13 ms,
+        // last wave out at 0.53), and a wave alone on its SIMD issues one instruction per ~8 cycles whatever it is — the tick costs
+        // what it has instructions.  Of the ~870 of a general tick more than 400 were not evaluation but the tick's frame: the
+        // refill's ballots and branches, the choice of the point and the state machine for all six phases behind divergent
+        // branches, the grid-burst test, the owner look-up.  When every live lane of the wave is inside its line search — nine
+        // ticks in ten — none of that is needed: the step, the evaluation, and the Armijo / stop update written with selects; the
+        // lane map is rebuilt only when the set of live lanes changes; whatever is rare (a clamped step, a search that ends) sits
+        // behind a wave-uniform branch.  Same operations on the same operands in the same order as the general tick: same bits
+        // (test_line_search_layouts_agree_bit_for_bit runs both).
+        if (lean_on && queue_empty && chunk_pos >= chunk_len && spread_lg >= 0) {
+            const unsigned long long srch = __ballot(phase == PH_SEARCH);
+            if (srch != 0ull && __ballot(phase != PH_SEARCH && phase != PH_DONE) == 0ull) {
+                const bool active = phase == PH_SEARCH;
+                if (srch != lmap.mask) {
+                    const int nact = __popcll(srch), lg_min = spread_lg - 2 > 1 ? spread_lg - 2 : 1;
+                    int lg_t = spread_lg;
+                    while (lg_t >= lg_min && (nact << lg_t) > 64) lg_t--;
+                    if (lg_t < lg_min) {
+                        lmap.mask = srch;
+                        lmap.lg = -1;
+                    } else {
+                        lmap = spread_map(s_tab, lane, lg_t, srch, active, MAP, prior_mean);
+                    }
+                }
+                if (lmap.lg >= 0) {
+                    DIAG({
+                        const unsigned long long now = __builtin_amdgcn_s_memtime();
+                        if (tk_kind == 0) cy_row += now - cy_last; else if (tk_kind == 1) cy_spread += now - cy_last; else if (tk_kind == 2) cy_burst += now - cy_last;
+                        cy_last = now;
+                        tk_all++;
+                        tk_spread++;
+                        tk_lean++;
+                        tk_kind = 1;
+                    })
+                    MARK("lean:begin");
+                    DIAG(const unsigned long long lean_t0 = __builtin_amdgcn_s_memtime();)
+                    iter += active ? 1 : 0;
+                    const double a_prop = a + kappa * dlp;
+                    if (__ballot(active && (a_prop < -30.0 || a_prop > 10.0)) != 0ull) {  // (rare: the step leaves [-30, 10])
+                        if (a_prop < -30.0) kappa = (-30.0 - a) / dlp;
+                        if (a_prop > 10.0) kappa = (10.0 - a) / dlp;
+                    }
+                    a_new = a + kappa * dlp;
+                    double l_new = 0, dl_new = 0, alpha_new = 0;
+                    DIAG(unsigned long long tms[7];)
+                    MARK("lean:eval_begin");
+                    eval_point_spread(s_nf, s_y, s_tab, lane, S, lmap, gmask, p2, a_new, MAP, prior_isig, l_new, dl_new, alpha_new, s_logtab, s_exptab DIAG(, tms));
+                    // Armijo test and stop rules of the general tick's PH_SEARCH branch, as selects
+                    MARK("lean:eval_end");
+                    const double theta_kappa = -l_new;
+                    const double theta_hat_kappa = -lp - kappa * 1.0e-4 * dlp * dlp;
+                    const bool acc = active && theta_kappa <= theta_hat_kappa;
+                    const double change = l_new - lp;
+                    const bool fin_tol = acc && change < o.dispTol;
+                    const bool fin_low = acc && !fin_tol && a_new < min_log_alpha;
+                    const bool go_on = acc && !fin_tol && !fin_low;
+                    iacc += acc ? 1 : 0;
+                    a = acc ? a_new : a;
+                    alpha_cur = acc ? alpha_new : alpha_cur;
+                    lp = (acc && !fin_low) ? l_new : lp;
+                    dlp = go_on ? dl_new : dlp;
+                    DIAG(if (active && !acc) rej_spread++; if (active) srch_spread++;)
+                    {
+                        double k_acc = fmin(kappa * 1.1, o.kappa0);
+                        if (iacc % 5 == 0) k_acc *= 0.5;
+                        kappa = go_on ? k_acc : ((active && !acc) ? kappa * 0.5 : kappa);
+                    }
+                    const bool finished = active && (fin_tol || fin_low || iter >= o.maxit);
+                    MARK("lean:update_end");
+                    if (__ballot(finished) != 0ull) {
+                        if (finished) {
+                            double result = 0;
+                            bool have_result = false;
+                            search_over(result, have_result);
+                            if (have_result) {
+                                store_result(result);
+                                phase = PH_DONE;  // (the queue is empty: what the refill makes of PH_NEED)
+                            }
+                        }
+                    }
+                    MARK("lean:end");
+                    DIAG(for (int q = 0; q < 6; q++) cy_sp[q] += tms[q + 1] - tms[q]; cy_sp[6] += tms[0] - lean_t0; cy_sp[7]++; cy_sp[8] += __builtin_amdgcn_s_memtime() - tms[6];)
+                    continue;
+                }
+            }
+        }
         MARK("tick:begin");
         DIAG(const bool sec_on = !queue_empty; const unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();)
         // ---- refill: lanes without a row pull the next ones from the queue -----------------
@@ -1070,8 +1221,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         DIAG(const unsigned long long sec_t2 = __builtin_amdgcn_s_memtime();)
         if (lg_t >= 0) {
             DIAG(unsigned long long tms[7];)
-            eval_point_spread(s_nf, s_y, s_tab, lane, S, lg_t, gmask, p2, actmask, active, a_eval, MAP,
-                              prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab, s_exptab DIAG(, tms));
+            const SpreadMap map = spread_map(s_tab, lane, lg_t, actmask, active, MAP, prior_mean);
+            eval_point_spread(s_nf, s_y, s_tab, lane, S, map, gmask, p2, a_eval, MAP, prior_isig, l_new, dl_new, alpha_new, s_logtab, s_exptab DIAG(, tms));
             DIAG(for (int q = 0; q < 6; q++) cy_sp[q] += tms[q + 1] - tms[q]; cy_sp[6] += tms[0] - sec_t0; cy_sp[7]++; sp_t6 = tms[6]; sp_on = true;)
         } else if (active || helper) {
             DIAG(unsigned long long tm[5];)
@@ -1137,27 +1288,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
             DIAG(if (lg_t >= 0) srch_spread++; else if (!queue_empty) srch_bulk++;)
             if (!finished && iter >= o.maxit) finished = true;
-            if (finished) {
-                bool grid;
-                if (!MAP) {
-                    double dd = fmin(alpha_cur, o.maxDisp);
-                    if (lp < init_lp + fabs(init_lp) / 1e6) dd = a0;  // noIncrease: keep alpha_init
-                    const bool conv = (iter < o.maxit) && (iter != 1);
-                    grid = !conv && dd > o.minDisp * 10;
-                    result = dd;
-                } else {
-                    grid = !(iter < o.maxit);
-                    result = alpha_cur;
-                }
-                if (grid) {
-                    phase = PH_GRID1;
-                    gt = 0;
-                    gbest = -INFINITY;
-                    gbi = 0;
-                } else {
-                    have_result = true;
-                }
-            }
+            if (finished) search_over(result, have_result);
         } else if (phase == PH_GRID1 || phase == PH_GRID2) {
             if (burst_done) {  // points gt .. gt+nhelp at once; an earlier point keeps a tie (strict >, as one by one)
                 if (l_new > gbest) {
@@ -1187,15 +1318,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
         }
         if (have_result) {
-            const double dd = fmin(fmax(result, o.minDisp), o.maxDisp);
-            if (!MAP) {
-                A.w.dispGene[row] = dd;
-                A.w.geneIter[row] = iter;
-            } else {
-                A.w.dispMAP[row] = dd;
-                A.w.disp[row] = is_outlier ? dgene : dd;
-                A.w.mapIter[row] = iter;
-            }
+            store_result(result);
             phase = PH_NEED;
         }
         MARK("tick:state_machine_end");
@@ -1218,6 +1341,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         for (int q = 0; q < 5; q++) A.stamps[gwave * kStampSlots + 11 + q] = cy_sec[q];
         for (int q = 0; q < 4; q++) A.stamps[gwave * kStampSlots + 16 + q] = cy_ev[q];
         for (int q = 0; q < 9; q++) A.stamps[gwave * kStampSlots + 20 + q] = cy_sp[q];
+        A.stamps[gwave * kStampSlots + 33] = tk_lean;
     })
     DIAG({  // rejected / all line-search steps, summed over the wave's lanes: in samples-across-lanes ticks, in bulk ticks
         unsigned long long v4[4] = {rej_spread, srch_spread, rej_bulk, srch_bulk};

@@ -34,14 +34,27 @@ def _compare(got, gold, sc_got, sc):
     if "dispFit" in got:
         assert np.allclose(got["dispFit"][nz], gold["dispFit"][nz], rtol=1e-6), "dispFit"
     assert np.isclose(sc_got["dispPriorVar"], float(sc["dispPriorVar"]), rtol=1e-9), (sc_got["dispPriorVar"], sc["dispPriorVar"])
+    # EVERY non-all-zero row by the bounds of tests/test_gpu_parity.py::assert_rows_explained — dispersion to 1e-6, log2FoldChange to
+    # 1e-6 * max(|lfc|, 1e-2), p to 1e-6 * max(1, z^2) — with the rows outside printed, not waved through: DESIGN.md section 3
+    # expects ~ 1 row in 1e5 to stop on a decision inside rounding noise, and against DESeq2 itself there is no referee to side
+    # with — the list is what a maintainer with R then looks at.
+    z2 = np.maximum(1.0, np.nan_to_num(gold["stat"][nz] if "stat" in gold else np.zeros(int(nz.sum()))) ** 2)
+    failed = []
     for k, g in (("dispersion", "dispersion"), ("log2FoldChange", "log2FoldChange"), ("pvalue", "waldPvalue")):
         if g not in gold:
             continue
         a, b = got[k][nz], gold[g][nz]
-        ok = np.isfinite(b) & (np.abs(b) > 1e-3 if k == "log2FoldChange" else True)
-        rel = np.abs(a[ok] - b[ok]) / np.maximum(np.abs(b[ok]), 1e-300)
-        print(f"{k} vs DESeq2: max rel {rel.max():.3e}, within 1e-6: {np.mean(rel <= 1e-6):.6f}")
-        assert np.mean(rel <= 1e-6) >= 0.999, k
+        scale = {"dispersion": np.abs(b), "log2FoldChange": np.maximum(np.abs(b), 1e-2), "pvalue": np.abs(b) * z2}[k]
+        ok = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), ok), (k, "NA pattern")
+        err = np.abs(a[ok] - b[ok]) / np.maximum(scale[ok], 1e-300)
+        off = np.flatnonzero(err > 1e-6)
+        print(f"{k} vs DESeq2: max scaled error {err.max():.3e}, rows outside 1e-6: {len(off)} of {int(ok.sum())}")
+        for i in off[:50]:
+            print(f"   row {np.flatnonzero(nz)[np.flatnonzero(ok)[i]]}: got {a[ok][i]!r} DESeq2 {b[ok][i]!r} (scaled error {err[i]:.3e})")
+        if len(off):
+            failed.append((k, len(off)))
+    assert not failed, failed
 
 
 @pytest.mark.skipif(not _cases(), reason="no DESeq2 goldens (tools/make_golden.R needs R + DESeq2; absent here): parity vs DESeq2 itself stays unpinned")

@@ -601,6 +601,17 @@ def test_fragment_background(ctx, oracle):
 FULL_WANT = ["log2FoldChange", "intercept", "pvalue", "stat", "dispersion", "dispGeneEst", "dispMAP", "dispFit", "dispOutlier", "dispIter", "betaConv", "betaIter"]
 
 
+def neither_side_right(gpu, ora, arb, floor=1e-6):
+    """Rows of a refereed list on which NEITHER double-precision search ends where the binary128 one does.  A side counts as
+    right when it is within 1e-6 of the referee, or when it and the referee both sit at or below the trend's floor
+    (100 * minDisp = 1e-6): DESeq2 keeps such a row out of the trend fit and out of the MAD (estimateDispersionsFit, reached from
+    chicdiff.R:1573), starts its MAP search from the fitted value and never calls it an outlier — where below the floor the
+    gene-wise estimate lies changes nothing downstream (round 4's one case: row 1244683 of 2 M x 8, GPU 1.12e-8, referee 1e-8)."""
+    gpu, ora, arb = (np.asarray(x, dtype=float) for x in (gpu, ora, arb))
+    right = lambda x: (rel(x, arb) <= 1e-6) | ((x <= floor) & (arb <= floor))
+    return ~right(gpu) & ~right(ora)
+
+
 def assert_rows_explained(tag, oracle, d, group, got, ref, dispPriorVar, maxit=100, gene_listed=None):
     """Full-size comparison of two fits that share their global scalars (trend, prior variance): EVERY non-all-zero row
     must agree — dispersion to 1e-6, log2FoldChange to 1e-6 * max(|lfc|, 1e-2), p to 1e-6 * max(1, z^2) (a relative change
@@ -621,7 +632,8 @@ def assert_rows_explained(tag, oracle, d, group, got, ref, dispPriorVar, maxit=1
     if gene_listed is None:
         arb = oracle.arbitrate_disp(d["counts"], d["nf"], group, gene_off, ref) if len(gene_off) else np.empty(0)
         eg, eo = rel(got["dispGeneEst"][gene_off], arb), rel(ref["dispGeneEst"][gene_off], arb)
-        assert int(((eg > 1e-6) & (eo > 1e-6)).sum()) <= 2, (tag, "gene-wise rows neither side gets right", gene_off[(eg > 1e-6) & (eo > 1e-6)])
+        nb = neither_side_right(got["dispGeneEst"][gene_off], ref["dispGeneEst"][gene_off], arb)
+        assert not nb.any(), (tag, "gene-wise rows neither side gets right", gene_off[nb])
         listed += [dict(row=int(i), kind="gene", gpu=float(got["dispGeneEst"][i]), oracle=float(ref["dispGeneEst"][i]), referee=float(a))
                    for i, a in zip(gene_off, arb)]
     else:
@@ -782,7 +794,10 @@ def test_full_size_2Mx8_against_oracle_and_permutation(ctx, oracle):
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(dict(n=n, S=S, rows_compared=int(live.sum()), disagreeing_rows=table, gpu_matches_arbiter=gpu_right,
                    oracle_matches_arbiter=ora_right, neither=neither), open("gpurun_out/arbiter_2Mx8.json", "w"), indent=1)
-    assert neither <= 2  # a row both double-precision paths miss would be a systematic error, not rounding noise
+    # a row both double-precision paths miss would be a systematic error, not rounding noise (neither_side_right: within 1e-6 of the
+    # referee, or below the trend's 1e-6 floor together with it)
+    nb = neither_side_right(got["dispGeneEst"][bad], ref["dispGeneEst"][bad], arb)
+    assert not nb.any(), ("gene-wise rows neither side gets right", bad[nb])
     # (2) trend | gene-wise estimates
     useg = (ref["allZero"] == 0) & (got["dispGeneEst"] > 1e-6)
     cg, itg, rc = oracle.parametric_dispersion_fit(ref["baseMean"][useg], got["dispGeneEst"][useg])
@@ -1001,6 +1016,11 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
         c = run()
     finally:
         ctx.set_option("line_search_spread", 1)
+    ctx.set_option("line_search_spread", 2)  # samples across lanes, but every tick of the launch's end through the general tick (no lean tick)
+    try:
+        g = run()
+    finally:
+        ctx.set_option("line_search_spread", 1)
     ctx.set_option("line_search_schedule", 0)  # natural row order through the queue instead of likely-long rows first
     try:
         e = run()
@@ -1024,6 +1044,7 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), f"{k}: two runs differ"
         assert np.array_equal(a[k], c[k], equal_nan=True), f"{k}: layouts differ in {np.sum(~((a[k] == c[k]) | (np.isnan(a[k]) & np.isnan(c[k]))))} rows"
+        assert np.array_equal(a[k], g[k], equal_nan=True), f"{k}: lean and general ticks differ in {np.sum(~((a[k] == g[k]) | (np.isnan(a[k]) & np.isnan(g[k]))))} rows"
         assert np.array_equal(a[k], e[k], equal_nan=True), f"{k}: schedules differ in {np.sum(~((a[k] == e[k]) | (np.isnan(a[k]) & np.isnan(e[k]))))} rows"
 
 

@@ -17,7 +17,7 @@ dk, dn = ctx.to_device(d["counts"], np.int32), ctx.to_device(d["nf"], np.float64
 ctx.nbglm_fit(dk, dn, d["group"])
 raw = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64)
 pos = 0
-K = 33
+K = 34
 while pos < len(raw):
     kind, nw = int(raw[pos]), int(raw[pos + 1]); pos += 2
     st = raw[pos:pos + nw * K].reshape(nw, K).astype(np.int64); pos += nw * K
