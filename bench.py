@@ -134,13 +134,15 @@ def theta_grid_time(ctx, torch, dk, dfm, S):
     return {"ms": round(float(np.median(ts)), 3), "thetas": len(grid), "runs_ms": [round(t, 3) for t in ts]}
 
 
-def theta_grid_replicas_time(hip, synth, torch, dist, local_rank, n_global, S):
+def theta_grid_replicas_time(hip, synth, torch, dist, local_rank, n_global, S, share_gpu=False):
     """a8 with N > 1 ranks as a REPLICA problem (chicdiff_amd.dist.theta_grid_replicas): every rank holds all `n_global` rows on
     its own GPU in a context WITHOUT a process group, fits its share of the 5 grid points, one all-gather of 5 doubles follows.
     Wall clock between barriers, max over ranks."""
     from chicdiff_amd.dist import theta_grid_replicas, theta_replica_plan
     c2 = hip.HipContext(local_rank)
     try:
+        if share_gpu and dist.get_world_size() > 1:  # one-GPU rehearsal: every rank's persistent trend kernel must be resident at once
+            c2.set_option("trend_persistent_blocks", max(1, 256 // dist.get_world_size()))
         d = synth.make(n_global, S)
         dk = c2.to_device(d["counts"], np.int32)
         dfm = c2.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)
@@ -160,7 +162,7 @@ def theta_grid_replicas_time(hip, synth, torch, dist, local_rank, n_global, S):
             ts.append(float(dt.item()) * 1e3)
         world = dist.get_world_size()
         return {"ms": round(float(np.median(ts)), 3), "thetas": len(grid), "runs_ms": [round(t, 3) for t in ts], "rows_per_rank": n_global,
-                "points_per_rank": [len(x) for x in theta_replica_plan(len(grid), world)],
+                "points_per_rank": [len(x) for x in theta_replica_plan(len(grid), world)], "refits_last_call": c2.last_refits(),
                 "what": "every rank holds all rows and fits theta k for k = rank mod world; one all-gather of 5 doubles (max over ranks)"}
     finally:
         c2.close()
@@ -388,7 +390,7 @@ def main():
                                    "ms_per_step": round(mo["elapsed"] / args.steps * 1e3, 3), "rows_per_gpu": mo["n"], "global_rows": mo["n_global"],
                                    "steps": args.steps, "warmup": args.warmup}
     if world > 1 and not args.no_hbm_kernels:  # (every rank takes part; rank 0 reports)
-        result["theta_grid_replicas"] = theta_grid_replicas_time(hip, synth, torch, dist, local_rank, args.rows, S)
+        result["theta_grid_replicas"] = theta_grid_replicas_time(hip, synth, torch, dist, local_rank, args.rows, S, share_gpu)
     if rank == 0 and world == 1 and not args.no_hbm_kernels:
         result["hbm_kernels"] = hbm_kernels(ctx, torch, n, S)
         result["theta_grid"] = theta_grid_time(ctx, torch, dk, dfm, S)

@@ -15,6 +15,7 @@
 #include <thread>
 #include <string>
 #include <vector>
+#include <unordered_set>
 
 #include <dlfcn.h>
 
@@ -115,6 +116,10 @@ struct chicdiff_hip_ctx {
     std::vector<std::pair<int, hipEvent_t>> pending;
     std::vector<hipEvent_t> event_pool;  // recycled: creating events per launch cost ~0.9 ms per step
     int scope_depth = 0;                 // nested scopes are folded into the outermost one
+    // chicdiff_hip_malloc: the caller's device vectors, so that destroying the context releases what its host forgot or could not
+    // release any more (R runs the finalizers of one garbage collection in no particular order: a context can go before its vectors)
+    std::unordered_set<void *> user_allocs;
+    std::mutex user_mu;
 };
 
 static char g_create_err[512];
@@ -230,6 +235,8 @@ void chicdiff_hip_destroy(chicdiff_hip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     delete c->chin;
+    for (void *p : c->user_allocs) (void)hipFree(p);
+    c->user_allocs.clear();
     if (c->io_dev) (void)hipFree(c->io_dev);
     if (c->io_pin) (void)hipHostFree(c->io_pin);
     for (auto *l : c->lanes) chicdiff_hip_destroy(l);
@@ -288,12 +295,16 @@ static int rccl_open(chicdiff_hip_ctx *c, const char *path) {
     c->rccl_lib = h;
     return CHICDIFF_OK;
 }
+// what the library's own RCCL callbacks return after a failure: the message is in c->err already (a host callback returns any other
+// non-zero value and gets the generic text — round 4 told the two apart by looking for "nccl" in c->err, which a stale message
+// from an earlier call satisfied just as well: ADVICE r04)
+constexpr int kCollMsgSet = 0x7e57;
 static int rccl_allreduce_cb(void *user, void *dev_buf, int64_t count) {
     chicdiff_hip_ctx *c = (chicdiff_hip_ctx *)user;
     const int r = c->rccl_allreduce(dev_buf, dev_buf, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->rccl_comm, c->stream);
     if (r != 0) {
         fail(c, CHICDIFF_E_COMM, "ncclAllReduce: %s", c->rccl_error_string ? c->rccl_error_string(r) : "error");
-        return 1;
+        return kCollMsgSet;
     }
     return 0;
 }
@@ -302,7 +313,7 @@ static int rccl_allgather_cb(void *user, const void *dev_send, void *dev_recv, i
     const int r = c->rccl_allgather(dev_send, dev_recv, (size_t)count, /*ncclFloat64*/ 8, c->rccl_comm, c->stream);
     if (r != 0) {
         fail(c, CHICDIFF_E_COMM, "ncclAllGather: %s", c->rccl_error_string ? c->rccl_error_string(r) : "error");
-        return 1;
+        return kCollMsgSet;
     }
     return 0;
 }
@@ -542,7 +553,7 @@ static int do_allreduce(chicdiff_hip_ctx *c, double *dev, int64_t count) {
         CollTimer t(c, "allreduce", 8.0 * (double)count);
         rc = c->allreduce(c->allreduce_user, dev, count);
     }
-    if (rc != 0) return c->err[0] && strstr(c->err, "nccl") ? CHICDIFF_E_COMM : fail(c, CHICDIFF_E_COMM, "all-reduce callback failed");
+    if (rc != 0) return rc == kCollMsgSet && c->allreduce == rccl_allreduce_cb ? CHICDIFF_E_COMM : fail(c, CHICDIFF_E_COMM, "all-reduce callback failed");
     return CHICDIFF_OK;
 }
 // every rank contributes `count` doubles at `send`; `recv` gets world x count, rank r's block at r * count
@@ -552,7 +563,7 @@ static int do_allgather(chicdiff_hip_ctx *c, const double *send, double *recv, i
         CollTimer t(c, "allgather", 8.0 * (double)count);
         rc = c->allgather(c->allgather_user, send, recv, count);
     }
-    if (rc != 0) return c->err[0] && strstr(c->err, "nccl") ? CHICDIFF_E_COMM : fail(c, CHICDIFF_E_COMM, "all-gather callback failed");
+    if (rc != 0) return rc == kCollMsgSet && c->allgather == rccl_allgather_cb ? CHICDIFF_E_COMM : fail(c, CHICDIFF_E_COMM, "all-gather callback failed");
     return CHICDIFF_OK;
 }
 
@@ -1557,7 +1568,13 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
             for (chicdiff_hip_ctx *l : c->lanes) chicdiff_hip_destroy(l);
             c->lanes.clear();
         }
-        if ((rc = ensure_workspace(c, n, S))) return rc;
+        rc = ensure_workspace(c, n, S);
+        if (rc == CHICDIFF_E_NOMEM && !c->lanes.empty()) {  // the cached lanes hold whole workspaces of their own: give them up and try once more
+            for (chicdiff_hip_ctx *l : c->lanes) chicdiff_hip_destroy(l);
+            c->lanes.clear();
+            rc = ensure_workspace(c, n, S);
+        }
+        if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(c->d_carry, 0, sizeof(int32_t), c->stream));  // no size-factor select belongs to this call
         HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
         for (int t = 0; t < ntheta; t++) {
@@ -1895,15 +1912,26 @@ extern "C" int chicdiff_hip_malloc(chicdiff_hip_ctx *c, uint64_t bytes, void **d
     HIPCHK(c, hipSetDevice(c->device));
     hipError_t e = hipMalloc(d_ptr, bytes ? (size_t)bytes : 1);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_NOMEM, "device allocation of %llu bytes: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(c->user_mu);
+    c->user_allocs.insert(*d_ptr);
     return CHICDIFF_OK;
 }
 extern "C" int chicdiff_hip_free(chicdiff_hip_ctx *c, void *d_ptr) {
     if (!c) return CHICDIFF_E_INVALID;
     if (!d_ptr) return CHICDIFF_OK;
+    {
+        std::lock_guard<std::mutex> lock(c->user_mu);
+        if (!c->user_allocs.erase(d_ptr)) return fail(c, CHICDIFF_E_INVALID, "chicdiff_hip_free: not an allocation of this context (or freed already)");
+    }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(d_ptr));
     return CHICDIFF_OK;
+}
+extern "C" int64_t chicdiff_hip_outstanding_allocations(chicdiff_hip_ctx *c) {
+    if (!c) return -1;
+    std::lock_guard<std::mutex> lock(c->user_mu);
+    return (int64_t)c->user_allocs.size();
 }
 extern "C" int chicdiff_hip_memcpy_h2d(chicdiff_hip_ctx *c, void *d_dst, const void *h_src, uint64_t bytes) {
     if (!c || (bytes && (!d_dst || !h_src))) return c ? fail(c, CHICDIFF_E_INVALID, "memcpy_h2d: NULL pointer") : CHICDIFF_E_INVALID;

@@ -44,9 +44,15 @@ def theta_grid_replicas(ctx, d_counts, d_fullmean, size_factors, thetas, group=N
     With world >= len(thetas) the grid costs one fit instead of len(thetas).
 
     `ctx` must be a context WITHOUT a process group attached (its fits are complete, nothing is sharded); the fits are the ones
-    `ctx.theta_grid` makes, so the totals are bit for bit those of the single-process grid.  The alternative when rows ARE
-    sharded — len(thetas) sharded fits one after the other on a context with `set_process_group` — needs no copy of the rows and
-    is what `DESeq2Wrap` uses; this function is for callers whose ranks hold the whole interaction set."""
+    `ctx.theta_grid` makes.  A rank that fits ONE point runs the single-launch trend kernel (with the MAD of the residuals in the
+    same launch), a single-process grid of several points runs its fits side by side with the trend as one launch per pass: the
+    same sums in another order, so the totals agree with the single-process grid's to the trend's summation order (~1e-13
+    relative; tests/test_gpu_sharded.py asserts 1e-10), not bit for bit.  The alternative when rows ARE sharded — len(thetas)
+    sharded fits one after the other on a context with `set_process_group` — needs no copy of the rows and is what `DESeq2Wrap`
+    uses; this function is for callers whose ranks hold the whole interaction set.
+
+    A fit that fails on ONE rank must not leave the others inside the all-gather: the local exception is caught, a status flag
+    travels with the totals, and every rank raises."""
     import torch
     import torch.distributed as dist
 
@@ -56,9 +62,14 @@ def theta_grid_replicas(ctx, d_counts, d_fullmean, size_factors, thetas, group=N
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     thetas = [float(t) for t in thetas]
     mine = theta_replica_plan(len(thetas), world)[rank]
-    part = np.zeros(len(thetas), dtype=np.float64)
+    part = np.zeros(len(thetas) + 1, dtype=np.float64)  # the totals, then this rank's status (0 = fine)
+    failure = None
     if mine:
-        part[mine] = ctx.theta_grid(d_counts, d_fullmean, size_factors, [thetas[k] for k in mine], opts=opts)
+        try:
+            part[mine] = ctx.theta_grid(d_counts, d_fullmean, size_factors, [thetas[k] for k in mine], opts=opts)
+        except Exception as e:  # noqa: BLE001 — whatever it is, the peers must hear of it
+            failure = e
+            part[-1] = 1.0
     # every point is fitted by exactly one rank: gather the ranks' vectors and pick each point from its owner (a sum of zero-filled
     # vectors would do as well, but a NaN total — a region with zero counts in every sample — must arrive as NaN, not poison the rest)
     backend = str(dist.get_backend(group))
@@ -67,6 +78,11 @@ def theta_grid_replicas(ctx, d_counts, d_fullmean, size_factors, thetas, group=N
         t = t.to(d_counts.device)
     got = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(got, t, group=group)
+    bad = [r for r in range(world) if float(got[r][-1]) != 0.0]
+    if bad:
+        if failure is not None:
+            raise failure
+        raise RuntimeError(f"theta_grid_replicas: the fit failed on rank(s) {bad}")
     out = np.empty(len(thetas), dtype=np.float64)
     for k in range(len(thetas)):
         out[k] = float(got[k % world][k])

@@ -29,7 +29,7 @@ EXPORTS = [
     "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
     "chicdiff_hip_chinput_read", "chicdiff_hip_chinput_table_dev", "chicdiff_hip_region_avdist_dev",
     "chicdiff_hip_count_join_inner_dev",
-    "chicdiff_hip_malloc", "chicdiff_hip_free", "chicdiff_hip_memcpy_h2d", "chicdiff_hip_memcpy_d2h",
+    "chicdiff_hip_malloc", "chicdiff_hip_free", "chicdiff_hip_outstanding_allocations", "chicdiff_hip_memcpy_h2d", "chicdiff_hip_memcpy_d2h",
     "chicdiff_hip_rccl_unique_id", "chicdiff_hip_rccl_init", "chicdiff_hip_cooks_filter_dev",
     "chicdiff_hip_independent_filtering_dev",
     "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_nbglm_fit", "chicdiff_hip_wald_test_dev", "chicdiff_hip_theta_grid_dev",
@@ -118,6 +118,8 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_rccl_init.argtypes = [vp, C.c_char_p, vp, i32, i32]
     L.chicdiff_hip_malloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.chicdiff_hip_free.argtypes = [vp, vp]
+    L.chicdiff_hip_outstanding_allocations.argtypes = [vp]
+    L.chicdiff_hip_outstanding_allocations.restype = i64
     L.chicdiff_hip_memcpy_h2d.argtypes = [vp, vp, vp, C.c_uint64]
     L.chicdiff_hip_memcpy_d2h.argtypes = [vp, vp, vp, C.c_uint64]
     L.chicdiff_hip_count_table_dev.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, vp, C.POINTER(i64)]

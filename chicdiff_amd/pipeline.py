@@ -55,8 +55,11 @@ def readAndFilterPeakMatrix(peakFiles, targetColumns, chicagoData, conditions, s
     x = x[x["dist"].notna()]                               # trans interactions out
     x = x[~((x["oeID"] == x["baitID"] + 1) | (x["oeID"] == x["baitID"] - 1))]   # directly adjacent fragments out
     filtered = np.asarray(all_baits)[~np.isin(all_baits, x["baitID"].to_numpy())]   # one %in%, as chicdiff.R:271
-    with open(f"{outprefix}_filteredBaits.txt", "w") as f:                         # fwrite(list(...)): a "V1" header line, then the IDs
-        f.write("V1\n" + "".join(f"{b}\n" for b in filtered))
+    # chicdiff.R:272-274: fwrite(list(filtered), file) — an UNNAMED list.  data.table's fwrite writes a header line only when the
+    # names attribute is a character vector, so the reference's file holds the bare IDs, one per line (round 4 wrote a "V1" line
+    # first on an unverified reading; no R here to settle it, so this follows fwriteR.c as recalled — ADVICE r04)
+    with open(f"{outprefix}_filteredBaits.txt", "w") as f:
+        f.write("".join(f"{b}\n" for b in filtered))
     return x.reset_index(drop=True)
 
 

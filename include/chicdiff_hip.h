@@ -112,9 +112,14 @@ int chicdiff_hip_rccl_init(chicdiff_hip_ctx *ctx, const char *librccl_path, cons
                            int32_t rank);
 
 /* Device memory for hosts without a GPU array library of their own (the R shim): plain allocations on the
- * context's device, copies ordered on the context's stream and complete on return. */
+ * context's device, copies ordered on the context's stream and complete on return.  The context keeps a list of
+ * them: chicdiff_hip_destroy() releases whatever is still outstanding (R runs the finalizers of one garbage
+ * collection in no particular order, so a context can be finalized before its vectors — r/src/chicdiff_hip_shim.c:
+ * devbuf_finalizer then finds the context gone and has nothing left to free); chicdiff_hip_free() of a pointer the
+ * context does not own is CHICDIFF_E_INVALID.  _outstanding_allocations: how many are live (-1: NULL context). */
 int chicdiff_hip_malloc(chicdiff_hip_ctx *ctx, uint64_t bytes, void **d_ptr);
 int chicdiff_hip_free(chicdiff_hip_ctx *ctx, void *d_ptr);
+int64_t chicdiff_hip_outstanding_allocations(chicdiff_hip_ctx *ctx);
 int chicdiff_hip_memcpy_h2d(chicdiff_hip_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int chicdiff_hip_memcpy_d2h(chicdiff_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 
@@ -140,7 +145,9 @@ typedef struct {
 void chicdiff_hip_default_opts(chicdiff_nbglm_opts *opts);
 
 /* Per-row outputs, length n each; any pointer may be NULL (not wanted).  Host or device
- * pointers according to the entry point used. */
+ * pointers according to the entry point used.  The device entry points write these columns IN PLACE while the fit
+ * runs (its workspace points into them), so after a return other than CHICDIFF_OK — and while a fit that had to
+ * start over is under way — their contents are undefined: partly written, not "untouched". */
 typedef struct {
     double *baseMean;       /* mcols(dds)$baseMean                                   */
     double *baseVar;

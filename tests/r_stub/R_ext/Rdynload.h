@@ -1,4 +1,4 @@
-/* Declaration-only stand-in for R's R_ext/Rdynload.h: SYNTAX CHECK ONLY (see tests/r_stub/README.md). */
+/* Stand-in for R's R_ext/Rdynload.h (see tests/r_stub/README.md; implemented by rstub.c). */
 #ifndef R_STUB_RDYNLOAD_H
 #define R_STUB_RDYNLOAD_H
 typedef void *(*DL_FUNC)(void);

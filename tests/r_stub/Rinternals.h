@@ -1,4 +1,7 @@
-/* Declaration-only stand-in for R's Rinternals.h: SYNTAX CHECK ONLY (see tests/r_stub/README.md). */
+/* Stand-in for R's Rinternals.h — the slice of R's C API that r/src/chicdiff_hip_shim.c uses, written from "Writing R
+ * Extensions" (sections 5 and 6).  Since round 5 the declarations are backed by a small FUNCTIONAL implementation (rstub.c) so
+ * that the shim can be linked and every .Call routine executed on the GPU box: see tests/r_stub/README.md for what that does
+ * and does not show.  It pins nothing about R itself. */
 #ifndef R_STUB_RINTERNALS_H
 #define R_STUB_RINTERNALS_H
 #include <stddef.h>
@@ -9,6 +12,10 @@ typedef int Rboolean;
 #define TRUE 1
 #define FALSE 0
 #endif
+#define NILSXP 0
+#define SYMSXP 1
+#define CHARSXP 9
+#define LGLSXP 10
 #define INTSXP 13
 #define REALSXP 14
 #define STRSXP 16

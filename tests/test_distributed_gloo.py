@@ -231,6 +231,59 @@ class _StubGrid:
         return np.array([np.nan if t == 0.75 else 1000.0 + 7.0 * t * t - 3.0 * t for t in thetas])
 
 
+class _FailingGrid(_StubGrid):
+    """... and a fit that fails on the rank it is told to"""
+
+    def __init__(self, fail):
+        super().__init__()
+        self.fail = fail
+
+    def theta_grid(self, d_counts, d_fullmean, size_factors, thetas, opts=None):
+        if self.fail:
+            raise RuntimeError("device fell over (injected)")
+        return super().theta_grid(d_counts, d_fullmean, size_factors, thetas, opts)
+
+
+def _replica_failure_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from chicdiff_amd.dist import theta_grid_replicas
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dummy = torch.zeros(2, 2)
+        try:
+            theta_grid_replicas(_FailingGrid(fail=rank == 1), dummy, dummy, [1.0, 1.0], [0.0, 0.25, 0.5, 0.75, 1.0])
+            q.put((rank, "returned"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_theta_grid_replicas_a_failure_on_one_rank_raises_on_every_rank():
+    """a fit that raises on ONE rank used to leave the others inside dist.all_gather for ever.  Now the local exception is
+    caught, a status flag travels with the totals, and every rank raises — the failing rank its own exception, the others a
+    message naming it."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_failure_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert "injected" in res[1] and "failed on rank(s) [1]" in res[0], res
+
+
 def _replica_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
