@@ -117,6 +117,199 @@ def hbm_kernels(ctx, torch, n, S, F=11):
     return out
 
 
+def end_to_end(ctx, torch, synth, n, S, F=11, reps=3):
+    """The drop-in's whole resident path in the reference's default mode (chicdiffPipeline, chicdiff.R:301-347: norm = "combined",
+    theta = NULL), one stage after the other on `n` peaks x `S` replicates, everything resident in HBM: what a user of
+    chicdiffPipeline(backend = "hip") waits for between "Chicago objects read" and "ihw() trained" — NOT part of `value`.
+
+      test set   : region universe (:353-426) -> count join x S (:843-858) -> Bmean / Tmean / FullMean (:628-703, 894-896)
+                   -> window sums (:1540-1556) -> size factors (:1561-1562) -> theta grid, 5 design-~1 fits (:1619-1662)
+                   -> final fit at the chosen theta (:1666-1674) -> results(): Cook's cutoff, independent filtering, BH (:1720-1762)
+      control set: the same up to the window sums, then ONE fit at the inherited theta (:331-332) and results()
+      IHW        : avDist per region (:1965) and the application block (:2038-2049) with fixed weights (training = IHW::ihw stays R)
+
+    Synthetic inputs: peaks on a 840 001-fragment map, RU rows from the device's own region universe, the synthetic count matrix
+    (chicdiff_amd/synth.py; rows [0, n) test, [n, 2n) control) split over each region's fragments by random weights and turned into
+    one sorted (baitID, otherEndID) -> N table per replicate (what a .chinput becomes), random Chicago tables (s_j, s_i, Tmean
+    bins, distance function).  A region whose counts are all zero gets one read (the reference's theta scan needs every total
+    deviance finite: sum() without na.rm, :1647)."""
+    dev = ctx.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    maxfrag = 840000
+    chr_of = (torch.arange(0, maxfrag + 1, device=dev) // 35000).to(torch.int32)
+    nid = maxfrag + 1
+    group = synth.groups(S)
+    grid = [0.0, 0.25, 0.5, 0.75, 1.0]
+
+    def peaks():
+        pb = torch.randint(1000, 800000, (n,), dtype=torch.int64, device=dev, generator=g)
+        dd = torch.randint(2, 60, (n,), dtype=torch.int64, device=dev, generator=g) * (torch.randint(0, 2, (n,), device=dev, generator=g) * 2 - 1)
+        # every region keeps fragments on its bait's chromosome (a region the cis filter empties, :406-419, trips the reference's own
+        # stopifnot at :1717): where the window around bait + d would leave the chromosome, the peak goes to the other side of the bait
+        off_chr = ((pb + dd + 5) // 35000 != pb // 35000) | ((pb + dd - 5) // 35000 != pb // 35000)
+        po = pb + torch.where(off_chr, -dd, dd)
+        key = torch.sort(pb * (1 << 32) + po).values      # setkey(baitID, oeID): regions bait-major, as the reference numbers them
+        return (key >> 32).to(torch.int32), (key & 0xFFFFFFFF).to(torch.int32)
+
+    def split_counts(ru, k):
+        """k (S, n) region counts -> (S, nfrag) fragment counts that sum back to k over each region's rows"""
+        ptr = ru["region_ptr"]
+        nfrag = int(ru["baitID"].numel())
+        cnt = ptr[1:] - ptr[:-1]
+        rid = torch.repeat_interleave(torch.arange(n, device=dev), cnt)
+        w = torch._standard_gamma(torch.full((nfrag,), 0.3, dtype=torch.float64, device=dev)) + 1e-12
+        cum = torch.cumsum(w, 0)
+        cum_excl = cum - w
+        start = cum_excl[ptr[:-1].clamp(max=nfrag - 1)]
+        tot = cum[(ptr[1:] - 1).clamp(min=0)] - start
+        hi = ((cum - start[rid]) / tot[rid]).clamp(0, 1)
+        lo = ((cum_excl - start[rid]) / tot[rid]).clamp(0, 1)
+        last = torch.zeros(nfrag, dtype=torch.bool, device=dev)
+        last[(ptr[1:] - 1)[cnt > 0]] = True
+        hi[last] = 1.0
+        out = torch.empty((S, nfrag), dtype=torch.int32, device=dev)
+        for j in range(S):
+            kj = k[j][rid].to(torch.float64)
+            out[j] = (torch.floor(kj * hi + 1e-9) - torch.floor(kj * lo + 1e-9)).to(torch.int32)
+        return out
+
+    # ---- set-up (not timed): both universes, the replicates' count tables, the Chicago tables ----
+    sets = {}
+    for name, start_row in (("test", 0), ("control", n)):
+        pb, po = peaks()
+        for _ in range(4):   # (a handful of peaks per million still lose every fragment to the clipping: they take their neighbour's place)
+            ru = ctx.region_universe(pb, po, 5, chr_of)
+            empty = torch.nonzero((ru["region_ptr"][1:] - ru["region_ptr"][:-1]) == 0).flatten()
+            if empty.numel() == 0:
+                break
+            src = (empty - 1).clamp(min=0)
+            pb[empty], po[empty] = pb[src], po[src]
+        d = synth.make(n, S, start=start_row)
+        k = torch.from_numpy(np.ascontiguousarray(d["counts"].T)).to(dev)
+        k[0, k.sum(0) == 0] = 1
+        sets[name] = dict(pb=pb, po=po, frag=split_counts(ru, k), key=ru["baitID"].to(torch.int64) * (1 << 32) + ru["otherEndID"].to(torch.int64))
+        del ru, k, d
+    tables = []
+    allkeys = torch.cat([sets["test"]["key"], sets["control"]["key"]])
+    for j in range(S):
+        v = torch.cat([sets["test"]["frag"][j], sets["control"]["frag"][j]])
+        sel = v > 0
+        ks, order = torch.sort(allkeys[sel])
+        vs = v[sel][order]
+        first = torch.ones_like(ks, dtype=torch.bool)
+        first[1:] = ks[1:] != ks[:-1]                      # a pair that sits in several regions keeps one count, as in a chinput
+        tables.append((ks[first].contiguous(), vs[first].contiguous()))
+    nkeys = int(np.mean([t[0].numel() for t in tables]))
+    for st in sets.values():
+        del st["frag"], st["key"]
+    del allkeys
+    sj = torch.exp(torch.randn((S, nid), dtype=torch.float64, device=dev, generator=g) * 0.3)
+    si = torch.exp(torch.randn((S, nid), dtype=torch.float64, device=dev, generator=g) * 0.3)
+    si[torch.rand((S, nid), device=dev, generator=g) < 0.02] = float("nan")   # other ends Chicago never saw: s_i NA -> 1 (:668-672)
+    ntblb, ntlb = 6, 6
+    tblb = torch.randint(0, ntblb, (S, nid), dtype=torch.int32, device=dev, generator=g)
+    tlb = torch.randint(0, ntlb, (S, nid), dtype=torch.int32, device=dev, generator=g)
+    T = torch.exp(torch.randn((S, ntblb, ntlb), dtype=torch.float64, device=dev, generator=g) * 0.5 - 3.0)
+    midsum = (torch.arange(nid, device=dev, dtype=torch.int64) * 8000 + 4000)
+    distfun = np.zeros((S, 10))
+    for j in range(S):
+        fit = np.array([14.0 + 0.1 * j, -1.6, 0.05, -0.003])
+        ends = np.array([np.log(10000.0), np.log(1.5e6)])
+        beta = fit[1] + 2 * fit[2] * ends + 3 * fit[3] * ends ** 2
+        alpha = fit[0] + (fit[1] - beta) * ends + fit[2] * ends ** 2 + fit[3] * ends ** 3
+        distfun[j] = [*fit, alpha[0], beta[0], alpha[1], beta[1], ends[0], ends[1]]
+    from scipy import stats
+    cutoff = float(stats.f.ppf(0.99, 2, S - 2)) if S - S // 2 >= 3 else None
+    breaks = np.array([0.0, 10.5, 11.5, 12.5, np.inf])
+    weights = np.array([1.8, 1.3, 0.7, 0.2])
+    want = ["baseMean", "dispersion", "log2FoldChange", "lfcSE", "stat", "pvalue", "maxCooks", "cooksArgmax"]
+
+    def run(sync, checks=None):
+        """one pass; sync=True: a device synchronisation after every stage (the per-stage split), False: only at the end"""
+        times = {}
+        torch.cuda.synchronize()
+        t_all = time.perf_counter()
+
+        def stage(name, fn):
+            t0 = time.perf_counter()
+            out = fn()
+            if sync:
+                torch.cuda.synchronize()
+                times[name] = times.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+            return out
+
+        res = {}
+        theta = None
+        for name in ("test", "control"):
+            st = sets[name]
+            ru = stage("region_universe", lambda: ctx.region_universe(st["pb"], st["po"], 5, chr_of))
+            nfrag = ru["baitID"].numel()
+            fragN = torch.empty((S, nfrag), dtype=torch.int32, device=dev)
+
+            def joins():
+                for j, (kk, vv) in enumerate(tables):
+                    fragN[j] = ctx.count_join(ru["baitID"], ru["otherEndID"], kk, vv)
+            stage("count_join", joins)
+            fragFM = stage("fragment_background", lambda: ctx.fragment_background(ru["baitID"], ru["otherEndID"], 0, midsum, sj, si, tblb, tlb, T, distfun, only_fullmean=True)[2])
+            N, FM = stage("window_sums", lambda: ctx.window_sums(fragN, fragFM, ru["region_ptr"]))
+            if checks is not None:  # (warm-up pass only: what the synthetic inputs look like after the join and the sums)
+                cnt = ru["region_ptr"][1:] - ru["region_ptr"][:-1]
+                checks[name] = dict(regions_without_fragments=int((cnt == 0).sum()), all_zero_rows=int((N.sum(0) == 0).sum()),
+                                    rows_with_na_fullmean=int(torch.isnan(FM).any(0).sum()), mean_count=float(N.double().mean()),
+                                    joined_nonzero_fraction=float((fragN > 0).double().mean()))
+            del fragN, fragFM
+            if name == "test":
+                sf = stage("size_factors", lambda: ctx.size_factors(N))
+                dv = stage("theta_grid", lambda: ctx.theta_grid(N, FM, sf, grid))
+                theta = grid[int(np.nanargmin(dv))] if np.isfinite(dv).any() else 0.5   # tt <- Grid[which(deviances == min(deviances))], :1660
+                res["deviances"] = [float(x) for x in dv]
+            out, sc = stage("final_fit" if name == "test" else "control_fit", lambda: ctx.wald_test(N, FM, group, theta=theta, want=want))
+
+            def results():
+                if cutoff is not None:
+                    ctx.cooks_filter(N, group, out["maxCooks"], out["cooksArgmax"], out["pvalue"], cutoff)
+                return ctx.independent_filtering(out["baseMean"], out["pvalue"], 0.1)
+            padj, info = stage("results", results)
+            if name == "test":
+                def ihw():
+                    av = ctx.region_avdist(ru["baitID"], ru["otherEndID"], ru["region_ptr"], 0, midsum, chr_of)
+                    if checks is not None:
+                        checks["avDist"] = dict(na=int(torch.isnan(av).sum()), min_abs=float(av.abs().min()), max_abs=float(av.abs().max()))
+                    return ctx.ihw_apply(av, out["pvalue"], breaks, weights)
+                w = stage("ihw_covariate_and_application", ihw)
+                res.update(nfrag=int(nfrag), rejections_padj_0_05=int((padj < 0.05).sum()), weighted_rejections=int((w["weighted_padj"] < 0.05).sum()),
+                           status=int(sc["status"]))
+            del ru, N, FM, out, padj
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t_all) * 1e3, times, theta, res
+
+    checks = {}
+    run(True, checks)                                       # warm-up: workspaces, the theta grid's child contexts
+    totals, splits = [], []
+    for _ in range(reps):
+        tot, _, theta, res = run(False)
+        totals.append(tot)
+    for _ in range(reps):
+        _, tms, _, _ = run(True)
+        splits.append(tms)
+    stages = {k: round(float(np.median([sp[k] for sp in splits])), 3) for k in splits[0]}
+    nfrag = res["nfrag"]
+    hbm = {  # algorithmic bytes of the HBM-bound stages (both sets), SURVEY.md 8(d): per RU row / fragment / region and replicate
+        "count_join": 2 * S * (12 * nfrag + 12 * nkeys),
+        "fragment_background": 2 * (8 * nfrag + 8 * S * nfrag),
+        "window_sums": 2 * (12 * S * nfrag + 12 * S * n),
+        "region_universe": 2 * (16 * n + 12 * nfrag + 16 * n),
+    }
+    return {"total_ms": round(float(np.median(totals)), 3), "total_runs_ms": [round(t, 3) for t in totals],
+            "sum_of_stages_ms": round(sum(stages.values()), 3), "stages_ms": stages,
+            "hbm_stage_fraction_of_peak": {k: round(v / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in hbm.items()},
+            "input_checks": checks, "theta_chosen": theta, "peaks_per_set": n, "ru_rows_per_set": nfrag, "keys_per_replicate_table": nkeys, **{k: v for k, v in res.items() if k != "nfrag"},
+            "what": "resident default-mode pipeline, test + control sets, chicdiff.R:301-347 order: total_ms = one pass without intermediate "
+                    "synchronisation (median of %d); stages_ms = a pass with a device synchronisation after every stage (host-side Python / ctypes "
+                    "overhead of ~40 calls included in both)" % reps}
+
+
 def theta_grid_time(ctx, torch, dk, dfm, S):
     """a8: the reference's default mode first scans theta over a 5-point grid, one design-~1 fit per theta
     (chicdiff.R:1619-1662); wall clock of that scan on the benchmark matrix."""
@@ -179,6 +372,7 @@ def main():
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-kernels", action="store_true", help="skip the window-sum / offsets / count-join side measurement")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the resident default-mode pipeline leg (region universe ... IHW application)")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--one-mode", action="store_true", help="N > 1: skip the second measurement (the other of strong / weak scaling)")
     args = ap.parse_args()
@@ -223,6 +417,16 @@ def main():
 
     S = args.samples
     ctx = hip.HipContext(local_rank)
+    # CHICDIFF_BENCH_FAKE_WORLD=N (with CHICDIFF_BENCH_FORCE_DIST=1, one GPU): rehearse ONE rank's step of an N-GPU strong-scaling run —
+    # rows / N on this rank, the whole sharded protocol over a 1-rank RCCL group, and the trend's rows gathered as if N ranks had
+    # each sent this rank's block, so that the single-launch trend + MAD kernel runs on all N x (rows / N) rows as it does on every
+    # rank of the real thing (library option "bench_fake_world").  `value` is then rows / (this rank's step): what N GPUs would
+    # deliver BEFORE any inter-GPU latency — a projection, labelled as such in `config`.
+    fake_world = int(os.environ.get("CHICDIFF_BENCH_FAKE_WORLD", "0") or 0)
+    if fake_world > 1:
+        if not (force_dist and world == 1):
+            raise SystemExit("CHICDIFF_BENCH_FAKE_WORLD needs CHICDIFF_BENCH_FORCE_DIST=1 and --gpus 1")
+        ctx.set_option("bench_fake_world", fake_world)
     if share_gpu and world > 1:  # rehearsal: all ranks' persistent trend kernels must be resident on the ONE GPU at the same time
         ctx.set_option("trend_persistent_blocks", max(1, 256 // world))
     collectives, comm_ranks = "none (single rank)", 1
@@ -270,7 +474,7 @@ def main():
     def measure(scaling, breakdown=True):
         """W warm-up steps, then exactly K timed steps between two barriers; the MAX over ranks."""
         if scaling == "strong":
-            lo, hi = shard_bounds(args.rows, world, rank)
+            lo, hi = shard_bounds(args.rows, fake_world if fake_world > 1 else world, rank)
             n, n_global = hi - lo, args.rows
         else:
             lo, n, n_global = rank * args.rows, args.rows, world * args.rows
@@ -329,6 +533,7 @@ def main():
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = None
     valu = None
+    ent = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
@@ -354,7 +559,15 @@ def main():
         coll_all = [None] * world
         dist.all_gather_object(coll_all, my_coll)
     valu_busy = valu.get("valu_busy_fraction") if valu else None
-    roofline = {"bound": "valu", "valu_busy": valu_busy, "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    fp64_frac = None
+    if valu and ent.get("valu", {}).get("fp64_flops_per_launch"):
+        # the roof that binds: counted fp64 flops of the launch (wave-level FMA x 2 + MUL + ADD + transcendental, x the lanes
+        # active per VALU instruction: profiles/pmc_traffic.json, its own --pmc pass) / this run's launch time / the 78.6 TF vector-fp64 peak
+        valu["fp64_flops_per_launch"] = ent["valu"]["fp64_flops_per_launch"]
+        valu["fp64_insts"] = ent["valu"].get("fp64_insts")
+        valu["fp64_source"] = ent["valu"].get("fp64_source")
+        fp64_frac = round(ent["valu"]["fp64_flops_per_launch"] / (avg_ms * 1e-3) / (FP64_VALU_PEAK_TFLOPS * 1e12), 4)
+    roofline = {"bound": "valu", "valu_busy": valu_busy, "fp64_frac": fp64_frac, "fp64_peak_tflops": FP64_VALU_PEAK_TFLOPS, "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "frac_of_measured_stream_6290": round(achieved / 6290.0, 5), "valu": valu,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
@@ -368,7 +581,10 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic {n_global} interactions x {S} samples ({S // 2}v{S - S // 2}), "
                                f"size factors + offsets(theta={args.theta}) + dispersions + Wald, design ~condition",
-                   "rows_per_gpu": n, "samples": S, "global_rows": n_global, "parallelism": f"rows-sharded x{world}",
+                   "rows_per_gpu": n, "samples": S, "global_rows": n_global,
+                   "parallelism": (f"rows-sharded x{world}" if fake_world <= 1 else
+                                   f"REHEARSAL on one GPU of one rank's step of a x{fake_world} run: {n} rows here, trend + MAD on all {fake_world} x {n} gathered rows, "
+                                   f"1-rank RCCL group; value = global rows / this step = a projection before inter-GPU latency"),
                    "collectives": collectives, "ranks_in_communicator": comm_ranks},
         "roofline": roofline,
         "kernels_ms": {k: [round(v[0] / args.steps, 4), v[1] // args.steps] for k, v in sorted(kfull.items(), key=lambda kv: -kv[1][0]) if k != "allreduce"},
@@ -394,6 +610,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_hbm_kernels:
         result["hbm_kernels"] = hbm_kernels(ctx, torch, n, S)
         result["theta_grid"] = theta_grid_time(ctx, torch, dk, dfm, S)
+    if rank == 0 and world == 1 and not args.no_hbm_kernels and not args.no_end_to_end:
+        del dk, dfm
+        torch.cuda.empty_cache()
+        result["end_to_end"] = end_to_end(ctx, torch, synth, n, S)
+        dk = ctx.to_device(d["counts"], np.int32)
+        dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / S), np.float64)
     if rank == 0 and world == 1 and not args.no_hbm_kernels:
         # what an R caller sees: chicdiff_hip_nbglm_fit on HOST buffers (INTEGER(counts), REAL(nf) in, six columns out) — staging
         # through pinned slices + PCIe both ways included.  Reported beside `value`, never as `value`.

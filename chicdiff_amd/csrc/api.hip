@@ -60,6 +60,10 @@ struct chicdiff_hip_ctx {
     // select candidate-list overflow, 2 = this rank's persistent trend kernel reports a grid-barrier timeout, 4 = this rank's
     // size-factor select reports an overflow.  Each verdict is all-reduced, so every rank of a sharded fit must re-enter together.
     int opt_trend_blocks = 0;  // persistent trend kernel: cap on its workgroups (0 = one per CU)
+    // bench hook (option "bench_fake_world", a 1-rank communicator only): the trend's rows are gathered as if N ranks had each sent
+    // this rank's block — the single-launch trend + MAD kernel then runs on N x n rows, which is what EVERY rank of an N-GPU fit
+    // does (bench.py's rehearsal of a rank's step at its share of the rows; the coefficients are those of the n rows up to rounding)
+    int opt_fake_world = 0;
     int opt_mad_in_kernel = 1; // the persistent trend kernel also takes the median / MAD of the residuals (0: separate launches, as round 3)
     int opt_fault = 0;
     int refits = 0;               // refits the last call went through (select overflow / barrier timeout / local substitute), for the tests
@@ -184,6 +188,7 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     else if (k == "trend_one_launch_per_pass" && (value == 0 || value == 1)) c->opt_trend_multilaunch = (int)value;
     else if (k == "fault_inject" && value >= 0 && value <= 7) c->opt_fault = (int)value;
     else if (k == "trend_persistent_blocks" && value >= 0 && value <= 256) c->opt_trend_blocks = (int)value;
+    else if (k == "bench_fake_world" && value >= 0 && value <= kGatherMaxWorld) c->opt_fake_world = (int)value;
     else if (k == "trend_mad_in_kernel" && (value == 0 || value == 1)) c->opt_mad_in_kernel = (int)value;
     else return fail(c, CHICDIFF_E_INVALID, "set_option: unknown option or value (%s = %lld)", name, (long long)value);
     return CHICDIFF_OK;
@@ -847,10 +852,14 @@ static int local_trend_fit(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
 static int gathered_trend(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
     hipStream_t st = c->stream;
     FitWork &w = c->w;
-    const int world = c->world > 0 ? c->world : 1, rank = c->rank;
+    const int real_world = c->world > 0 ? c->world : 1, rank = c->rank;
+    const int fake = (real_world == 1 && c->opt_fake_world > 1 && c->allgather != nullptr) ? c->opt_fake_world : 0;  // bench hook, see opt_fake_world
+    const int world = fake ? fake : real_world;
     std::vector<double> cnt((size_t)world, 0.0);
     int rc;
-    if (c->shard_n_valid && world <= kSelMaxWorld && (int64_t)c->shard_n[rank] == d.n) {
+    if (fake) {
+        for (int r = 0; r < world; r++) cnt[(size_t)r] = (double)d.n;
+    } else if (c->shard_n_valid && world <= kSelMaxWorld && (int64_t)c->shard_n[rank] == d.n) {
         for (int r = 0; r < world; r++) cnt[(size_t)r] = c->shard_n[r];  // exchanged with the argument verdicts: no collective, no host stop
     } else {
         cnt[(size_t)rank] = (double)d.n;
@@ -894,6 +903,8 @@ static int gathered_trend(chicdiff_hip_ctx *c, FitDims d, const Opts &o) {
         HIPCHK(c, hipMemsetAsync(flags, 0, ni, st));
         launch_trend_gather(d, w, o, send, send + maxn, st);
         if ((rc = do_allgather(c, send, recv, (int64_t)(blk / sizeof(double))))) return rc;
+        for (int r = 1; r < fake; r++)  // the other "ranks'" blocks: copies of this one's
+            HIPCHK(c, hipMemcpyAsync((char *)recv + (size_t)r * blk, recv, blk, hipMemcpyDeviceToDevice, st));
         GatherLayout gl{};
         gl.world = world;
         gl.block = (int64_t)(blk / sizeof(double));
@@ -1689,8 +1700,9 @@ extern "C" int chicdiff_hip_fragment_background_dev(chicdiff_hip_ctx *c, const i
         S < 1 || S > kMaxS || ntblb < 1 || ntlb < 1)
         return fail(c, CHICDIFF_E_INVALID, "fragment_background: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    double *d_df = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_df, sizeof(double) * 10 * S));
+    int rc = ensure_aux(c, sizeof(double) * 10 * kMaxS);  // (the context's scratch: no allocation per call once warm)
+    if (rc) return rc;
+    double *d_df = reinterpret_cast<double *>(c->aux);
     hipError_t e = hipMemcpyAsync(d_df, distfun_host, sizeof(double) * 10 * S, hipMemcpyHostToDevice, c->stream);
     timing_reset(c);
     if (e == hipSuccess && nru > 0) {
@@ -1700,7 +1712,6 @@ extern "C" int chicdiff_hip_fragment_background_dev(chicdiff_hip_ctx *c, const i
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     timing_collect(c);
-    (void)hipFree(d_df);
     if (e != hipSuccess) return fail(c, CHICDIFF_E_HIP, "fragment_background: %s", hipGetErrorString(e));
     return CHICDIFF_OK;
 }

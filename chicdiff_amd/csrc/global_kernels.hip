@@ -1675,40 +1675,50 @@ struct BgArgs {
     const double *distfun;  // device, S x 10
     double *bmean, *tmean, *fullmean;
 };
+// One thread per RU row, the replicates in a loop (round 5; before: one thread per (row, replicate), grid.y = S): the row's two
+// fragment IDs, the two midpoints and log|distance| are the same for every replicate — S - 1 of every S logarithms, ID loads and
+// midpoint gathers were repeats — and a caller that wants FullMean alone (chicdiff.R:896: the one column DESeq2Wrap reads) passes
+// NULL for the other two and saves two thirds of the stores.  Same expressions in the same order: same bits.
 __global__ __launch_bounds__(256) void fragment_background_kernel(BgArgs a) {
-    const int s = blockIdx.y;
-    const double *p = a.distfun + 10 * s;
-    const double c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3], h0 = p[4], h1 = p[5], t0 = p[6], t1 = p[7], omin = p[8],
-                 omax = p[9];
+    extern __shared__ double s_df[];  // S x 10: the replicates' distance functions
+    for (int k = threadIdx.x; k < 10 * a.S; k += 256) s_df[k] = a.distfun[k];
+    __syncthreads();
     for (int64_t r = blockIdx.x * 256 + threadIdx.x; r < a.nru; r += (int64_t)gridDim.x * 256) {
         const int32_t b = a.bait[r] - a.id_min, o = a.oe[r] - a.id_min;
-        double B = NAN, Tm = NAN;
-        if (b >= 0 && b < a.nid && o >= 0 && o < a.nid) {
+        const bool on_map = b >= 0 && b < a.nid && o >= 0 && o < a.nid;
+        double ld = 0.0;
+        if (on_map) {
             const double dist = rint((double)(a.midsum[o] - a.midsum[b]) / 2.0);  // R round(): half to even
-            const double s_j = a.sj[(int64_t)s * a.nid + b];
-            double s_i = a.si[(int64_t)s * a.nid + o];
-            if (s_i != s_i) s_i = 1.0;
-            const double ld = log(fabs(dist));
-            double e;
-            if (ld > omax) e = t0 + ld * t1;
-            else if (ld < omin) e = h0 + ld * h1;
-            else e = c0 + c1 * ld + c2 * (ld * ld) + c3 * (ld * ld * ld);
-            B = s_j * s_i * exp(e);
-            const int32_t tb = a.tblb[(int64_t)s * a.nid + b], tl = a.tlb[(int64_t)s * a.nid + o];
-            if (tb >= 0 && tl >= 0) {
-                Tm = a.T[((int64_t)s * a.ntblb + tb) * a.ntlb + tl];
-            } else if (tb >= 0) {
-                double m = INFINITY;
-                for (int k = 0; k < a.ntlb; k++) {
-                    const double v = a.T[((int64_t)s * a.ntblb + tb) * a.ntlb + k];
-                    if (v == v && v < m) m = v;
-                }
-                Tm = isfinite(m) ? m : NAN;
-            }
+            ld = log(fabs(dist));
         }
-        if (a.bmean) a.bmean[(int64_t)s * a.nru + r] = B;
-        if (a.tmean) a.tmean[(int64_t)s * a.nru + r] = Tm;
-        if (a.fullmean) a.fullmean[(int64_t)s * a.nru + r] = B + Tm;
+        for (int s = 0; s < a.S; s++) {
+            double B = NAN, Tm = NAN;
+            if (on_map) {
+                const double *p = s_df + 10 * s;
+                const double s_j = a.sj[(int64_t)s * a.nid + b];
+                double s_i = a.si[(int64_t)s * a.nid + o];
+                if (s_i != s_i) s_i = 1.0;
+                double e;
+                if (ld > p[9]) e = p[6] + ld * p[7];
+                else if (ld < p[8]) e = p[4] + ld * p[5];
+                else e = p[0] + p[1] * ld + p[2] * (ld * ld) + p[3] * (ld * ld * ld);
+                B = s_j * s_i * exp(e);
+                const int32_t tb = a.tblb[(int64_t)s * a.nid + b], tl = a.tlb[(int64_t)s * a.nid + o];
+                if (tb >= 0 && tl >= 0) {
+                    Tm = a.T[((int64_t)s * a.ntblb + tb) * a.ntlb + tl];
+                } else if (tb >= 0) {
+                    double m = INFINITY;
+                    for (int k = 0; k < a.ntlb; k++) {
+                        const double v = a.T[((int64_t)s * a.ntblb + tb) * a.ntlb + k];
+                        if (v == v && v < m) m = v;
+                    }
+                    Tm = isfinite(m) ? m : NAN;
+                }
+            }
+            if (a.bmean) a.bmean[(int64_t)s * a.nru + r] = B;
+            if (a.tmean) a.tmean[(int64_t)s * a.nru + r] = Tm;
+            if (a.fullmean) a.fullmean[(int64_t)s * a.nru + r] = B + Tm;
+        }
     }
 }
 void launch_fragment_background(const int32_t *bait, const int32_t *oe, int64_t nru, int32_t id_min, int32_t nid,
@@ -1717,9 +1727,9 @@ void launch_fragment_background(const int32_t *bait, const int32_t *oe, int64_t 
                                 double *bmean, double *tmean, double *fullmean, hipStream_t st) {
     BgArgs a{bait, oe, nru, id_min, nid, S, ntblb, ntlb, midsum, sj, si, tblb, tlb, T, distfun_dev, bmean, tmean, fullmean};
     int64_t blocks = (nru + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    fragment_background_kernel<<<dim3((unsigned)blocks, S), 256, 0, st>>>(a);
+    fragment_background_kernel<<<(unsigned)blocks, 256, sizeof(double) * 10 * S, st>>>(a);
 }
 
 // device-math self test (tests/test_gpu_parity.py::test_device_math): out[i] = f_op(x[i])

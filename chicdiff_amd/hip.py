@@ -347,18 +347,20 @@ class HipContext:
         return out
 
     # -- a3 ---------------------------------------------------------------------------------
-    def fragment_background(self, d_bait, d_oe, id_min, d_midsum, d_sj, d_si, d_tblb, d_tlb, d_T, distfun):
-        """Bmean, Tmean, FullMean (S, nru) for RU rows (d_bait, d_oe); tables as in the header."""
+    def fragment_background(self, d_bait, d_oe, id_min, d_midsum, d_sj, d_si, d_tblb, d_tlb, d_T, distfun, only_fullmean=False):
+        """Bmean, Tmean, FullMean (S, nru) for RU rows (d_bait, d_oe); tables as in the header.  ``only_fullmean``: the first two
+        come back as None and are never written (FullMean is the one column DESeq2Wrap reads, chicdiff.R:896, :1543)."""
         torch = self.torch
         S, nid = d_sj.shape
         nru = d_bait.numel()
         df = np.ascontiguousarray(distfun, dtype=np.float64)
         assert df.shape == (S, 10) and d_T.shape[0] == S
-        outs = [torch.empty((S, nru), dtype=torch.float64, device=self.device) for _ in range(3)]
+        outs = [None if (only_fullmean and k < 2) else torch.empty((S, nru), dtype=torch.float64, device=self.device) for k in range(3)]
+        ptr = lambda t: t.data_ptr() if t is not None else None
         self._check(self.lib.chicdiff_hip_fragment_background_dev(
             self.h, d_bait.data_ptr(), d_oe.data_ptr(), nru, int(id_min), nid, d_midsum.data_ptr(), S, d_sj.data_ptr(),
             d_si.data_ptr(), d_tblb.data_ptr(), d_tlb.data_ptr(), d_T.data_ptr(), d_T.shape[1], d_T.shape[2],
-            df.ctypes.data_as(C.POINTER(C.c_double)), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr()))
+            df.ctypes.data_as(C.POINTER(C.c_double)), ptr(outs[0]), ptr(outs[1]), ptr(outs[2])))
         return outs
 
     # -- f2: chinput columns -> key table of the count join -------------------------------------

@@ -281,7 +281,7 @@ def getFullRegionData(chicdiff_settings, RU, RUcontrol, suffix="", ctx=None, rea
             message("Merging countData")
             fragN = ctx.count_join_inner(d_bait, d_oe, tables)
         _, _, fragFM = ctx.fragment_background(d_bait, d_oe, id_min, d_midsum, d_bg["sj"], d_bg["si"], d_bg["tblb"], d_bg["tlb"],
-                                               d_bg["T"], bg["distfun"])
+                                               d_bg["T"], bg["distfun"], only_fullmean=True)
         avDist = ctx.region_avdist(d_bait, d_oe, ptr, id_min, d_midsum, d_chr)
         blocks.append(post.HipRegionData(samples=names, condition=list(conditions), S=S, n=n, fragN=fragN, fragFullMean=fragFM,
                                          region_ptr=ptr, avDist=avDist, dispersions=dispersions, is_control=is_control))

@@ -13,6 +13,8 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 $B
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- python3 $P > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write --output-format csv -- python3 $P > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY -d $OUT/pmc_sq --output-format csv -- python3 $P > /dev/null 2> $OUT/pmc_sq.err
+# fp64 instruction mix of the fit kernels (their own pass: the SQ block holds few counters at once); not fatal if a name is missing
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 -d $OUT/pmc_f64 --output-format csv -- python3 $P > /dev/null 2> $OUT/pmc_f64.err || echo "fp64 counter pass failed (see pmc_f64.err)"
 cd $R
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
@@ -35,6 +37,23 @@ for k, kn in names.items():
         tj[key]["valu"] = {"SQ_INSTS_VALU": float(r["SQ_INSTS_VALU"]), "SQ_ACTIVE_INST_VALU": float(r["SQ_ACTIVE_INST_VALU"]),
                            "active_lanes_per_inst": round(float(r["SQ_THREAD_CYCLES_VALU"] / r["SQ_INSTS_VALU"]), 1),
                            "source": "profiles/${TAG}_pmc_sq_bench_2Mx8.csv"}
+# fp64 flops per launch: wave-level instruction counts (FMA = 2 flops) x the lanes active per VALU instruction of the same kernel
+fs = glob.glob("$OUT/pmc_f64/**/*counter_collection.csv", recursive=True)
+if fs:
+    d6 = pd.concat([pd.read_csv(f) for f in fs])
+    d6["k"] = d6["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("cd::", "").str.replace("void ", "")
+    g6 = d6.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
+    g6.to_csv("$OUT/${TAG}_pmc_f64_bench_2Mx8.csv")
+    print(g6.to_string())
+    for k, kn in names.items():
+        key = k + ":2000000x8"
+        if key in tj and kn in g6.index and "valu" in tj[key]:
+            r6 = g6.loc[kn]
+            mix = {c: float(r6[c]) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64") if c in r6}
+            wave_flops = 2 * mix.get("SQ_INSTS_VALU_FMA_F64", 0) + mix.get("SQ_INSTS_VALU_MUL_F64", 0) + mix.get("SQ_INSTS_VALU_ADD_F64", 0) + mix.get("SQ_INSTS_VALU_TRANS_F64", 0)
+            tj[key]["valu"]["fp64_insts"] = mix
+            tj[key]["valu"]["fp64_flops_per_launch"] = wave_flops * tj[key]["valu"]["active_lanes_per_inst"]
+            tj[key]["valu"]["fp64_source"] = "profiles/${TAG}_pmc_f64_bench_2Mx8.csv"
 json.dump(tj, open("$OUT/pmc_traffic.json", "w"), indent=1)
 PY
 tail -1 $OUT/bench.json
