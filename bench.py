@@ -97,7 +97,7 @@ def hbm_kernels(ctx, torch, n, S, F=11):
     ru = ctx.region_universe(pb, po, 5, chr_of)
     nrow = ru["baitID"].numel()
     del ru
-    def run_ru():  # two API calls (count + scan, then fill): their kernel times added up (HIP events on the library's stream)
+    def run_ru():  # one API call since round 5 (scan, fill, one read-back): its kernel time (HIP events on the library's stream)
         ctx.region_universe(pb, po, 5, chr_of)
         ts = []
         for _ in range(5):
@@ -106,7 +106,7 @@ def hbm_kernels(ctx, torch, n, S, F=11):
         ms = float(np.median(ts))
         nbytes = 2 * (8 * n) + 16 * n + 12 * nrow
         out["region_universe"] = {"ms": round(ms, 4), "achieved_GBs": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                                  "algorithmic_bytes": nbytes, "timing": "kernel time of both calls (count + scan, fill)"}
+                                  "algorithmic_bytes": nbytes, "timing": "kernel time of the one call (scan + fill)"}
 
     run_ru()
     pv = torch.rand(n, dtype=torch.float64, device=dev, generator=g)
@@ -489,9 +489,12 @@ def main():
 
         for _ in range(args.warmup):
             step()
-        # HIP events on the library's stream around the three fit kernels only (one of them is the dominant kernel of the roofline):
-        # bracketing all ~20 stages costs 0.09 ms per step (tools/timing_overhead.py), so the full breakdown comes from a second pass
-        ctx.enable_timing(2)
+        # HIP events on the library's stream around the gene-wise line search only — the dominant kernel of every configuration
+        # measured (checked against the second pass below) and the one the roofline is quoted on: an event is a packet of its own
+        # on the stream, each bracketed stage costs the step ~12 us (rocprofv3 kernel trace, profiles/r05_kernel_gaps_250000x8.txt;
+        # round 4 bracketed three stages here, all ~20 cost 0.09 ms: tools/timing_overhead.py), so the full breakdown comes from a
+        # second pass of the same steps
+        ctx.enable_timing(3)
         ktimes = {}
         barrier()
         t0 = time.perf_counter()
@@ -529,6 +532,10 @@ def main():
     dom = max(((k, v) for k, v in ktimes.items() if k != "allreduce"), key=lambda kv: kv[1][0])
     dom_name, (dom_ms, dom_launches) = dom
     avg_ms = dom_ms / dom_launches
+    if kfull:  # the stage bracketed in the timed region must be the largest of the fully bracketed pass
+        top = max(((k, v) for k, v in kfull.items() if k not in ("allreduce", "allgather")), key=lambda kv: kv[1][0])[0]
+        if top != dom_name:
+            print(f"bench.py: WARNING the largest stage of the breakdown pass is {top}, the roofline is quoted on {dom_name}", file=sys.stderr)
     alg_bytes = algorithmic_bytes(S) * n
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = None
@@ -588,7 +595,7 @@ def main():
                    "collectives": collectives, "ranks_in_communicator": comm_ranks},
         "roofline": roofline,
         "kernels_ms": {k: [round(v[0] / args.steps, 4), v[1] // args.steps] for k, v in sorted(kfull.items(), key=lambda kv: -kv[1][0]) if k != "allreduce"},
-        "kernels_ms_note": "second pass of the same K steps with every stage bracketed by HIP events (costs 0.09 ms per step); the timed region brackets only the three fit kernels (roofline.avg_launch_ms)",
+        "kernels_ms_note": "second pass of the same K steps with every stage bracketed by HIP events (costs 0.09 ms per step); the timed region brackets only the gene-wise line search (roofline.avg_launch_ms); since round 5 the offsets are formed inside prep (no stage of their own)",
         "collectives_per_step": ({"count": kfull["allreduce"][1] // args.steps, "ms": round(kfull["allreduce"][0] / args.steps, 4),
                                   "note": "sum-all-reduces of one fit on this rank and their summed duration on the stream (already inside the stages' kernels_ms)"}
                                  if "allreduce" in kfull else None),

@@ -60,6 +60,10 @@ struct chicdiff_hip_ctx {
     // select candidate-list overflow, 2 = this rank's persistent trend kernel reports a grid-barrier timeout, 4 = this rank's
     // size-factor select reports an overflow.  Each verdict is all-reduced, so every rank of a sharded fit must re-enter together.
     int opt_trend_blocks = 0;  // persistent trend kernel: cap on its workgroups (0 = one per CU)
+    // set by an entry point for the fit it is about to make (d_nf = d_nf_tmp): the offsets are formed from FullMean inside the fit's
+    // first kernel instead of by a launch of their own (common.h FusedOffsets); cleared when the fit returns
+    FusedOffsets fuse;
+    int opt_fuse_offsets = 1;  // (option "fuse_offsets": 0 = offsets as a launch of their own, for the bit-identity test)
     // bench hook (option "bench_fake_world", a 1-rank communicator only): the trend's rows are gathered as if N ranks had each sent
     // this rank's block — the single-launch trend + MAD kernel then runs on N x n rows, which is what EVERY rank of an N-GPU fit
     // does (bench.py's rehearsal of a rank's step at its share of the rows; the coefficients are those of the n rows up to rounding)
@@ -188,6 +192,7 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     else if (k == "trend_one_launch_per_pass" && (value == 0 || value == 1)) c->opt_trend_multilaunch = (int)value;
     else if (k == "fault_inject" && value >= 0 && value <= 7) c->opt_fault = (int)value;
     else if (k == "trend_persistent_blocks" && value >= 0 && value <= 256) c->opt_trend_blocks = (int)value;
+    else if (k == "fuse_offsets" && (value == 0 || value == 1)) c->opt_fuse_offsets = (int)value;
     else if (k == "bench_fake_world" && value >= 0 && value <= kGatherMaxWorld) c->opt_fake_world = (int)value;
     else if (k == "trend_mad_in_kernel" && (value == 0 || value == 1)) c->opt_mad_in_kernel = (int)value;
     else return fail(c, CHICDIFF_E_INVALID, "set_option: unknown option or value (%s = %lld)", name, (long long)value);
@@ -365,7 +370,7 @@ int chicdiff_hip_rccl_init(chicdiff_hip_ctx *c, const char *librccl_path, const 
 
 int chicdiff_hip_enable_timing(chicdiff_hip_ctx *c, int32_t on) {
     if (!c) return CHICDIFF_E_INVALID;
-    c->timing = on == 2 ? 2 : (on != 0 ? 1 : 0);
+    c->timing = (on == 2 || on == 3) ? on : (on != 0 ? 1 : 0);
     return CHICDIFF_OK;
 }
 
@@ -382,6 +387,9 @@ struct Scope {
         // mode 2: an event pair costs ~2 us on the stream and as much on the host when it is read back; a caller that times whole
         // calls (bench.py) brackets only the fit kernels — 0.09 ms less per call than bracketing all ~20 stages
         if (c->timing == 2 && strcmp(name, "disp_gene") != 0 && strcmp(name, "disp_map") != 0 && strcmp(name, "wald_irls") != 0) return;
+        // mode 3: the gene-wise line search alone — the dominant kernel of every configuration measured (an event on the stream is a
+        // packet of its own: each pair costs ~12 us of a 1.3 ms step at 250 k rows; rocprofv3 kernel trace, profiles/r05_kernel_gaps_*)
+        if (c->timing == 3 && strcmp(name, "disp_gene") != 0) return;
         for (size_t i = 0; i < c->timers.size(); i++)
             if (c->timers[i].name == name) idx = (int)i;
         if (idx < 0) {
@@ -970,7 +978,8 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
     if (col_slots) HIPCHK(c, hipMemsetAsync(slots, 0, sizeof(double) * slot_doubles * world, st));
     {
         Scope t(c, "prep");
-        launch_prep(d_counts, d_nf, d, w, o, st);
+        const bool fused = c->fuse.fm != nullptr && d.S <= 16 && d_nf == c->d_nf_tmp;
+        launch_prep(d_counts, const_cast<double *>(d_nf), d, w, o, st, fused ? c->fuse : FusedOffsets());
         launch_prep_finish(d, w, col_slots ? slots + slot_doubles * c->rank : nullptr, st);
     }
     if (col_slots) {
@@ -1454,11 +1463,17 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
             int r = size_factors_impl(c, d_counts, n, S);
             if (r) return r;
             const int mix = theta == theta;
-            {
+            if (d_fullMean && S <= 16 && c->opt_fuse_offsets) {  // the offsets are formed inside the fit's first kernel
+                c->fuse.fm = d_fullMean;
+                c->fuse.sf = c->d_sf;
+                c->fuse.theta = mix ? theta : 0.0;
+                c->fuse.mix = mix;
+            } else {
                 Scope t(c, "offsets");
                 launch_offsets(d_fullMean, c->d_sf, n, S, mix ? theta : 0.0, mix, c->d_nf_tmp, c->stream);
             }
             r = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, make_opts(c, opts, S), d_out, scalars);  // ends with a stream sync; the size factors come back with its scalars
+            c->fuse = FusedOffsets();
             // the sharded size-factor select ran without a host look at its candidate lists: one that did not fit on ANY rank (massive
             // ties) shows in the fit's last all-reduce, on every rank alike, and the call is repeated with every histogram round
             if (r || !c->sf_overflow_seen || c->opt_select_rounds) return r;
@@ -1589,12 +1604,19 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         HIPCHK(c, hipMemsetAsync(c->d_carry, 0, sizeof(int32_t), c->stream));  // no size-factor select belongs to this call
         HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
         for (int t = 0; t < ntheta; t++) {
-            {
+            if (S <= 16 && c->opt_fuse_offsets) {
+                c->fuse.fm = d_fullMean;
+                c->fuse.sf = c->d_sf;
+                c->fuse.theta = thetas[t];
+                c->fuse.mix = 1;
+            } else {
                 Scope s(c, "offsets");
                 launch_offsets(d_fullMean, c->d_sf, n, S, thetas[t], 1, c->d_nf_tmp, c->stream);
             }
             chicdiff_nbglm_scalars sc;
-            if ((rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, o, nullptr, &sc))) return rc;
+            rc = fit_dev_impl(c, d_counts, c->d_nf_tmp, d, o, nullptr, &sc);
+            c->fuse = FusedOffsets();
+            if (rc) return rc;
             deviances_host[t] = sc.sumDeviance;
         }
         timing_collect(c);
@@ -1631,9 +1653,17 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
             if (!r) r = ensure_workspace(l, n, S);
             if (!r && hipMemcpyAsync(l->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, l->stream) != hipSuccess) r = CHICDIFF_E_HIP;
             for (int t = k; t < ntheta && !r; t += lanes) {
-                launch_offsets(d_fullMean, l->d_sf, n, S, thetas[t], 1, l->d_nf_tmp, l->stream);
+                if (S <= 16 && c->opt_fuse_offsets) {
+                    l->fuse.fm = d_fullMean;
+                    l->fuse.sf = l->d_sf;
+                    l->fuse.theta = thetas[t];
+                    l->fuse.mix = 1;
+                } else {
+                    launch_offsets(d_fullMean, l->d_sf, n, S, thetas[t], 1, l->d_nf_tmp, l->stream);
+                }
                 chicdiff_nbglm_scalars sc;
                 r = fit_dev_impl(l, d_counts, l->d_nf_tmp, d, o, nullptr, &sc);
+                l->fuse = FusedOffsets();
                 if (!r) deviances_host[t] = sc.sumDeviance;
             }
             lane_rc[k] = r;
@@ -1802,6 +1832,42 @@ extern "C" int chicdiff_hip_region_universe_fill_dev(chicdiff_hip_ctx *c, const 
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_collect(c);
+    return CHICDIFF_OK;
+}
+
+// both steps in one call (round 5): the caller gives room for the upper bound n max(2 RUexpand + 1, 2) rows, so that nothing on the host
+// stands between the scan and the fill — one synchronisation and one read-back instead of two of each
+extern "C" int chicdiff_hip_region_universe_dev(chicdiff_hip_ctx *c, const int32_t *d_bait, const int32_t *d_oe, int64_t n, int32_t RUexpand,
+                                                const int32_t *d_chr_of, int32_t maxfrag, int64_t *d_region_ptr, int32_t *d_minOE,
+                                                int32_t *d_maxOE, int32_t *d_ru_bait, int32_t *d_ru_region, int32_t *d_ru_oe,
+                                                int64_t capacity, int64_t *total_host) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_bait || !d_oe || !d_chr_of || !d_region_ptr || !d_ru_bait || !d_ru_region || !d_ru_oe || !total_host || n < 1 || RUexpand < 0 ||
+        RUexpand > (1 << 20) || maxfrag < 1)
+        return fail(c, CHICDIFF_E_INVALID, "region_universe: bad arguments");
+    // rows per peak: (oe - s):(oe + s) = 2 s + 1 — or, for RUexpand = 0 and a peak right beside its bait, R's DESCENDING (bait + 2):(oe + 0): two
+    const int64_t per_peak = RUexpand > 0 ? 2 * (int64_t)RUexpand + 1 : 2;
+    if (capacity < n * per_peak)
+        return fail(c, CHICDIFF_E_INVALID, "region_universe: room for n max(2 RUexpand + 1, 2) = %lld rows needed, %lld given",
+                    (long long)(n * per_peak), (long long)capacity);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t scan = ru_scan_bytes(n);
+    int rc = ensure_aux(c, 256 + scan);
+    if (rc) return rc;
+    int *bad = (int *)c->aux;
+    timing_reset(c);
+    {
+        Scope t(c, "region_universe");
+        if (launch_ru_count(d_bait, d_oe, n, RUexpand, d_chr_of, maxfrag, d_region_ptr, d_minOE, d_maxOE, bad, c->aux + 256, scan, c->stream))
+            return fail(c, CHICDIFF_E_HIP, "region_universe: scan failed");
+        launch_ru_fill(d_bait, d_oe, n, RUexpand, d_chr_of, maxfrag, d_region_ptr, d_ru_bait, d_ru_region, d_ru_oe, c->stream);
+    }
+    int h_bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(total_host, d_region_ptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    if (h_bad) return fail(c, CHICDIFF_E_INVALID, "region_universe: Invalid parameters (a peak with baitID == oeID)");
     return CHICDIFF_OK;
 }
 

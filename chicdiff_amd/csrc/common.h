@@ -64,7 +64,11 @@ struct Opts {
 };
 
 // ---- launchers (defined in the .hip files; all enqueue on `st` and never synchronise) -------
-void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);
+// fm != NULL (S <= 16): the offsets are formed here, from FullMean — sc(theta) of chicdiff.R:1635-1638 / M3 of :1583-1589, the very
+// function offsets16_kernel runs — written to `nf` (the stages behind read them from there) and used at once: one read and one
+// launch less than offsets + prep (round 5)
+struct FusedOffsets { const double *fm = nullptr; const double *sf = nullptr; double theta = 0; int mix = 0; };
+void launch_prep(const int32_t *counts, double *nf, FitDims d, FitWork w, Opts o, hipStream_t st, FusedOffsets fo = FusedOffsets());
 void launch_prep_finish(FitDims d, FitWork w, double *slot, hipStream_t st);  // partials -> colsum, nnz (slot: as (hi, lo) pairs into this rank's slot instead)
 void launch_xim(FitDims d, FitWork w, const double *slots, int world, hipStream_t st);  // (the ranks' slots ->) colsum -> xim
 void launch_disp_gene(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st);

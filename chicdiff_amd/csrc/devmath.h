@@ -393,4 +393,45 @@ __device__ __forceinline__ double pnorm_two_sided(double z) {
     return 2.0 * (exp(-xsq * xsq * 0.5) * exp(-del * 0.5) * temp);
 }
 
+
+// log() of an R double as the offsets need it: NA / zero / negative / subnormal values take the library path (NaN, -Inf: what R's log()
+// gives and the NA-row rule of chicdiff.R:1588 reads), the common positive case the table logarithm
+__device__ __forceinline__ double rlog_t(double x, const LogEntry *lt) { return (x > 2.3e-308 && x < 1.7e308) ? tlog(x, lt) : log(x); }
+// a4 — one row of the offsets (chicdiff.R:1583-1589 M3, :1635-1638 / :1666-1669 the theta mix): v[0..S) = FullMean in, the
+// normalisation factors out.  Shared by offsets16_kernel and by prep16_kernel's fused form (global_kernels.hip / disp_kernels.hip),
+// so that the two produce the same bits.  S <= 16; sf: the size factors (nullSizeFactors), wave-uniform loads.
+__device__ __forceinline__ void offsets_row16(double (&v)[16], int S, const double *__restrict__ sf, double theta, int mix, const LogEntry *lt) {
+    const double iS = 1.0 / S;
+    double sl = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (j < S) sl += rlog_t(v[j], lt);
+    const double gmean = exp(sl * iS);
+    const double ig = (gmean > 1e-300 && gmean < 1e300) ? rcp(gmean) : 1.0 / gmean;
+    bool anyna = false;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (j < S) {
+            v[j] = v[j] * ig;
+            anyna |= (v[j] != v[j]);
+        }
+    double sl2 = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (j < S) {
+            if (anyna) v[j] = sf[j];
+            if (mix) {
+                v[j] = v[j] * (1 - theta) + sf[j] * theta;
+                sl2 += rlog_t(v[j], lt);
+            }
+        }
+    if (mix) {
+        const double g2 = exp(sl2 * iS);
+        const double i2 = (g2 > 1e-300 && g2 < 1e300) ? rcp(g2) : 1.0 / g2;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < S) v[j] = v[j] * i2;
+    }
+}
+
 }  // namespace cd

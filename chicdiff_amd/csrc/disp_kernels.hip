@@ -64,8 +64,11 @@ __device__ __forceinline__ void prep_store(FitDims d, FitWork w, int64_t i, doub
 // through an LDS tile (row pitch + 1 dword: conflict-free both ways) and leave as one contiguous run of 16-byte stores.
 // (Measured, 2 M x 8: with every thread storing its own row straight to global memory — 16 partial-line stores per row — the
 // pass took 0.47 ms instead of 0.12; through the tile it is 0.19 ms, and the three row-queue kernels gain 0.46 ms.)
+template <bool FUSED>
 __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__ counts,
-                                                     const double *__restrict__ nf, FitDims d, FitWork w) {
+                                                     double *__restrict__ nf, FitDims d, FitWork w, FusedOffsets fo) {
+    __shared__ LogEntry s_lt[FUSED ? 64 : 1];
+    if (FUSED) log_table_to_lds(s_lt);
     extern __shared__ uint32_t s_tile[];  // T rows x (stride / 4 + 1) dwords, T = blockDim.x (256, or 128 when a row is longer than 128 bytes)
     __shared__ DD s_part[256];            // column sums of the tile by row group: [group][column]
     __shared__ unsigned char s_live[256]; // row of the tile is not all zero
@@ -90,12 +93,21 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
             uint32_t *row = s_tile + tid * ldw;
             for (int k = 4; k < 8; k++) row[k] = 0;                           // second half of the header (start values: the kernels' init passes)
             for (int k = 8 + 3 * S; k < (int)(stride / 4); k++) row[k] = 0;  // the pad behind the row
+            double fv[16];
+            if (FUSED) {  // the row's normalisation factors from FullMean (offsets_row16: the function offsets16_kernel runs)
+#pragma unroll
+                for (int j = 0; j < 16; j++) fv[j] = j < S ? fo.fm[(int64_t)j * n + i] : 1.0;
+                offsets_row16(fv, S, fo.sf, fo.theta, fo.mix, s_lt);
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (j < S) nf[(int64_t)j * n + i] = fv[j];
+            }
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 q[j] = 0;
                 if (j < S) {
                     const int32_t k = counts[(int64_t)j * n + i];
-                    const double f = nf[(int64_t)j * n + i];
+                    const double f = FUSED ? fv[j] : nf[(int64_t)j * n + i];
                     row[8 + 2 * j] = (uint32_t)__double2loint(f);
                     row[8 + 2 * j + 1] = (uint32_t)__double2hiint(f);
                     row[8 + 2 * S + j] = (uint32_t)k;
@@ -251,10 +263,11 @@ __global__ void xim_kernel(FitDims d, FitWork w, const double *slots, int world)
 
 constexpr int kColsumBlocks = 512;  // per column; (S+1) x 512 partials fit the 1024 x 72 partials buffer for S <= 64
 static int prep16_blocks(int) { return 1024; }  // four workgroups per CU — what their LDS tiles (34-38 KB) allow at once: one full round, no tail (768: 0.148 -> 0.127 ms at 2 M x 8, 1280: 0.163; S = 16: 1536 -> 1024: 0.40 -> 0.32, 2048: 0.33; round 4); (S + 1) x 1024 partials
-void launch_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts, hipStream_t st) {
+void launch_prep(const int32_t *counts, double *nf, FitDims d, FitWork w, Opts, hipStream_t st, FusedOffsets fo) {
     if (d.S <= 16) {  // one resident round: 3 workgroups of 256 per CU; the LDS tile stays under 34 KB; the column sums ride along
         const int T = row_stride(d.S) > 128 ? 128 : 256;
-        prep16_kernel<<<prep16_blocks(d.S), T, (size_t)T * (row_stride(d.S) + 4), st>>>(counts, nf, d, w);
+        if (fo.fm) prep16_kernel<true><<<prep16_blocks(d.S), T, (size_t)T * (row_stride(d.S) + 4), st>>>(counts, nf, d, w, fo);
+        else prep16_kernel<false><<<prep16_blocks(d.S), T, (size_t)T * (row_stride(d.S) + 4), st>>>(counts, nf, d, w, fo);
     } else {
         prep_kernel<<<kRedBlocks, 256, 0, st>>>(counts, nf, d, w);
         colsum_kernel<<<dim3(kColsumBlocks, d.S + 1), 256, 0, st>>>(nf, d, w);

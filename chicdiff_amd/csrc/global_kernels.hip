@@ -1278,7 +1278,6 @@ void launch_row_ratio(const int32_t *counts, int64_t n, int S, double *ratio, in
 // larger S re-reads the row from L1/L2.  log() keeps R's semantics for NA/0/negative inputs, the
 // common positive-finite case takes the cheaper flog().
 __device__ __forceinline__ double rlog(double x) { return (x > 0.0 && x < 1.7e308) ? flog(x) : log(x); }
-__device__ __forceinline__ double rlog_t(double x, const LogEntry *lt) { return (x > 2.3e-308 && x < 1.7e308) ? tlog(x, lt) : log(x); }
 
 // 2 S logarithms, 2 exponentials and 2 S quotients per row sit beside 16 S bytes of traffic: the kernel is only
 // HBM-bound if that arithmetic is lean — table-driven log (devmath.h tlog, 1 KB table in LDS) and one reciprocal per
@@ -1288,42 +1287,14 @@ __global__ __launch_bounds__(256) void offsets16_kernel(const double *__restrict
                                                         double *__restrict__ out) {
     __shared__ LogEntry s_lt[64];
     log_table_to_lds(s_lt);
-    const double iS = 1.0 / S;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double v[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] = j < S ? fm[(int64_t)j * n + i] : 1.0;
-        double sl = 0;
+        offsets_row16(v, S, sf, theta, mix, s_lt);
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            if (j < S) sl += rlog_t(v[j], s_lt);
-        const double gmean = exp(sl * iS);
-        const double ig = (gmean > 1e-300 && gmean < 1e300) ? rcp(gmean) : 1.0 / gmean;
-        bool anyna = false;
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            if (j < S) {
-                v[j] = v[j] * ig;
-                anyna |= (v[j] != v[j]);
-            }
-        double sl2 = 0;
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            if (j < S) {
-                if (anyna) v[j] = sf[j];
-                if (mix) {
-                    v[j] = v[j] * (1 - theta) + sf[j] * theta;
-                    sl2 += rlog_t(v[j], s_lt);
-                }
-            }
-        double i2 = 1.0;
-        if (mix) {
-            const double g2 = exp(sl2 * iS);
-            i2 = (g2 > 1e-300 && g2 < 1e300) ? rcp(g2) : 1.0 / g2;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            if (j < S) out[(int64_t)j * n + i] = mix ? v[j] * i2 : v[j];
+            if (j < S) out[(int64_t)j * n + i] = v[j];
     }
 }
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "chicdiff_hip_set_allreduce", "chicdiff_hip_set_allgather", "chicdiff_hip_last_refits", "chicdiff_hip_set_option", "chicdiff_hip_default_opts", "chicdiff_hip_size_factors_dev",
     "chicdiff_hip_offsets_dev", "chicdiff_hip_window_sums_dev", "chicdiff_hip_count_join_dev",
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
-    "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_count_table_dev",
+    "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_region_universe_dev", "chicdiff_hip_count_table_dev",
     "chicdiff_hip_chinput_read", "chicdiff_hip_chinput_table_dev", "chicdiff_hip_region_avdist_dev",
     "chicdiff_hip_count_join_inner_dev",
     "chicdiff_hip_malloc", "chicdiff_hip_free", "chicdiff_hip_outstanding_allocations", "chicdiff_hip_memcpy_h2d", "chicdiff_hip_memcpy_d2h",
@@ -131,6 +131,7 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_ihw_apply_dev.argtypes = [vp, vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl), i32, vp, vp, vp, vp]
     L.chicdiff_hip_region_universe_count_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, C.POINTER(i64)]
     L.chicdiff_hip_region_universe_fill_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, vp]
+    L.chicdiff_hip_region_universe_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.chicdiff_hip_nbglm_fit_dev.argtypes = [vp, vp, vp, i64, i32, C.POINTER(i32), C.POINTER(Opts), C.POINTER(Out),
                                              C.POINTER(Scalars)]
     L.chicdiff_hip_nbglm_fit.argtypes = L.chicdiff_hip_nbglm_fit_dev.argtypes
@@ -448,16 +449,13 @@ class HipContext:
         ptr = torch.empty(n + 1, dtype=torch.int64, device=self.device)
         mn, mx = (torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(2))
         total = C.c_int64(0)
-        self._check(self.lib.chicdiff_hip_region_universe_count_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), n, int(RUexpand),
-                                                                    d_chr_of.data_ptr(), maxfrag, ptr.data_ptr(), mn.data_ptr(),
-                                                                    mx.data_ptr(), C.byref(total)))
-        self.last_region_universe_ms = self.kernel_times().get("region_universe", (0.0, 0))[0]  # (count + scan; the fill is added below)
-        rb, rr, ro = (torch.empty(max(total.value, 1), dtype=torch.int32, device=self.device)[: total.value] for _ in range(3))
-        if total.value:
-            self._check(self.lib.chicdiff_hip_region_universe_fill_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), n, int(RUexpand),
-                                                                       d_chr_of.data_ptr(), maxfrag, ptr.data_ptr(), rb.data_ptr(),
-                                                                       rr.data_ptr(), ro.data_ptr()))
-            self.last_region_universe_ms += self.kernel_times().get("region_universe", (0.0, 0))[0]
+        cap = n * max(2 * int(RUexpand) + 1, 2)   # the upper bound (two for RUexpand = 0: R's descending a:b beside a bait): scan and fill in one call (round 5)
+        rb, rr, ro = (torch.empty(max(cap, 1), dtype=torch.int32, device=self.device) for _ in range(3))
+        self._check(self.lib.chicdiff_hip_region_universe_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), n, int(RUexpand), d_chr_of.data_ptr(),
+                                                              maxfrag, ptr.data_ptr(), mn.data_ptr(), mx.data_ptr(), rb.data_ptr(), rr.data_ptr(),
+                                                              ro.data_ptr(), cap, C.byref(total)))
+        self.last_region_universe_ms = self.kernel_times().get("region_universe", (0.0, 0))[0]
+        rb, rr, ro = rb[: total.value], rr[: total.value], ro[: total.value]
         return dict(region_ptr=ptr, minOE=mn, maxOE=mx, baitID=rb, regionID=rr, otherEndID=ro)
 
     # -- a6 + a7 ----------------------------------------------------------------------------

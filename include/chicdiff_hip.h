@@ -315,6 +315,13 @@ int chicdiff_hip_region_universe_fill_dev(chicdiff_hip_ctx *ctx, const int32_t *
                                           int32_t RUexpand, const int32_t *d_chr_of, int32_t maxfrag,
                                           const int64_t *d_region_ptr, int32_t *d_ru_bait, int32_t *d_ru_region,
                                           int32_t *d_ru_oe);
+/* ... both in ONE call: the caller gives room for the upper bound `capacity` >= n max(2 RUexpand + 1, 2) rows in the three row vectors
+ * (the first *total_host of them are written; two rows per peak for RUexpand = 0: R's descending (bait + 2):(oe + 0) beside a bait,
+ * chicdiff.R:359-363), so that nothing on the host stands between the scan and the fill. */
+int chicdiff_hip_region_universe_dev(chicdiff_hip_ctx *ctx, const int32_t *d_baitID, const int32_t *d_oeID, int64_t n, int32_t RUexpand,
+                                     const int32_t *d_chr_of, int32_t maxfrag, int64_t *d_region_ptr, int32_t *d_minOE,
+                                     int32_t *d_maxOE, int32_t *d_ru_baitID, int32_t *d_ru_regionID, int32_t *d_ru_otherEndID,
+                                     int64_t capacity, int64_t *total_host);
 
 /* a6 + a7 — estimateDispersions + nbinomWaldTest (chicdiff.R:1573-1574, 1602-1603, 1643-1644,
  * 1673-1674) for design ~condition (group[j] in {0,1}, both present) or ~1 (all group[j]==0).
@@ -372,8 +379,9 @@ typedef struct {
     double bytes; /* "allreduce" / "allgather" (timing mode 1): payload this rank handed to the transport; 0 for kernels */
 } chicdiff_kernel_time;
 int32_t chicdiff_hip_kernel_times(chicdiff_hip_ctx *ctx, chicdiff_kernel_time *out, int32_t cap);
-/* on: 0 = off, 1 = every stage of a call gets an event pair, 2 = only the three fit kernels (disp_gene, disp_map, wald_irls):
- * an event pair costs ~2 us on the stream and again on the host, 0.09 ms per fit with all ~20 stages bracketed */
+/* on: 0 = off, 1 = every stage of a call gets an event pair, 2 = only the three fit kernels (disp_gene, disp_map, wald_irls),
+ * 3 = the gene-wise line search alone: an event pair is a packet pair on the stream — ~12 us of a 1.3 ms fit per bracketed
+ * stage, 0.09 ms per fit with all ~20 stages bracketed */
 int chicdiff_hip_enable_timing(chicdiff_hip_ctx *ctx, int32_t on);
 
 #ifdef __cplusplus

@@ -1049,8 +1049,9 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
 
 
 def test_kernel_timing_modes(ctx):
-    """chicdiff_hip_enable_timing: 1 brackets every stage of a call with HIP events, 2 only the three fit kernels (what bench.py's
-    timed region uses), 0 nothing; the results do not depend on it."""
+    """chicdiff_hip_enable_timing: 1 brackets every stage of a call with HIP events, 2 only the three fit kernels, 3 the gene-wise
+    line search alone (what bench.py's timed region uses), 0 nothing; the results do not depend on it.  Since round 5 the fused call
+    forms the offsets inside `prep` (option fuse_offsets = 0: a launch of their own, as the composed calls make it) — same bits."""
     d = synth.make(20000, 8)
     dk = ctx.to_device(d["counts"], np.int32)
     dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / 8), np.float64)
@@ -1062,18 +1063,42 @@ def test_kernel_timing_modes(ctx):
         ctx.enable_timing(2)
         b, _ = ctx.wald_test(dk, dfm, d["group"], theta=0.5, want=want)
         fit = ctx.kernel_times()
+        ctx.enable_timing(3)
+        b3, _ = ctx.wald_test(dk, dfm, d["group"], theta=0.5, want=want)
+        fit3 = ctx.kernel_times()
+        ctx.enable_timing(1)
+        ctx.set_option("fuse_offsets", 0)
+        u, _ = ctx.wald_test(dk, dfm, d["group"], theta=0.5, want=want)
+        unfused = ctx.kernel_times()
     finally:
         ctx.enable_timing(0)
+        ctx.set_option("fuse_offsets", 1)
     c, _ = ctx.wald_test(dk, dfm, d["group"], theta=0.5, want=want)
-    # (the median / MAD of the residuals is taken inside the trend kernel since round 4: no "mad_select" stage of its own)
-    for name in ("size_factors", "offsets", "prep", "disp_gene", "trend_fit", "disp_map", "wald_prep", "wald_irls", "wald_final"):
+    # (the median / MAD of the residuals is taken inside the trend kernel since round 4: no "mad_select" stage of its own; the offsets
+    # inside prep since round 5: no "offsets" stage unless asked for)
+    for name in ("size_factors", "prep", "disp_gene", "trend_fit", "disp_map", "wald_prep", "wald_irls", "wald_final"):
         assert name in full and full[name][0] > 0 and full[name][1] == 1, name
+    assert full.get("offsets", (0.0, 0))[1] == 0 and unfused["offsets"][1] == 1 and unfused["offsets"][0] > 0
     timed = {k for k, (ms, launches) in fit.items() if launches > 0}
     assert timed == {"disp_gene", "disp_map", "wald_irls"}, timed
     assert all(fit[k][0] > 0 for k in timed)
+    assert {k for k, (ms, launches) in fit3.items() if launches > 0} == {"disp_gene"} and fit3["disp_gene"][0] > 0
+    # NA rows take the size factors (chicdiff.R:1588-1589): a few of them, through both forms
+    fm_na = dfm.clone()
+    fm_na[3, 17] = float("nan")
+    fm_na[0, 19999] = float("nan")
+    na1, _ = ctx.wald_test(dk, fm_na, d["group"], theta=0.25, want=want)
+    ctx.set_option("fuse_offsets", 0)
+    try:
+        na0, _ = ctx.wald_test(dk, fm_na, d["group"], theta=0.25, want=want)
+    finally:
+        ctx.set_option("fuse_offsets", 1)
     for k in want:
         assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=True)
+        assert np.array_equal(a[k].cpu().numpy(), b3[k].cpu().numpy(), equal_nan=True)
         assert np.array_equal(a[k].cpu().numpy(), c[k].cpu().numpy(), equal_nan=True)
+        assert np.array_equal(a[k].cpu().numpy(), u[k].cpu().numpy(), equal_nan=True), f"{k}: offsets inside prep and as a launch of their own differ"
+        assert np.array_equal(na1[k].cpu().numpy(), na0[k].cpu().numpy(), equal_nan=True), f"{k}: ... with NA rows"
 
 
 def test_bh_on_device(ctx, oracle):
