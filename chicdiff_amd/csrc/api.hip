@@ -44,6 +44,7 @@ struct chicdiff_hip_ctx {
     int device = 0;
     bool no_persistent_trend = false;  // set after a grid-barrier timeout (see fit_dev_impl)
     // tuning / test options (chicdiff_hip_set_option); the defaults are what the benchmarks run
+    int opt_chunk = 0;  // line search: rows per dequeue (0 = automatic)
     int opt_spread = 1, opt_min_waves = 2, opt_select_rounds = 0, opt_trend_multilaunch = 0, opt_schedule = 1, opt_deal = 0;
     int opt_trend_gather = 1;  // sharded fits: gather the rows of the trend on every rank (two collectives) instead of one all-reduce per IRLS pass
     char *tg_buf = nullptr;    // ... the gathered rows (grow-only)
@@ -63,7 +64,7 @@ struct chicdiff_hip_ctx {
     // set by an entry point for the fit it is about to make (d_nf = d_nf_tmp): the offsets are formed from FullMean inside the fit's
     // first kernel instead of by a launch of their own (common.h FusedOffsets); cleared when the fit returns
     FusedOffsets fuse;
-    int opt_fuse_offsets = 1;  // (option "fuse_offsets": 0 = offsets as a launch of their own, for the bit-identity test)
+    int opt_fuse_offsets = 1;  // (option "fuse_offsets": 0 = offsets always as a launch of their own, 2 = always inside prep: the bit-identity test)
     // bench hook (option "bench_fake_world", a 1-rank communicator only): the trend's rows are gathered as if N ranks had each sent
     // this rank's block — the single-launch trend + MAD kernel then runs on N x n rows, which is what EVERY rank of an N-GPU fit
     // does (bench.py's rehearsal of a rank's step at its share of the rows; the coefficients are those of the n rows up to rounding)
@@ -131,6 +132,7 @@ struct chicdiff_hip_ctx {
 };
 
 static char g_create_err[512];
+constexpr int64_t kFuseOffsetsMaxRows = 1 << 18;  // fits up to this many rows form their offsets inside prep (see wald_test_dev)
 
 // simulated residual densities + loess operator of one d.f. (prior_mc.h): constants, built once per process
 static const PmcTable &pmc_table(int df) {
@@ -182,6 +184,7 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     const std::string k(name);
     if (k == "line_search_spread" && value >= 0 && value <= 2) c->opt_spread = (int)value;  // 2: samples across lanes without the lean tick of the launch's end (bit-identity tests)
     else if (k == "line_search_min_waves" && value >= 2 && value <= 4) c->opt_min_waves = (int)value;
+    else if (k == "line_search_chunk" && (value == 0 || (value >= 8 && value <= 64))) c->opt_chunk = (int)value;
     else if (k == "line_search_schedule" && (value == 0 || value == 1)) c->opt_schedule = (int)value;
     else if (k == "line_search_deal" && value >= 0 && value <= 64) c->opt_deal = (int)value;
     else if (k == "local_trend_substitute" && (value == 0 || value == 1)) c->opt_no_local_substitute = value ? 0 : 1;
@@ -192,7 +195,7 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     else if (k == "trend_one_launch_per_pass" && (value == 0 || value == 1)) c->opt_trend_multilaunch = (int)value;
     else if (k == "fault_inject" && value >= 0 && value <= 7) c->opt_fault = (int)value;
     else if (k == "trend_persistent_blocks" && value >= 0 && value <= 256) c->opt_trend_blocks = (int)value;
-    else if (k == "fuse_offsets" && (value == 0 || value == 1)) c->opt_fuse_offsets = (int)value;
+    else if (k == "fuse_offsets" && value >= 0 && value <= 2) c->opt_fuse_offsets = (int)value;
     else if (k == "bench_fake_world" && value >= 0 && value <= kGatherMaxWorld) c->opt_fake_world = (int)value;
     else if (k == "trend_mad_in_kernel" && (value == 0 || value == 1)) c->opt_mad_in_kernel = (int)value;
     else return fail(c, CHICDIFF_E_INVALID, "set_option: unknown option or value (%s = %lld)", name, (long long)value);
@@ -735,6 +738,7 @@ static Opts make_opts(const chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *in, 
     r.min_waves = c->opt_min_waves;
     r.schedule = c->opt_schedule;
     r.deal = c->opt_deal;
+    r.chunk = c->opt_chunk;
     r.trend_blocks = c->opt_trend_blocks;
     return r;
 }
@@ -1463,7 +1467,10 @@ int chicdiff_hip_wald_test_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, con
             int r = size_factors_impl(c, d_counts, n, S);
             if (r) return r;
             const int mix = theta == theta;
-            if (d_fullMean && S <= 16 && c->opt_fuse_offsets) {  // the offsets are formed inside the fit's first kernel
+            // the offsets formed inside the fit's first kernel — where a launch is worth more than the arithmetic: measured (round 5), offsets +
+            // prep against the fused prep: 18.5 + 28 -> 47 us at 250 k x 8 (and one launch, ~5 us + its gap, less), 30 + 40 -> 76 at 500 k,
+            // 67 + 130 -> 291 at 2 M (the fused kernel carries 2 S logarithms per row at the four waves per SIMD its LDS tiles allow)
+            if (d_fullMean && S <= 16 && c->opt_fuse_offsets && (c->opt_fuse_offsets == 2 || n <= kFuseOffsetsMaxRows)) {
                 c->fuse.fm = d_fullMean;
                 c->fuse.sf = c->d_sf;
                 c->fuse.theta = mix ? theta : 0.0;
@@ -1604,7 +1611,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         HIPCHK(c, hipMemsetAsync(c->d_carry, 0, sizeof(int32_t), c->stream));  // no size-factor select belongs to this call
         HIPCHK(c, hipMemcpyAsync(c->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
         for (int t = 0; t < ntheta; t++) {
-            if (S <= 16 && c->opt_fuse_offsets) {
+            if (S <= 16 && c->opt_fuse_offsets && (c->opt_fuse_offsets == 2 || n <= kFuseOffsetsMaxRows)) {
                 c->fuse.fm = d_fullMean;
                 c->fuse.sf = c->d_sf;
                 c->fuse.theta = thetas[t];
@@ -1633,6 +1640,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         l->opt_min_waves = c->opt_min_waves;
         l->opt_schedule = c->opt_schedule ? 2 : 0;  // concurrent fits: class order through the queue, nothing dealt out statically
         l->opt_deal = c->opt_deal;
+        l->opt_chunk = c->opt_chunk;
         l->opt_no_local_substitute = c->opt_no_local_substitute;
         l->opt_trend_gather = c->opt_trend_gather;
         l->opt_select_rounds = c->opt_select_rounds;
@@ -1653,7 +1661,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
             if (!r) r = ensure_workspace(l, n, S);
             if (!r && hipMemcpyAsync(l->d_sf, sf_host, sizeof(double) * S, hipMemcpyHostToDevice, l->stream) != hipSuccess) r = CHICDIFF_E_HIP;
             for (int t = k; t < ntheta && !r; t += lanes) {
-                if (S <= 16 && c->opt_fuse_offsets) {
+                if (S <= 16 && c->opt_fuse_offsets && (c->opt_fuse_offsets == 2 || n <= kFuseOffsetsMaxRows)) {
                     l->fuse.fm = d_fullMean;
                     l->fuse.sf = l->d_sf;
                     l->fuse.theta = thetas[t];

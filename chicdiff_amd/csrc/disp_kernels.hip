@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
     if (!MAP && tile > 0) order_hist_store(mine, hist);
 }
 
-constexpr int kChunk = 64;   // rows a wave takes from the global queue per atomic
+constexpr int kChunk = 64;   // rows a wave takes from the global queue per atomic (at most: DispArgs::chunk)
 enum Phase : int { PH_NEED = 0, PH_INIT = 1, PH_SEARCH = 2, PH_GRID1 = 3, PH_GRID2 = 4, PH_DONE = 5 };
 
 // One row of FitWork::rowpack -> the lane's LDS column, with mu_j = max(nf_j * groupmean_g, minmu) formed on the way (what the
@@ -536,6 +536,7 @@ struct DispArgs {
     const int32_t *order;        // gene-wise launch: the schedule (order_*); NULL = rows 0..n-1 through the queue (MAP, option "line_search_schedule" 0)
     int deal;                    // entries per group of the static deal (0 = by the number of entries per wave)
     int prefetch;                // 1 = warm the cache lines of the rows handed out next
+    int chunk;                   // rows per dequeue (<= kChunk)
 };
 // make ISA_MARK=1 (tools/isa_account.py): comment lines in the generated assembly that delimit the parts of a tick; a volatile asm
 // statement also keeps the compiler from moving code across it, so the marked build is for counting, not for running
@@ -880,6 +881,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     bool queue_empty = false;
     // the open chunk (wave-uniform): entries [chunk_pos, chunk_len) of it are still to be handed out; lane l holds the row of entry l
     uint32_t chunk_base = 0, chunk_pos = 0, chunk_len = 0;
+    const uint32_t chunk_rows = (uint32_t)A.chunk;
     int ord_reg = 0;
     bool touch = false;
     const int64_t rstride = row_stride(S);
@@ -1080,7 +1082,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     unsigned int kq = 0;
                     if (lane == 0) kq = (unsigned int)atomicAdd(heads + 8 * cur_head, 1ull);
                     kq = __builtin_amdgcn_readfirstlane(kq);
-                    b = nA + (kq * (uint32_t)kHeads + (uint32_t)cur_head) * (uint32_t)kChunk;
+                    b = nA + (kq * (uint32_t)kHeads + (uint32_t)cur_head) * chunk_rows;
                     if (b >= nTot) {  // this head is dry: on to the next one that is not known to be (uses up one attempt)
                         heads_left &= ~(1u << cur_head);
                         if (MAP)
@@ -1090,7 +1092,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                             }
                         continue;
                     }
-                    e = b + kChunk < nTot ? b + kChunk : nTot;
+                    e = b + chunk_rows < nTot ? b + chunk_rows : nTot;
                     chunk_base = b;
                     chunk_len = e - b;
                     chunk_pos = 0;
@@ -1160,18 +1162,26 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         })
 
         // ---- choose this tick's evaluation point -------------------------------------------
-        double a_eval = a;
-        if (phase == PH_SEARCH) {
-            iter++;
+        // (Round 5: written with selects, the rare cases behind wave-uniform tests.  A branch around a lane-dependent block makes the
+        // scalar unit wait for the vector compare — ~90 cycles for a lone wave, ~190 with the second wave of the bulk on the SIMD,
+        // profiles/r05_lone_wave_latency.txt — and the if / else-if chains over the six phases, here and in the state machine below,
+        // were a dozen of them per tick.  Same operations on the same operands: same bits.)
+        const bool in_search = phase == PH_SEARCH, in_init = phase == PH_INIT;
+        const bool in_grid = phase == PH_GRID1 || phase == PH_GRID2;
+        const unsigned long long gridmask = __ballot(in_grid);
+        iter += in_search ? 1 : 0;
+        {
             const double a_prop = a + kappa * dlp;
-            if (a_prop < -30.0) kappa = (-30.0 - a) / dlp;
-            if (a_prop > 10.0) kappa = (10.0 - a) / dlp;
-            a_new = a + kappa * dlp;
-            a_eval = a_new;
-        } else if (phase == PH_GRID1) {
-            a_eval = (gt == 19) ? ghi : glo + gt * gstep;
-        } else if (phase == PH_GRID2) {
-            a_eval = (gt == 19) ? ghat + gstep : (ghat - gstep) + gt * (2.0 * gstep / 19.0);
+            if (__ballot(in_search && (a_prop < -30.0 || a_prop > 10.0)) != 0ull) {  // (rare: the step leaves [-30, 10])
+                if (in_search && a_prop < -30.0) kappa = (-30.0 - a) / dlp;
+                if (in_search && a_prop > 10.0) kappa = (10.0 - a) / dlp;
+            }
+        }
+        a_new = in_search ? a + kappa * dlp : a_new;
+        double a_eval = in_search ? a_new : a;
+        if (gridmask != 0ull) {
+            if (phase == PH_GRID1) a_eval = (gt == 19) ? ghi : glo + gt * gstep;
+            else if (phase == PH_GRID2) a_eval = (gt == 19) ? ghat + gstep : (ghat - gstep) + gt * (2.0 * gstep / 19.0);
         }
 
         // ---- grid burst -------------------------------------------------------------------------
@@ -1183,7 +1193,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         bool helper = false;
         double pm_e = prior_mean;
         if (queue_empty && A.spread) {
-            const unsigned long long ingrid = __ballot(phase == PH_GRID1 || phase == PH_GRID2);
+            const unsigned long long ingrid = gridmask;
             const unsigned long long idle = __ballot(phase == PH_DONE);
             if (ingrid && idle) {
                 burst_owner = __ffsll((long long)ingrid) - 1;
@@ -1264,75 +1274,70 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
 
         // ---- advance the per-lane state machine ---------------------------------------------
         MARK("tick:burst_reduce_end");
-        bool finished = false;  // line search over: decide between result and grid fallback
         double result = 0;
         bool have_result = false;
-        if (phase == PH_INIT) {
-            lp = l_new;
-            dlp = dl_new;
-            init_lp = l_new;
-            alpha_cur = alpha_new;  // exp(a), kept so that finishing needs no further exp()
-            kappa = o.kappa0;
-            iter = 0;
-            iacc = 0;
-            phase = PH_SEARCH;
-        } else if (phase == PH_SEARCH) {
-            const double theta_kappa = -l_new;
-            const double theta_hat_kappa = -lp - kappa * 1.0e-4 * dlp * dlp;
-            if (theta_kappa <= theta_hat_kappa) {
-                iacc++;
-                a = a_new;
-                alpha_cur = alpha_new;
-                const double change = l_new - lp;
-                if (change < o.dispTol) {
-                    lp = l_new;
-                    finished = true;
-                } else if (a < min_log_alpha) {
-                    finished = true;
-                } else {
-                    lp = l_new;
-                    dlp = dl_new;
-                    kappa = fmin(kappa * 1.1, o.kappa0);
-                    if (iacc % 5 == 0) kappa *= 0.5;
-                }
-            } else {
-                kappa *= 0.5;
-                DIAG(if (lg_t >= 0) rej_spread++; else if (!queue_empty) rej_bulk++;)
-            }
-            DIAG(if (lg_t >= 0) srch_spread++; else if (!queue_empty) srch_bulk++;)
-            if (!finished && iter >= o.maxit) finished = true;
+        // a lane that entered this tick at its start point (in_init) or inside its line search (in_search): the update as selects
+        const double theta_kappa = -l_new;
+        const double theta_hat_kappa = -lp - kappa * 1.0e-4 * dlp * dlp;
+        const bool acc = in_search && theta_kappa <= theta_hat_kappa;
+        const double change = l_new - lp;
+        const bool fin_tol = acc && change < o.dispTol;
+        const bool fin_low = acc && !fin_tol && a_new < min_log_alpha;
+        const bool go_on = acc && !fin_tol && !fin_low;
+        iacc += acc ? 1 : 0;
+        a = acc ? a_new : a;
+        alpha_cur = (acc || in_init) ? alpha_new : alpha_cur;  // (start point: exp(a), kept so that finishing needs no further exp())
+        lp = ((acc && !fin_low) || in_init) ? l_new : lp;
+        dlp = (go_on || in_init) ? dl_new : dlp;
+        init_lp = in_init ? l_new : init_lp;
+        {
+            double k_acc = fmin(kappa * 1.1, o.kappa0);
+            if (iacc % 5 == 0) k_acc *= 0.5;
+            kappa = in_init ? o.kappa0 : (go_on ? k_acc : ((in_search && !acc) ? kappa * 0.5 : kappa));
+        }
+        DIAG(if (in_search) { if (lg_t >= 0) { srch_spread++; if (!acc) rej_spread++; } else if (!queue_empty) { srch_bulk++; if (!acc) rej_bulk++; } })
+        const bool finished = in_search && (fin_tol || fin_low || iter >= o.maxit);  // line search over: result, or the grid fallback
+        iter = in_init ? 0 : iter;
+        iacc = in_init ? 0 : iacc;
+        phase = in_init ? (int)PH_SEARCH : phase;
+        if (__ballot(finished) != 0ull) {
             if (finished) search_over(result, have_result);
-        } else if (phase == PH_GRID1 || phase == PH_GRID2) {
-            if (burst_done) {  // points gt .. gt+nhelp at once; an earlier point keeps a tie (strict >, as one by one)
-                if (l_new > gbest) {
-                    gbest = l_new;
-                    gbi = hk;
-                }
-                gt += nhelp + 1;
-            } else {
-                if (l_new > gbest) {
-                    gbest = l_new;
-                    gbi = gt;
-                }
-                gt++;
-            }
-            if (gt == 20) {
-                if (phase == PH_GRID1) {
-                    ghat = (gbi == 19) ? ghi : glo + gbi * gstep;
-                    phase = PH_GRID2;
-                    gt = 0;
-                    gbest = -INFINITY;
-                    gbi = 0;
+        }
+        if (gridmask != 0ull) {
+            if (in_grid) {  // (the lanes that were inside a grid stage when the tick began: one that has just entered is not)
+                if (burst_done) {  // points gt .. gt+nhelp at once; an earlier point keeps a tie (strict >, as one by one)
+                    if (l_new > gbest) {
+                        gbest = l_new;
+                        gbi = hk;
+                    }
+                    gt += nhelp + 1;
                 } else {
-                    const double fa = (gbi == 19) ? ghat + gstep : (ghat - gstep) + gbi * (2.0 * gstep / 19.0);
-                    result = exp(fa);
-                    have_result = true;
+                    if (l_new > gbest) {
+                        gbest = l_new;
+                        gbi = gt;
+                    }
+                    gt++;
+                }
+                if (gt == 20) {
+                    if (phase == PH_GRID1) {
+                        ghat = (gbi == 19) ? ghi : glo + gbi * gstep;
+                        phase = PH_GRID2;
+                        gt = 0;
+                        gbest = -INFINITY;
+                        gbi = 0;
+                    } else {
+                        const double fa = (gbi == 19) ? ghat + gstep : (ghat - gstep) + gbi * (2.0 * gstep / 19.0);
+                        result = exp(fa);
+                        have_result = true;
+                    }
                 }
             }
         }
-        if (have_result) {
-            store_result(result);
-            phase = PH_NEED;
+        if (__ballot(have_result) != 0ull) {
+            if (have_result) {
+                store_result(result);
+                phase = PH_NEED;
+            }
         }
         MARK("tick:state_machine_end");
         DIAG(if (sp_on) { cy_sp[8] += __builtin_amdgcn_s_memtime() - sp_t6; sp_on = false; })
@@ -1396,7 +1401,7 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     // grid's lanes) keeps the class order but deals nothing out statically — its waves are not all resident at once, and a wave
     // that starts late must not be the owner of likely-long rows
     if (sched) launch_order_build(d, w, o.schedule == 2 ? 0 : kSchedClassesA, true, st);
-    DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, o.deal, 1};
+    DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, o.deal, 1, kChunk};
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks
     int threads = 128;
@@ -1428,6 +1433,15 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
         (void)hipMemsetAsync(A.stamps, 0, stamp_words * 8, st);
     }
 #endif
+    // rows per dequeue: 64 — unless a wave's share of the rows is about ONE such chunk (the reference's own data set: 30 k rows on
+    // 470 waves): the queue then balances nothing, and which wave gets its chunk last decides which leaves last.  Then 16 at a time:
+    // gene-wise 0.313 -> 0.300 ms, MAP 0.084 -> 0.076 at 30 k x 4.  Not beyond: at 200 k rows 16-row chunks cost 0.424 -> 0.525 ms (the
+    // one queue head saturates near 90 dequeues per us, and every dequeue is a refill on cold lines): profiles/r05_ab_queue_chunk.txt
+    // (option "line_search_chunk" overrides)
+    {
+        const int64_t per_wave = d.n / (blocks * waves_per_block > 0 ? blocks * waves_per_block : 1);
+        A.chunk = o.chunk > 0 ? o.chunk : (per_wave < 96 ? 16 : kChunk);
+    }
     const int variant = min_waves;
 #define LAUNCH(M, W) disp_fit_kernel<M, W><<<(unsigned)blocks, threads, lds, st>>>(A)
     if (map) {

@@ -1035,6 +1035,13 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
             deals[deal] = run()
         finally:
             ctx.set_option("line_search_deal", 0)
+    # rows per dequeue (64; 16 when a wave's share of the rows is about one chunk): any size gives the same bits
+    for ch in (8, 24):
+        ctx.set_option("line_search_chunk", ch)
+        try:
+            deals[f"chunk {ch}"] = run()
+        finally:
+            ctx.set_option("line_search_chunk", 0)
     assert (a["dispGeneIter"] >= 100).sum() > 10  # the stragglers this is about are present
     for deal, f in deals.items():
         for k in a:
@@ -1051,7 +1058,8 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
 def test_kernel_timing_modes(ctx):
     """chicdiff_hip_enable_timing: 1 brackets every stage of a call with HIP events, 2 only the three fit kernels, 3 the gene-wise
     line search alone (what bench.py's timed region uses), 0 nothing; the results do not depend on it.  Since round 5 the fused call
-    forms the offsets inside `prep` (option fuse_offsets = 0: a launch of their own, as the composed calls make it) — same bits."""
+    forms the offsets inside `prep` for fits of up to 262 144 rows (option fuse_offsets = 0: always a launch of their own, as the
+    composed calls make it; 2: always inside prep) — same bits."""
     d = synth.make(20000, 8)
     dk = ctx.to_device(d["counts"], np.int32)
     dfm = ctx.to_device(d["nf"] * (d["mu"][:, None] / 8), np.float64)
