@@ -1437,11 +1437,9 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     // 470 waves): the queue then balances nothing, and which wave gets its chunk last decides which leaves last.  Then 16 at a time:
     // gene-wise 0.313 -> 0.300 ms, MAP 0.084 -> 0.076 at 30 k x 4.  Not beyond: at 200 k rows 16-row chunks cost 0.424 -> 0.525 ms (the
     // one queue head saturates near 90 dequeues per us, and every dequeue is a refill on cold lines): profiles/r05_ab_queue_chunk.txt
-    // (option "line_search_chunk" overrides)
-    {
-        const int64_t per_wave = d.n / (blocks * waves_per_block > 0 ? blocks * waves_per_block : 1);
-        A.chunk = o.chunk > 0 ? o.chunk : (per_wave < 96 ? 16 : kChunk);
-    }
+    // (option "line_search_chunk" overrides; the rule is on the row count, not on rows per wave: the 3-waves-per-SIMD MAP build at
+    // 200 k x 4 has 65 rows per wave and lost 0.157 -> 0.204 ms to 16-row chunks)
+    A.chunk = o.chunk > 0 ? o.chunk : (d.n <= 65536 ? 16 : kChunk);
     const int variant = min_waves;
 #define LAUNCH(M, W) disp_fit_kernel<M, W><<<(unsigned)blocks, threads, lds, st>>>(A)
     if (map) {
