@@ -45,6 +45,7 @@ struct chicdiff_hip_ctx {
     bool no_persistent_trend = false;  // set after a grid-barrier timeout (see fit_dev_impl)
     // tuning / test options (chicdiff_hip_set_option); the defaults are what the benchmarks run
     int opt_chunk = 0;  // line search: rows per dequeue (0 = automatic)
+    int opt_classes_a = 0;  // gene-wise line search: classes of the schedule dealt out statically (0 = default)
     int opt_spread = 1, opt_min_waves = 2, opt_select_rounds = 0, opt_trend_multilaunch = 0, opt_schedule = 1, opt_deal = 0;
     int opt_trend_gather = 1;  // sharded fits: gather the rows of the trend on every rank (two collectives) instead of one all-reduce per IRLS pass
     char *tg_buf = nullptr;    // ... the gathered rows (grow-only)
@@ -185,6 +186,7 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     if (k == "line_search_spread" && value >= 0 && value <= 2) c->opt_spread = (int)value;  // 2: samples across lanes without the lean tick of the launch's end (bit-identity tests)
     else if (k == "line_search_min_waves" && value >= 2 && value <= 4) c->opt_min_waves = (int)value;
     else if (k == "line_search_chunk" && (value == 0 || (value >= 8 && value <= 64))) c->opt_chunk = (int)value;
+    else if (k == "line_search_classes_a" && value >= 0 && value <= 6) c->opt_classes_a = (int)value;
     else if (k == "line_search_schedule" && (value == 0 || value == 1)) c->opt_schedule = (int)value;
     else if (k == "line_search_deal" && value >= 0 && value <= 64) c->opt_deal = (int)value;
     else if (k == "local_trend_substitute" && (value == 0 || value == 1)) c->opt_no_local_substitute = value ? 0 : 1;
@@ -739,6 +741,7 @@ static Opts make_opts(const chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *in, 
     r.schedule = c->opt_schedule;
     r.deal = c->opt_deal;
     r.chunk = c->opt_chunk;
+    r.classes_a = c->opt_classes_a;
     r.trend_blocks = c->opt_trend_blocks;
     return r;
 }

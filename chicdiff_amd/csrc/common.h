@@ -60,7 +60,8 @@ struct Opts {
     int32_t min_waves = 2;  // line search: waves per SIMD the kernel variant is built for
     int32_t schedule = 1;   // gene-wise line search / IRLS: visit the rows likely-long first (0 = natural order; 2 = class order through the queue only)
     int32_t deal = 0;       // ... entries per group of its static deal (0 = chosen from the number of entries per wave)
-    int32_t chunk = 0;      // line search: rows per dequeue (0 = chosen from the rows per wave; 8 .. 64)
+    int32_t chunk = 0;      // line search: rows per dequeue (0 = chosen from the row count; 8 .. 64)
+    int32_t classes_a = 0;  // gene-wise line search: score classes dealt out statically (0 = the default, 2; 1 .. 6)
     int32_t trend_blocks = 0;  // persistent trend kernel: at most this many workgroups (0 = one per CU); option "trend_persistent_blocks"
 };
 

@@ -1397,11 +1397,6 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
         order_tiles(d.n, nblk, tile);
         disp_init_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(d, w, o, tile, reinterpret_cast<unsigned int *>(w.hist));
     }
-    // the gene-wise launch visits the rows likely-long first; schedule 2 (a fit that shares the GPU with other fits: the theta
-    // grid's lanes) keeps the class order but deals nothing out statically — its waves are not all resident at once, and a wave
-    // that starts late must not be the owner of likely-long rows
-    if (sched) launch_order_build(d, w, o.schedule == 2 ? 0 : kSchedClassesA, true, st);
-    DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, o.deal, 1, kChunk};
     const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks
     int threads = 128;
@@ -1425,6 +1420,23 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     const int64_t max_blocks = 256 * blocks_per_cu;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
+    // the gene-wise launch visits the rows likely-long first; schedule 2 (a fit that shares the GPU with other fits: the theta
+    // grid's lanes) keeps the class order but deals nothing out statically — its waves are not all resident at once, and a wave
+    // that starts late must not be the owner of likely-long rows
+    // classes dealt out statically: 0-1 (the likely-long 8 % of the rows) — or, when the launch has 1.8 .. 8 rows per lane, all but
+    // the last (everything except the minDisp starts and the highest scores), in groups of four.  The queue hands a class out in
+    // chunks of 64 consecutive schedule entries: a fifth of the waves each received a whole chunk of class-2 rows (20-50 steps)
+    // and, with so few rows per lane, nothing afterwards to even that out — they were the waves that left last.  Measured, two or
+    // three repeats each (profiles/r05_ab_static_deal_classes.txt): gene-wise 0.525 -> 0.495 ms at 250 k x 8 (1.9 rows per lane),
+    // 0.702 -> 0.658 at 500 k x 8, 0.934 -> 0.915 at 1 M x 8 (7.6), 0.562 -> 0.531 at 500 k x 4, 0.733 -> 0.716 at 1 M x 4,
+    // 0.666 -> 0.644 at 250 k x 16 (2.5); NOT at 2 M x 8 (15 rows per lane: the queue balances better than any deal: 1.356 -> 1.44),
+    // 1 M x 16 (10: + 1.5 %), 200 k x 4 (1.5: + 1.5 %), 150 k x 8 (1.1: + 2 %).  Groups of 8 (the automatic size for so many entries)
+    // gave nothing: 2 or 4.
+    const double rows_per_lane = (double)d.n / (double)(blocks * threads);
+    const bool deal_most = !map && o.schedule == 1 && o.classes_a == 0 && rows_per_lane >= 1.8 && rows_per_lane <= 8.0;
+    const int classes_a = o.schedule == 2 ? 0 : (o.classes_a > 0 ? o.classes_a : (deal_most ? 5 : kSchedClassesA));
+    if (sched) launch_order_build(d, w, classes_a, true, st);
+    DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, (deal_most && o.deal == 0) ? 4 : o.deal, 1, kChunk};
 #ifdef CHICDIFF_DIAG
     const char *stamp_file = getenv("CHICDIFF_DISP_STAMPS");  // diagnostic build only: blocking, never timed
     const size_t stamp_words = (size_t)blocks * (threads / 64) * kStampSlots;

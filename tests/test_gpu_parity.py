@@ -1035,6 +1035,13 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
             deals[deal] = run()
         finally:
             ctx.set_option("line_search_deal", 0)
+    # score classes dealt out statically (0-1 by default, all but the last when the launch has 1.8 .. 8 rows per lane): any number
+    for ca in (1, 5, 6):
+        ctx.set_option("line_search_classes_a", ca)
+        try:
+            deals[f"classes dealt {ca}"] = run()
+        finally:
+            ctx.set_option("line_search_classes_a", 0)
     # rows per dequeue (64; 16 when a wave's share of the rows is about one chunk): any size gives the same bits
     for ch in (8, 24):
         ctx.set_option("line_search_chunk", ch)
