@@ -1446,7 +1446,11 @@ void launch_window_sums(const int32_t *fragN, const double *fragFM, int64_t nfra
 //      step; a wider range (a far denser table, an unsorted caller) is searched in global memory the same way;
 //   4. key and value at the lower bound decide match / no match (N <- 0, chicdiff.R:851-853).
 // Results do not depend on the tiling or on the path taken.
-constexpr int kJoinPerLane = 8, kJoinTile = 64 * kJoinPerLane, kJoinCap = 512;
+// kJoinCap = 768 (round 5; 512 before): a table nearly as dense as RU (the end-to-end leg: 19 M keys under 21.5 M rows) sent every
+// other tile through the global search — 0.20 ms at 22 M x 19.8 M against 0.135 with the wider window, four blocks per CU instead of
+// six; a sparser table (10 M keys) is unchanged at 0.117.  Tried on the way and dropped (no gain: the tile's chain of dependent loads
+// is NOT what bounds the kernel any more): runs of consecutive tiles per wave with the last tile's answer as a hint for the next.
+constexpr int kJoinPerLane = 8, kJoinTile = 64 * kJoinPerLane, kJoinCap = 768;
 // lower_bound over keys[lo, hi) by the 64 lanes of a wave; every lane returns the same value
 __device__ __forceinline__ int64_t wave_lower_bound(const int64_t *__restrict__ keys, int64_t lo, int64_t hi, int64_t target, int lane) {
     while (hi - lo > 64) {
@@ -1463,7 +1467,7 @@ __device__ __forceinline__ int64_t wave_lower_bound(const int64_t *__restrict__ 
 }
 
 template <bool VEC>  // VEC: bait / oe / out are 16-byte aligned, full tiles move as 4 x int32
-__global__ __launch_bounds__(256, 6) void count_join_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
+__global__ __launch_bounds__(256, 4) void count_join_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
                                                          int64_t nru, const int64_t *__restrict__ keys,
                                                          const int32_t *__restrict__ vals, int64_t nkeys,
                                                          const int64_t *__restrict__ index, int64_t nidx,
@@ -1646,6 +1650,11 @@ struct BgArgs {
     const double *distfun;  // device, S x 10
     double *bmean, *tmean, *fullmean;
 };
+// What bounds it (round 5, 22 M rows x 8 replicates, FullMean only: 0.95 ms = 1.7 TB/s of algorithmic bytes; profiles/r05_fragment_background_ablation.txt):
+// instruction issue, not memory — 830 vector + 420 scalar instructions per 64 rows (SQ_INSTS_VALU / SQ_INSTS_SALU), HBM traffic 0.53 GB
+// read + 1.375 GB written (as computed: every XCD reads the tables once).  Without the gathers 0.76 ms, without the stores 0.74, without
+// either and without the midpoints 0.58.  Measured and NOT taken, each within +-2 % of the kernel below: the gathers of four replicates
+// issued together, table-driven exp / log (devmath.h) in place of the device library's, the Tmean tables in LDS.
 // One thread per RU row, the replicates in a loop (round 5; before: one thread per (row, replicate), grid.y = S): the row's two
 // fragment IDs, the two midpoints and log|distance| are the same for every replicate — S - 1 of every S logarithms, ID loads and
 // midpoint gathers were repeats — and a caller that wants FullMean alone (chicdiff.R:896: the one column DESeq2Wrap reads) passes
