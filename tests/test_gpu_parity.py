@@ -303,6 +303,28 @@ def test_count_join_randomised_shapes(ctx, oracle):
         assert np.array_equal(got, ref[off:]), (trial, nk, nq, nb, span, mode, off)
 
 
+def test_count_join_window_boundary(ctx, oracle):
+    """The join's LDS key window holds 768 keys (global_kernels.hip kJoinCap); a tile whose key range is wider goes through the global
+    search.  One tile of 512 queries over a dense run of keys, the run's width swept across the limit (the range a tile takes is
+    rounded up to the table's coarse level, every 64th key, so the sweep covers every residue): both paths, bit-exact, on either side
+    of the boundary and exactly on it."""
+    import torch
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(ctx.device)
+    rng = np.random.default_rng(77)
+    base = np.int64(700) << 32
+    keys = base + np.arange(5000, dtype=np.int64) * 2                     # even other-end IDs 0 .. 9998 of bait 700
+    vals = rng.integers(1, 1000, len(keys)).astype(np.int32)
+    dk, dv = t(keys), t(vals)
+    for start in (0, 37, 1000):
+        for width in list(range(640, 900, 7)) + [703, 704, 705, 767, 768, 769, 831, 832, 833]:
+            # 512 sorted queries between key `start` and key `start + width - 1`: hits (even IDs) and misses (odd IDs) mixed
+            oe = np.sort(rng.integers(2 * start, 2 * (start + width), 512)).astype(np.int32)
+            oe[0], oe[-1] = 2 * start, 2 * (start + width - 1)          # the tile spans the whole run
+            qb = np.full(512, 700, dtype=np.int32)
+            got = ctx.count_join(t(qb), t(oe), dk, dv).cpu().numpy()
+            assert np.array_equal(got, oracle.count_join(qb, oe, keys, vals)), (start, width)
+
+
 def test_theta_grid(ctx, oracle):
     d = synth.make(6000, 8, fragments=3)
     keep = d["counts"].sum(1) > 0
