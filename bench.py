@@ -117,6 +117,10 @@ def hbm_kernels(ctx, torch, n, S, F=11):
     return out
 
 
+class EndToEndError(RuntimeError):
+    pass
+
+
 def end_to_end(ctx, torch, synth, n, S, F=11, reps=3):
     """The drop-in's whole resident path in the reference's default mode (chicdiffPipeline, chicdiff.R:301-347: norm = "combined",
     theta = NULL), one stage after the other on `n` peaks x `S` replicates, everything resident in HBM: what a user of
@@ -152,22 +156,25 @@ def end_to_end(ctx, torch, synth, n, S, F=11, reps=3):
         key = torch.sort(pb * (1 << 32) + po).values      # setkey(baitID, oeID): regions bait-major, as the reference numbers them
         return (key >> 32).to(torch.int32), (key & 0xFFFFFFFF).to(torch.int32)
 
+    wrng = np.random.Generator(np.random.PCG64(20190123 + 7))
+
     def split_counts(ru, k):
-        """k (S, n) region counts -> (S, nfrag) fragment counts that sum back to k over each region's rows"""
+        """k (S, n) region counts -> (S, nfrag) fragment counts that sum back to k over each region's rows.  The fragment weights are
+        INTEGERS drawn on the host from a seeded PCG64 (Gamma(0.3), scaled, + 1): round 5 drew them with torch._standard_gamma, which
+        took no seeded generator (the inputs differed from run to run), and formed a region's shares from differences of a GLOBAL fp64
+        running sum — a one-fragment region whose weight fell below the sum's ulp got 0 / 0 and with it an all-zero row (BENCH_r05).
+        With integer weights the running sum is exact in int64 and each region's shares are exact ratios: first lo = 0, last hi = 1."""
         ptr = ru["region_ptr"]
         nfrag = int(ru["baitID"].numel())
         cnt = ptr[1:] - ptr[:-1]
         rid = torch.repeat_interleave(torch.arange(n, device=dev), cnt)
-        w = torch._standard_gamma(torch.full((nfrag,), 0.3, dtype=torch.float64, device=dev)) + 1e-12
+        w = torch.from_numpy(np.minimum(wrng.standard_gamma(0.3, nfrag) * 4096.0, 2.0 ** 30).astype(np.int64) + 1).to(dev)
         cum = torch.cumsum(w, 0)
         cum_excl = cum - w
         start = cum_excl[ptr[:-1].clamp(max=nfrag - 1)]
-        tot = cum[(ptr[1:] - 1).clamp(min=0)] - start
-        hi = ((cum - start[rid]) / tot[rid]).clamp(0, 1)
-        lo = ((cum_excl - start[rid]) / tot[rid]).clamp(0, 1)
-        last = torch.zeros(nfrag, dtype=torch.bool, device=dev)
-        last[(ptr[1:] - 1)[cnt > 0]] = True
-        hi[last] = 1.0
+        tot = (cum[(ptr[1:] - 1).clamp(min=0)] - start).to(torch.float64)
+        hi = (cum - start[rid]).to(torch.float64) / tot[rid]
+        lo = (cum_excl - start[rid]).to(torch.float64) / tot[rid]
         out = torch.empty((S, nfrag), dtype=torch.int32, device=dev)
         for j in range(S):
             kj = k[j][rid].to(torch.float64)
@@ -200,10 +207,43 @@ def end_to_end(ctx, torch, synth, n, S, F=11, reps=3):
         first = torch.ones_like(ks, dtype=torch.bool)
         first[1:] = ks[1:] != ks[:-1]                      # a pair that sits in several regions keeps one count, as in a chinput
         tables.append((ks[first].contiguous(), vs[first].contiguous()))
+    for st in sets.values():
+        del st["frag"]
+    del allkeys
+
+    # the one-read guard, checked where it matters: on the JOINED matrix (after the split and the de-duplication).  A region that the
+    # join leaves without a read in every replicate gets one: its first fragment's key goes into replicate 0's table.  (The reference's
+    # theta scan needs every total deviance finite: sum() without na.rm, chicdiff.R:1647, 1660.)
+    def joined_all_zero(st):
+        ru = ctx.region_universe(st["pb"], st["po"], 5, chr_of)
+        ptr = ru["region_ptr"].to(torch.int64)
+        tot = torch.zeros(n, dtype=torch.int64, device=dev)
+        for kk, vv in tables:
+            cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(ctx.count_join(ru["baitID"], ru["otherEndID"], kk, vv).to(torch.int64), 0)])
+            tot += cs[ptr[1:]] - cs[ptr[:-1]]
+        return torch.nonzero(tot == 0).flatten(), ptr
+
+    repaired = 0
+    for _ in range(3):
+        extra = []
+        for st in sets.values():
+            zero, ptr = joined_all_zero(st)
+            if zero.numel():
+                extra.append(st["key"][ptr[zero]])
+        if not extra:
+            break
+        extra = torch.unique(torch.cat(extra))
+        repaired += int(extra.numel())
+        ks, order = torch.sort(torch.cat([tables[0][0], extra]), stable=True)     # (an existing key sorts first and keeps its count)
+        vs = torch.cat([tables[0][1], torch.ones_like(extra, dtype=tables[0][1].dtype)])[order]
+        first = torch.ones_like(ks, dtype=torch.bool)
+        first[1:] = ks[1:] != ks[:-1]
+        tables[0] = (ks[first].contiguous(), vs[first].contiguous())
+    else:
+        raise RuntimeError("end_to_end set-up: regions without a read remain after three repair passes")
     nkeys = int(np.mean([t[0].numel() for t in tables]))
     for st in sets.values():
-        del st["frag"], st["key"]
-    del allkeys
+        del st["key"]
     sj = torch.exp(torch.randn((S, nid), dtype=torch.float64, device=dev, generator=g) * 0.3)
     si = torch.exp(torch.randn((S, nid), dtype=torch.float64, device=dev, generator=g) * 0.3)
     si[torch.rand((S, nid), device=dev, generator=g) < 0.02] = float("nan")   # other ends Chicago never saw: s_i NA -> 1 (:668-672)
@@ -247,10 +287,8 @@ def end_to_end(ctx, torch, synth, n, S, F=11, reps=3):
             nfrag = ru["baitID"].numel()
             fragN = torch.empty((S, nfrag), dtype=torch.int32, device=dev)
 
-            def joins():
-                for j, (kk, vv) in enumerate(tables):
-                    fragN[j] = ctx.count_join(ru["baitID"], ru["otherEndID"], kk, vv)
-            stage("count_join", joins)
+            # all S replicates' joins from one read of the RU rows (round 6; before: S joins, each re-reading them)
+            stage("count_join", lambda: ctx.count_join_multi(ru["baitID"], ru["otherEndID"], tables, out=fragN))
             fragFM = stage("fragment_background", lambda: ctx.fragment_background(ru["baitID"], ru["otherEndID"], 0, midsum, sj, si, tblb, tlb, T, distfun, only_fullmean=True)[2])
             N, FM = stage("window_sums", lambda: ctx.window_sums(fragN, fragFM, ru["region_ptr"]))
             if checks is not None:  # (warm-up pass only: what the synthetic inputs look like after the join and the sums)
@@ -262,8 +300,12 @@ def end_to_end(ctx, torch, synth, n, S, F=11, reps=3):
             if name == "test":
                 sf = stage("size_factors", lambda: ctx.size_factors(N))
                 dv = stage("theta_grid", lambda: ctx.theta_grid(N, FM, sf, grid))
-                theta = grid[int(np.nanargmin(dv))] if np.isfinite(dv).any() else 0.5   # tt <- Grid[which(deviances == min(deviances))], :1660
                 res["deviances"] = [float(x) for x in dv]
+                if not np.isfinite(dv).all():
+                    # tt <- Grid[which(deviances == min(deviances))], :1660: with an NA total the reference selects nothing and fails at
+                    # the next line; so does this leg (round 5 fell back to theta = 0.5 silently: BENCH_r05's leg ran that way)
+                    raise EndToEndError("theta grid: total deviances not all finite (an all-zero row in the joined matrix?): %r" % (res["deviances"],))
+                theta = grid[int(np.argmin(dv))]
             out, sc = stage("final_fit" if name == "test" else "control_fit", lambda: ctx.wald_test(N, FM, group, theta=theta, want=want))
 
             def results():
@@ -284,19 +326,22 @@ def end_to_end(ctx, torch, synth, n, S, F=11, reps=3):
         torch.cuda.synchronize()
         return (time.perf_counter() - t_all) * 1e3, times, theta, res
 
-    checks = {}
-    run(True, checks)                                       # warm-up: workspaces, the theta grid's child contexts
-    totals, splits = [], []
-    for _ in range(reps):
-        tot, _, theta, res = run(False)
-        totals.append(tot)
-    for _ in range(reps):
-        _, tms, _, _ = run(True)
-        splits.append(tms)
+    checks = {"reads_added_by_the_guard": repaired}
+    try:
+        run(True, checks)                                       # warm-up: workspaces, the theta grid's child contexts
+        totals, splits = [], []
+        for _ in range(reps):
+            tot, _, theta, res = run(False)
+            totals.append(tot)
+        for _ in range(reps):
+            _, tms, _, _ = run(True)
+            splits.append(tms)
+    except EndToEndError as e:   # no total_ms: a pass that selected no theta is not a measurement
+        return {"error": str(e), "input_checks": checks}
     stages = {k: round(float(np.median([sp[k] for sp in splits])), 3) for k in splits[0]}
     nfrag = res["nfrag"]
     hbm = {  # algorithmic bytes of the HBM-bound stages (both sets), SURVEY.md 8(d): per RU row / fragment / region and replicate
-        "count_join": 2 * S * (12 * nfrag + 12 * nkeys),
+        "count_join": 2 * (8 * nfrag + S * (4 * nfrag + 12 * nkeys)),   # one pass for all replicates: the RU rows read once (S separate joins: 2 S (12 nfrag + 12 nkeys))
         "fragment_background": 2 * (8 * nfrag + 8 * S * nfrag),
         "window_sums": 2 * (12 * S * nfrag + 12 * S * n),
         "region_universe": 2 * (16 * n + 12 * nfrag + 16 * n),
@@ -304,6 +349,7 @@ def end_to_end(ctx, torch, synth, n, S, F=11, reps=3):
     return {"total_ms": round(float(np.median(totals)), 3), "total_runs_ms": [round(t, 3) for t in totals],
             "sum_of_stages_ms": round(sum(stages.values()), 3), "stages_ms": stages,
             "hbm_stage_fraction_of_peak": {k: round(v / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in hbm.items()},
+            "count_join_fraction_by_the_bytes_of_S_separate_joins": round(2 * S * (12 * nfrag + 12 * nkeys) / (stages["count_join"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "input_checks": checks, "theta_chosen": theta, "peaks_per_set": n, "ru_rows_per_set": nfrag, "keys_per_replicate_table": nkeys, **{k: v for k, v in res.items() if k != "nfrag"},
             "what": "resident default-mode pipeline, test + control sets, chicdiff.R:301-347 order: total_ms = one pass without intermediate "
                     "synchronisation (median of %d); stages_ms = a pass with a device synchronisation after every stage (host-side Python / ctypes "
@@ -527,6 +573,10 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_global / (elapsed / args.steps)
+    projected_value = None
+    if fake_world > 1:  # a rehearsal: `value` stays what was MEASURED (this rank's rows / its step); the x N projection has a key of its own
+        projected_value = value
+        value = n / (elapsed / args.steps)
 
     # dominant kernel = largest total HIP-event time inside the timed region
     dom = max(((k, v) for k, v in ktimes.items() if k != "allreduce"), key=lambda kv: kv[1][0])
@@ -591,7 +641,7 @@ def main():
                    "rows_per_gpu": n, "samples": S, "global_rows": n_global,
                    "parallelism": (f"rows-sharded x{world}" if fake_world <= 1 else
                                    f"REHEARSAL on one GPU of one rank's step of a x{fake_world} run: {n} rows here, trend + MAD on all {fake_world} x {n} gathered rows, "
-                                   f"1-rank RCCL group; value = global rows / this step = a projection before inter-GPU latency"),
+                                   f"1-rank RCCL group; value = THIS rank's rows / its step (measured); projected_value = global rows / this step, a projection before inter-GPU latency"),
                    "collectives": collectives, "ranks_in_communicator": comm_ranks},
         "roofline": roofline,
         "kernels_ms": {k: [round(v[0] / args.steps, 4), v[1] // args.steps] for k, v in sorted(kfull.items(), key=lambda kv: -kv[1][0]) if k != "allreduce"},
@@ -603,6 +653,8 @@ def main():
         "timed_outputs": want,
         "fit_status": int(sc["status"]),
     }
+    if projected_value is not None:
+        result["projected_value"] = round(projected_value, 1)
     if world > 1 and not args.one_mode:
         # the other way of scaling, measured in the same run with the same K / W: `value` follows --scaling (default strong =
         # BASELINE.json configs[3], 2 M rows in all); this is the same metric with the per-GPU work fixed instead

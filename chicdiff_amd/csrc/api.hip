@@ -198,7 +198,13 @@ int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value
     else if (k == "fault_inject" && value >= 0 && value <= 7) c->opt_fault = (int)value;
     else if (k == "trend_persistent_blocks" && value >= 0 && value <= 256) c->opt_trend_blocks = (int)value;
     else if (k == "fuse_offsets" && value >= 0 && value <= 2) c->opt_fuse_offsets = (int)value;
-    else if (k == "bench_fake_world" && value >= 0 && value <= kGatherMaxWorld) c->opt_fake_world = (int)value;
+    else if (k == "bench_fake_world" && value >= 0 && value <= kGatherMaxWorld) {
+        // a rehearsal hook of bench.py, not an option of the product: refused unless the process says it is that rehearsal
+        // (it makes a 1-rank fit's trend run on N copies of its rows — a fit nobody asked for)
+        if (value > 1 && !getenv("CHICDIFF_BENCH_FAKE_WORLD"))
+            return fail(c, CHICDIFF_E_INVALID, "set_option: bench_fake_world is a rehearsal hook of bench.py (CHICDIFF_BENCH_FAKE_WORLD unset)");
+        c->opt_fake_world = (int)value;
+    }
     else if (k == "trend_mad_in_kernel" && (value == 0 || value == 1)) c->opt_mad_in_kernel = (int)value;
     else return fail(c, CHICDIFF_E_INVALID, "set_option: unknown option or value (%s = %lld)", name, (long long)value);
     return CHICDIFF_OK;
@@ -1917,6 +1923,28 @@ extern "C" int chicdiff_hip_region_avdist_dev(chicdiff_hip_ctx *c, const int32_t
     {
         Scope t(c, "region_avdist");
         launch_region_avdist(d_ru_bait, d_ru_oe, d_region_ptr, n, id_min, nid, d_midsum, d_chr, d_avDist, c->stream);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return CHICDIFF_OK;
+}
+
+// a1 for all replicates in one pass (chicdiff.R:843-858, the loop over the replicates): out = S x nru, column s = merge(RU, table s, all.x = TRUE)
+extern "C" int chicdiff_hip_count_join_multi_dev(chicdiff_hip_ctx *c, const int32_t *d_ru_bait, const int32_t *d_ru_oe, int64_t nru,
+                                                 int32_t S, const int64_t *const *d_keys, const int32_t *const *d_vals,
+                                                 const int64_t *nkeys, int32_t *d_out) {
+    if (!c) return CHICDIFF_E_INVALID;
+    if (!d_ru_bait || !d_ru_oe || !d_out || !d_keys || !d_vals || !nkeys || nru < 0 || S < 1 || S > kMaxS)
+        return fail(c, CHICDIFF_E_INVALID, "count_join_multi: bad arguments");
+    for (int s = 0; s < S; s++)
+        if (nkeys[s] < 0 || (nkeys[s] > 0 && (!d_keys[s] || !d_vals[s])))
+            return fail(c, CHICDIFF_E_INVALID, "count_join_multi: bad table %d", s);
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_reset(c);
+    if (nru > 0) {
+        if (int rc = ensure_aux(c, count_join_multi_scratch_bytes(S, nkeys))) return rc;
+        Scope t(c, "count_join_multi");
+        launch_count_join_multi(d_ru_bait, d_ru_oe, nru, S, d_keys, d_vals, nkeys, d_out, c->aux, c->stream);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_collect(c);

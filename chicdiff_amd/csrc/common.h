@@ -166,6 +166,9 @@ void launch_ru_fill(const int32_t *bait, const int32_t *oe, int64_t n, int s, co
                     const int64_t *region_ptr, int32_t *ru_bait, int32_t *ru_region, int32_t *ru_oe, hipStream_t st);
 void launch_region_avdist(const int32_t *bait, const int32_t *oe, const int64_t *ptr, int64_t n, int32_t id_min, int32_t nid,
                           const int64_t *midsum, const int32_t *chr, double *avDist, hipStream_t st);
+size_t count_join_multi_scratch_bytes(int S, const int64_t *nkeys);
+void launch_count_join_multi(const int32_t *bait, const int32_t *oe, int64_t nru, int S, const int64_t *const *keys, const int32_t *const *vals,
+                             const int64_t *nkeys, int32_t *out, void *scratch, hipStream_t st);
 void launch_count_join_inner(const int32_t *bait, const int32_t *oe, int64_t nru, int S, const int64_t *const *keys,
                              const int32_t *const *vals, const int64_t *nkeys, int32_t *out, hipStream_t st);
 void launch_math_selftest(int op, const double *x, int64_t n, double *out, hipStream_t st);

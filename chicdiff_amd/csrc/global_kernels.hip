@@ -1466,6 +1466,165 @@ __device__ __forceinline__ int64_t wave_lower_bound(const int64_t *__restrict__ 
     return lo + __popcll(__ballot(pos < hi && keys[pos] < target));
 }
 
+// One tile's 512 queries (eight per lane, q[]; kmin / kmax = the tile's smallest / largest, wave-uniform) against ONE sorted key table:
+// steps 1-4 above.  sk / sv = the wave's LDS slice.  Shared by the single-table and the all-replicates kernels.
+__device__ __forceinline__ void join_tile_table(const int64_t (&q)[kJoinPerLane], int64_t kmin, int64_t kmax, const int64_t *__restrict__ keys,
+                                                const int32_t *__restrict__ vals, int64_t nkeys, const int64_t *__restrict__ index, int64_t nidx,
+                                                int64_t *sk, int32_t *sv, int lane, int32_t (&res)[kJoinPerLane]) {
+    // lo: the coarse level (every 64th key, L2-resident) says which 64 keys hold the lower bound of the tile's
+    // smallest query, one dense load of those finishes; hi: the first coarse entry >= the largest query, from the
+    // 64 entries after lo (one dense load), or a proper search for a tile that spans more than 4096 keys
+    const int64_t jlo = wave_lower_bound(index, 0, nidx, kmin, lane);  // first j with keys[64 j] >= kmin
+    int64_t lo = 0;
+    if (jlo > 0) {
+        const int64_t e = 64 * jlo < nkeys ? 64 * jlo : nkeys;
+        lo = wave_lower_bound(keys, 64 * (jlo - 1) + 1, e, kmin, lane);
+    }
+    int64_t hi;
+    {
+        const int64_t j0 = lo / 64 + 1, pos = j0 + lane;
+        const int c = __popcll(__ballot(pos < nidx && index[pos] < kmax));
+        int64_t jhi = j0 + c;  // keys[64 jhi] >= kmax, or jhi >= nidx
+        if (c == 64) jhi = wave_lower_bound(index, j0 + 64, nidx, kmax, lane);
+        hi = jhi < nidx ? 64 * jhi + 1 : nkeys;
+    }
+    if (hi - lo <= kJoinCap) {
+        const int w = (int)(hi - lo);
+        {
+            int64_t tk[kJoinCap / 64];
+            int32_t tv[kJoinCap / 64];
+#pragma unroll
+            for (int e = 0; e < kJoinCap / 64; e++) {
+                const int at = e * 64 + lane;
+                tk[e] = at < w ? keys[lo + at] : 0;
+                tv[e] = at < w ? vals[lo + at] : 0;
+            }
+#pragma unroll
+            for (int e = 0; e < kJoinCap / 64; e++) {
+                sk[e * 64 + lane] = tk[e];
+                sv[e * 64 + lane] = tv[e];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int b[kJoinPerLane];  // the answer of query k stays in [b[k], b[k] + len]
+#pragma unroll
+        for (int k = 0; k < kJoinPerLane; k++) b[k] = 0;
+        int len = w;
+        while (len > 1) {
+            const int half = len >> 1;
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) b[k] += sk[b[k] + half - 1] < q[k] ? half : 0;
+            len -= half;
+        }
+        if (len == 1) {
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) b[k] += sk[b[k]] < q[k] ? 1 : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kJoinPerLane; k++) {
+            const bool in = b[k] < w;
+            const int at = in ? b[k] : 0;
+            res[k] = (in && sk[at] == q[k]) ? sv[at] : 0;
+        }
+        __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next tile
+    } else {
+        int64_t b[kJoinPerLane];
+#pragma unroll
+        for (int k = 0; k < kJoinPerLane; k++) b[k] = lo;
+        int64_t len = hi - lo;
+        while (len > 1) {
+            const int64_t half = len >> 1;
+#pragma unroll
+            for (int k = 0; k < kJoinPerLane; k++) b[k] += keys[b[k] + half - 1] < q[k] ? half : 0;
+            len -= half;
+        }
+#pragma unroll
+        for (int k = 0; k < kJoinPerLane; k++) b[k] += keys[b[k]] < q[k] ? 1 : 0;  // len == 1: the range has > kJoinCap keys
+#pragma unroll
+        for (int k = 0; k < kJoinPerLane; k++) {
+            const bool in = b[k] < hi;
+            const int64_t at = in ? b[k] : lo;
+            res[k] = (in && keys[at] == q[k]) ? vals[at] : 0;
+        }
+    }
+}
+// a tile's queries: eight consecutive RU rows per lane -> q[], and the tile's smallest / largest key (wave-uniform)
+template <bool VEC>
+__device__ __forceinline__ void join_tile_queries(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe, int64_t nru, int64_t r0,
+                                                  int64_t (&q)[kJoinPerLane], int64_t &kmin, int64_t &kmax) {
+    int32_t qb[kJoinPerLane], qo[kJoinPerLane];
+    if (VEC) {
+        const int4 b0 = *(const int4 *)(bait + r0), b1 = *(const int4 *)(bait + r0 + 4);
+        const int4 o0 = *(const int4 *)(oe + r0), o1 = *(const int4 *)(oe + r0 + 4);
+        qb[0] = b0.x; qb[1] = b0.y; qb[2] = b0.z; qb[3] = b0.w; qb[4] = b1.x; qb[5] = b1.y; qb[6] = b1.z; qb[7] = b1.w;
+        qo[0] = o0.x; qo[1] = o0.y; qo[2] = o0.z; qo[3] = o0.w; qo[4] = o1.x; qo[5] = o1.y; qo[6] = o1.z; qo[7] = o1.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kJoinPerLane; k++) {
+            const bool v = r0 + k < nru;
+            qb[k] = v ? bait[r0 + k] : 0;
+            qo[k] = v ? oe[r0 + k] : 0;
+        }
+    }
+    kmin = INT64_MAX;
+    kmax = INT64_MIN;
+#pragma unroll
+    for (int k = 0; k < kJoinPerLane; k++) {
+        q[k] = ((int64_t)qb[k] << 32) | (uint32_t)qo[k];
+        if (VEC || r0 + k < nru) {
+            kmin = q[k] < kmin ? q[k] : kmin;
+            kmax = q[k] > kmax ? q[k] : kmax;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int64_t a = __shfl_xor(kmin, off), c = __shfl_xor(kmax, off);
+        kmin = a < kmin ? a : kmin;
+        kmax = c > kmax ? c : kmax;
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void join_tile_store(int32_t *__restrict__ out, int64_t nru, int64_t r0, const int32_t (&res)[kJoinPerLane]) {
+    if (VEC) {
+        *(int4 *)(out + r0) = make_int4(res[0], res[1], res[2], res[3]);
+        *(int4 *)(out + r0 + 4) = make_int4(res[4], res[5], res[6], res[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kJoinPerLane; k++)
+            if (r0 + k < nru) out[r0 + k] = res[k];
+    }
+}
+
+// A full tile's 512 results to a column that is only 4-byte aligned (column t of an S x nru matrix starts at t * nru: 16-byte aligned
+// for one nru in four).  The tile is one contiguous run of 2 KB; with k = the number of leading elements up to the next 16-byte
+// boundary (wave-uniform: r0 is a multiple of 8), lane L stores the ALIGNED eight elements [8 L + k, 8 L + k + 8) — its own res[k..7]
+// and the next lane's res[0..k-1] — as 2 x int4; lane 0 adds the tile's first k elements, lane 63 keeps its last 8 - k, as dwords.
+__device__ __forceinline__ void join_tile_store_shifted(int32_t *__restrict__ col, int64_t r0, int lane, const int32_t (&res)[kJoinPerLane]) {
+    const int k = (int)((4u - (unsigned)(((uintptr_t)(col + r0)) >> 2)) & 3u);  // same in every lane
+    if (k == 0) {
+        *(int4 *)(col + r0) = make_int4(res[0], res[1], res[2], res[3]);
+        *(int4 *)(col + r0 + 4) = make_int4(res[4], res[5], res[6], res[7]);
+        return;
+    }
+    const int n0 = __shfl_down(res[0], 1), n1 = __shfl_down(res[1], 1), n2 = __shfl_down(res[2], 1);
+    int32_t v[kJoinPerLane];
+    if (k == 1) { v[0] = res[1]; v[1] = res[2]; v[2] = res[3]; v[3] = res[4]; v[4] = res[5]; v[5] = res[6]; v[6] = res[7]; v[7] = n0; }
+    else if (k == 2) { v[0] = res[2]; v[1] = res[3]; v[2] = res[4]; v[3] = res[5]; v[4] = res[6]; v[5] = res[7]; v[6] = n0; v[7] = n1; }
+    else { v[0] = res[3]; v[1] = res[4]; v[2] = res[5]; v[3] = res[6]; v[4] = res[7]; v[5] = n0; v[6] = n1; v[7] = n2; }
+    int32_t *dst = col + r0 + k;
+    if (lane < 63) {
+        *(int4 *)dst = make_int4(v[0], v[1], v[2], v[3]);
+        *(int4 *)(dst + 4) = make_int4(v[4], v[5], v[6], v[7]);
+    } else {
+        for (int i = 0; i < kJoinPerLane - k; i++) dst[i] = v[i];
+    }
+    if (lane == 0)
+        for (int i = 0; i < k; i++) col[r0 + i] = res[i];
+}
+
+// (gfx950: 160 KB of LDS per CU — the four waves' slices take 4 x 768 x 12 = 36 864 bytes per workgroup, so FOUR workgroups = 16 waves
+// are resident per CU, which is what the launch bound asks the register allocator for; with the 512-key window it was six)
 template <bool VEC>  // VEC: bait / oe / out are 16-byte aligned, full tiles move as 4 x int32
 __global__ __launch_bounds__(256, 4) void count_join_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe,
                                                          int64_t nru, const int64_t *__restrict__ keys,
@@ -1487,121 +1646,50 @@ __global__ __launch_bounds__(256, 4) void count_join_kernel(const int32_t *__res
     const int64_t wave0 = (int64_t)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), nwave = (int64_t)(gridDim.x >> 3) * 4;
     for (int64_t tile = t_begin + wave0; tile < t_end; tile += nwave) {
         const int64_t r0 = tile * kJoinTile + (int64_t)lane * kJoinPerLane;
-        int32_t qb[kJoinPerLane], qo[kJoinPerLane];
-        if (VEC) {
-            const int4 b0 = *(const int4 *)(bait + r0), b1 = *(const int4 *)(bait + r0 + 4);
-            const int4 o0 = *(const int4 *)(oe + r0), o1 = *(const int4 *)(oe + r0 + 4);
-            qb[0] = b0.x; qb[1] = b0.y; qb[2] = b0.z; qb[3] = b0.w; qb[4] = b1.x; qb[5] = b1.y; qb[6] = b1.z; qb[7] = b1.w;
-            qo[0] = o0.x; qo[1] = o0.y; qo[2] = o0.z; qo[3] = o0.w; qo[4] = o1.x; qo[5] = o1.y; qo[6] = o1.z; qo[7] = o1.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++) {
-                const bool v = r0 + k < nru;
-                qb[k] = v ? bait[r0 + k] : 0;
-                qo[k] = v ? oe[r0 + k] : 0;
-            }
-        }
-        int64_t q[kJoinPerLane];
-        int64_t kmin = INT64_MAX, kmax = INT64_MIN;
-#pragma unroll
-        for (int k = 0; k < kJoinPerLane; k++) {
-            q[k] = ((int64_t)qb[k] << 32) | (uint32_t)qo[k];
-            if (VEC || r0 + k < nru) {
-                kmin = q[k] < kmin ? q[k] : kmin;
-                kmax = q[k] > kmax ? q[k] : kmax;
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const int64_t a = __shfl_xor(kmin, off), c = __shfl_xor(kmax, off);
-            kmin = a < kmin ? a : kmin;
-            kmax = c > kmax ? c : kmax;
-        }
-        // lo: the coarse level (every 64th key, L2-resident) says which 64 keys hold the lower bound of the tile's
-        // smallest query, one dense load of those finishes; hi: the first coarse entry >= the largest query, from the
-        // 64 entries after lo (one dense load), or a proper search for a tile that spans more than 4096 keys
-        const int64_t jlo = wave_lower_bound(index, 0, nidx, kmin, lane);  // first j with keys[64 j] >= kmin
-        int64_t lo = 0;
-        if (jlo > 0) {
-            const int64_t e = 64 * jlo < nkeys ? 64 * jlo : nkeys;
-            lo = wave_lower_bound(keys, 64 * (jlo - 1) + 1, e, kmin, lane);
-        }
-        int64_t hi;
-        {
-            const int64_t j0 = lo / 64 + 1, pos = j0 + lane;
-            const int c = __popcll(__ballot(pos < nidx && index[pos] < kmax));
-            int64_t jhi = j0 + c;  // keys[64 jhi] >= kmax, or jhi >= nidx
-            if (c == 64) jhi = wave_lower_bound(index, j0 + 64, nidx, kmax, lane);
-            hi = jhi < nidx ? 64 * jhi + 1 : nkeys;
-        }
+        int64_t q[kJoinPerLane], kmin, kmax;
+        join_tile_queries<VEC>(bait, oe, nru, r0, q, kmin, kmax);
         int32_t res[kJoinPerLane];
-        if (hi - lo <= kJoinCap) {
-            const int w = (int)(hi - lo);
-            {
-                int64_t tk[kJoinCap / 64];
-                int32_t tv[kJoinCap / 64];
-#pragma unroll
-                for (int e = 0; e < kJoinCap / 64; e++) {
-                    const int at = e * 64 + lane;
-                    tk[e] = at < w ? keys[lo + at] : 0;
-                    tv[e] = at < w ? vals[lo + at] : 0;
-                }
-#pragma unroll
-                for (int e = 0; e < kJoinCap / 64; e++) {
-                    sk[e * 64 + lane] = tk[e];
-                    sv[e * 64 + lane] = tv[e];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            int b[kJoinPerLane];  // the answer of query k stays in [b[k], b[k] + len]
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++) b[k] = 0;
-            int len = w;
-            while (len > 1) {
-                const int half = len >> 1;
-#pragma unroll
-                for (int k = 0; k < kJoinPerLane; k++) b[k] += sk[b[k] + half - 1] < q[k] ? half : 0;
-                len -= half;
-            }
-            if (len == 1) {
-#pragma unroll
-                for (int k = 0; k < kJoinPerLane; k++) b[k] += sk[b[k]] < q[k] ? 1 : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++) {
-                const bool in = b[k] < w;
-                const int at = in ? b[k] : 0;
-                res[k] = (in && sk[at] == q[k]) ? sv[at] : 0;
-            }
-            __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next tile
-        } else {
-            int64_t b[kJoinPerLane];
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++) b[k] = lo;
-            int64_t len = hi - lo;
-            while (len > 1) {
-                const int64_t half = len >> 1;
-#pragma unroll
-                for (int k = 0; k < kJoinPerLane; k++) b[k] += keys[b[k] + half - 1] < q[k] ? half : 0;
-                len -= half;
-            }
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++) b[k] += keys[b[k]] < q[k] ? 1 : 0;  // len == 1: the range has > kJoinCap keys
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++) {
-                const bool in = b[k] < hi;
-                const int64_t at = in ? b[k] : lo;
-                res[k] = (in && keys[at] == q[k]) ? vals[at] : 0;
-            }
-        }
-        if (VEC) {
-            *(int4 *)(out + r0) = make_int4(res[0], res[1], res[2], res[3]);
-            *(int4 *)(out + r0 + 4) = make_int4(res[4], res[5], res[6], res[7]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < kJoinPerLane; k++)
-                if (r0 + k < nru) out[r0 + k] = res[k];
+        join_tile_table(q, kmin, kmax, keys, vals, nkeys, index, nidx, sk, sv, lane, res);
+        join_tile_store<VEC>(out, nru, r0, res);
+    }
+}
+
+// a1 for ALL replicates in one pass (round 6): chicdiff.R:843-858 is a loop over the replicates, each merge() reading the same RU
+// rows; here a tile's (baitID, otherEndID) pairs are read ONCE and resolved against every replicate's key table in turn — per set of
+// S joins 8 nru + S (4 nru + 12 nkeys) bytes instead of S (12 nru + 12 nkeys) (S = 8, 21.5 M rows, 19 M keys: 2.7 instead of 3.9 GB),
+// one launch instead of S, and the coarse levels of all tables built by one launch.  Same per-table steps (join_tile_table): same bits.
+constexpr int kJoinMaxTables = 16;  // per launch (the tables' pointers travel as kernel arguments); more replicates: several launches
+struct JoinTables {
+    const int64_t *keys[kJoinMaxTables];
+    const int32_t *vals[kJoinMaxTables];
+    const int64_t *index[kJoinMaxTables];
+    int64_t nkeys[kJoinMaxTables];
+    int32_t T;
+};
+template <bool VEC>
+__global__ __launch_bounds__(256, 4) void count_join_multi_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe, int64_t nru,
+                                                                  JoinTables tb, int32_t *__restrict__ out, int64_t out_stride) {
+    __shared__ int64_t s_keys[4][kJoinCap];
+    __shared__ int32_t s_vals[4][kJoinCap];
+    const int lane = threadIdx.x & 63;
+    int64_t *const sk = s_keys[threadIdx.x >> 6];
+    int32_t *const sv = s_vals[threadIdx.x >> 6];
+    const int64_t ntile = VEC ? nru / kJoinTile : (nru + kJoinTile - 1) / kJoinTile;
+    const int64_t per_xcd = (ntile + 7) / 8, t_begin = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t t_end = t_begin + per_xcd < ntile ? t_begin + per_xcd : ntile;
+    const int64_t wave0 = (int64_t)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), nwave = (int64_t)(gridDim.x >> 3) * 4;
+    for (int64_t tile = t_begin + wave0; tile < t_end; tile += nwave) {
+        const int64_t r0 = tile * kJoinTile + (int64_t)lane * kJoinPerLane;
+        int64_t q[kJoinPerLane], kmin, kmax;
+        join_tile_queries<VEC>(bait, oe, nru, r0, q, kmin, kmax);
+#pragma unroll 1
+        for (int t = 0; t < tb.T; t++) {
+            int32_t res[kJoinPerLane];
+            const int64_t nk = tb.nkeys[t];
+            join_tile_table(q, kmin, kmax, tb.keys[t], tb.vals[t], nk, tb.index[t], (nk + 63) / 64, sk, sv, lane, res);
+            int32_t *col = out + (int64_t)t * out_stride;
+            if (VEC) join_tile_store_shifted(col, r0, lane, res);
+            else join_tile_store<false>(col, nru, r0, res);
         }
     }
 }
@@ -1625,6 +1713,51 @@ void launch_count_join(const int32_t *bait, const int32_t *oe, int64_t nru, cons
     if (body > 0) count_join_kernel<true><<<grid(body), 256, 0, st>>>(bait, oe, body, keys, vals, nkeys, index, nidx, out);
     if (nru > body)
         count_join_kernel<false><<<grid(nru - body), 256, 0, st>>>(bait + body, oe + body, nru - body, keys, vals, nkeys, index, nidx, out + body);
+}
+
+// all tables' coarse levels in one launch: grid.y = table
+__global__ __launch_bounds__(256) void join_index_multi_kernel(JoinTables tb) {
+    const int t = blockIdx.y;
+    const int64_t nidx = (tb.nkeys[t] + 63) / 64;
+    int64_t *index = const_cast<int64_t *>(tb.index[t]);
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < nidx; j += (int64_t)gridDim.x * 256) index[j] = tb.keys[t][64 * j];
+}
+size_t count_join_multi_scratch_bytes(int S, const int64_t *nkeys) {
+    size_t b = 0;
+    for (int s = 0; s < S; s++) b += count_join_scratch_bytes(nkeys[s]);
+    return b;
+}
+// out: S x nru (replicate-major); keys / vals / nkeys: host arrays of S entries (device pointers inside); scratch: count_join_multi_scratch_bytes
+void launch_count_join_multi(const int32_t *bait, const int32_t *oe, int64_t nru, int S, const int64_t *const *keys, const int32_t *const *vals,
+                             const int64_t *nkeys, int32_t *out, void *scratch, hipStream_t st) {
+    auto grid = [](int64_t rows) {
+        int64_t blocks = (((rows + kJoinTile - 1) / kJoinTile + 3) / 4 + 7) / 8 * 8;
+        return (unsigned)(blocks > 8192 ? 8192 : (blocks < 8 ? 8 : blocks));
+    };
+    int64_t *index = (int64_t *)scratch;
+    for (int s0 = 0; s0 < S; s0 += kJoinMaxTables) {
+        JoinTables tb{};
+        tb.T = S - s0 < kJoinMaxTables ? S - s0 : kJoinMaxTables;
+        int64_t maxidx = 0;
+        for (int t = 0; t < tb.T; t++) {
+            tb.keys[t] = keys[s0 + t];
+            tb.vals[t] = vals[s0 + t];
+            tb.nkeys[t] = nkeys[s0 + t];
+            tb.index[t] = index;
+            const int64_t nidx = (nkeys[s0 + t] + 63) / 64;
+            index += nidx + 1;
+            maxidx = nidx > maxidx ? nidx : maxidx;
+        }
+        if (maxidx > 0) {
+            int64_t bx = (maxidx + 255) / 256;
+            join_index_multi_kernel<<<dim3((unsigned)(bx > 1024 ? 1024 : bx), tb.T), 256, 0, st>>>(tb);
+        }
+        int32_t *o = out + (int64_t)s0 * nru;
+        const bool vec = (((uintptr_t)bait | (uintptr_t)oe) & 15) == 0;  // (the columns of `out` need not be: join_tile_store_shifted)
+        const int64_t body = vec ? nru / kJoinTile * kJoinTile : 0;
+        if (body > 0) count_join_multi_kernel<true><<<grid(body), 256, 0, st>>>(bait, oe, body, tb, o, nru);
+        if (nru > body) count_join_multi_kernel<false><<<grid(nru - body), 256, 0, st>>>(bait + body, oe + body, nru - body, tb, o + body, nru);
+    }
 }
 
 __global__ __launch_bounds__(256) void pvalue_kernel(const double *__restrict__ stat, int64_t n, double *__restrict__ p) {

@@ -28,7 +28,7 @@ EXPORTS = [
     "chicdiff_hip_fragment_background_dev", "chicdiff_hip_bh_adjust_dev", "chicdiff_hip_ihw_apply_dev",
     "chicdiff_hip_region_universe_count_dev", "chicdiff_hip_region_universe_fill_dev", "chicdiff_hip_region_universe_dev", "chicdiff_hip_count_table_dev",
     "chicdiff_hip_chinput_read", "chicdiff_hip_chinput_table_dev", "chicdiff_hip_region_avdist_dev",
-    "chicdiff_hip_count_join_inner_dev",
+    "chicdiff_hip_count_join_inner_dev", "chicdiff_hip_count_join_multi_dev",
     "chicdiff_hip_malloc", "chicdiff_hip_free", "chicdiff_hip_outstanding_allocations", "chicdiff_hip_memcpy_h2d", "chicdiff_hip_memcpy_d2h",
     "chicdiff_hip_rccl_unique_id", "chicdiff_hip_rccl_init", "chicdiff_hip_cooks_filter_dev",
     "chicdiff_hip_independent_filtering_dev",
@@ -128,6 +128,7 @@ def load_library() -> C.CDLL:
     L.chicdiff_hip_bh_adjust_dev.argtypes = [vp, vp, i64, vp]
     L.chicdiff_hip_region_avdist_dev.argtypes = [vp, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp]
     L.chicdiff_hip_count_join_inner_dev.argtypes = [vp, vp, vp, i64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]
+    L.chicdiff_hip_count_join_multi_dev.argtypes = [vp, vp, vp, i64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]
     L.chicdiff_hip_ihw_apply_dev.argtypes = [vp, vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl), i32, vp, vp, vp, vp]
     L.chicdiff_hip_region_universe_count_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, C.POINTER(i64)]
     L.chicdiff_hip_region_universe_fill_dev.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp, vp, vp, vp]
@@ -321,6 +322,19 @@ class HipContext:
         self._check(self.lib.chicdiff_hip_count_join_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), d_bait.numel(),
                                                          d_keys.data_ptr(), d_vals.data_ptr(), d_keys.numel(),
                                                          out.data_ptr()))
+        return out
+
+    def count_join_multi(self, d_bait, d_oe, tables, out=None):
+        """The chinput branch for all replicates at once (chicdiff.R:843-858, the loop over the replicates): ``tables`` =
+        [(keys, vals)] per replicate; N (S, nru), row s = ``count_join`` with table s, from ONE read of the RU rows."""
+        S, nru = len(tables), d_bait.numel()
+        if out is None:
+            out = self.torch.empty((S, nru), dtype=self.torch.int32, device=self.device)
+        kp = (C.c_void_p * S)(*[k.data_ptr() for k, _ in tables])
+        vp_ = (C.c_void_p * S)(*[v.data_ptr() for _, v in tables])
+        nk = (C.c_int64 * S)(*[k.numel() for k, _ in tables])
+        self._check(self.lib.chicdiff_hip_count_join_multi_dev(self.h, d_bait.data_ptr(), d_oe.data_ptr(), nru, S, kp, vp_, nk,
+                                                               out.data_ptr()))
         return out
 
     def count_join_inner(self, d_bait, d_oe, tables):

@@ -274,9 +274,7 @@ def getFullRegionData(chicdiff_settings, RU, RUcontrol, suffix="", ctx=None, rea
         d_bait, d_oe, ptr = u["csr_baitID"], u["csr_otherEndID"], u["region_ptr"]
         nfrag, n = d_bait.numel(), ptr.numel() - 1
         if countData is not None:
-            fragN = torch.empty((S, nfrag), dtype=torch.int32, device=ctx.device)
-            for i, (keys, vals) in enumerate(tables):
-                fragN[i] = ctx.count_join(d_bait, d_oe, keys, vals)
+            fragN = ctx.count_join_multi(d_bait, d_oe, tables)   # the replicate loop of :843-858 as one pass over the RU rows
         else:
             message("Merging countData")
             fragN = ctx.count_join_inner(d_bait, d_oe, tables)

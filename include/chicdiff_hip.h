@@ -200,6 +200,14 @@ int chicdiff_hip_count_join_dev(chicdiff_hip_ctx *ctx, const int32_t *d_ru_bait,
                                 int64_t nru, const int64_t *d_keys, const int32_t *d_vals, int64_t nkeys,
                                 int32_t *d_out);
 
+/* a1 for ALL replicates in one pass (chicdiff.R:843-858: the loop `for (i in 1:length(chicdiff.settings$countData))` around
+ * merge(RU, temp, all.x = TRUE)): every replicate's column of N from one read of the RU rows.  d_keys / d_vals / nkeys are HOST
+ * arrays of S entries (device pointers inside), one sorted key table per replicate; d_out is nru x S column-major (column s =
+ * replicate s) and equals S calls of chicdiff_hip_count_join_dev bit for bit. */
+int chicdiff_hip_count_join_multi_dev(chicdiff_hip_ctx *ctx, const int32_t *d_ru_bait, const int32_t *d_ru_oe, int64_t nru,
+                                      int32_t S, const int64_t *const *d_keys, const int32_t *const *d_vals,
+                                      const int64_t *nkeys, int32_t *d_out);
+
 /* a1, branch without chinput files (chicdiff.R:774-807, = :1202-1260 in getFullRegionData2): N comes from the
  * replicates' Chicago objects.  tempForCounts[[i]] = x[, c("baitID", "otherEndID", "N")] per replicate;
  * mergedFiles <- Reduce(merge, tempForCounts) is merge()'s default INNER join on (baitID, otherEndID), so a pair keeps its

@@ -14,7 +14,7 @@
 ##
 ##   reference step                                              here
 ##   fread(chinput); setkey; x[J(baits)]        chicdiff.R:828-831   chicdiff_hip_chinput_table (host threads + device sort)
-##   merge(x, temp, all.x = TRUE); N[NA] <- 0   chicdiff.R:843-858   chicdiff_hip_count_join
+##   merge(x, temp, all.x = TRUE); N[NA] <- 0   chicdiff.R:843-858   chicdiff_hip_count_join_multi (all replicates; _count_join: one)
 ##   no chinput: Reduce(merge, tempForCounts)   chicdiff.R:742-747, 774-807   chicdiff_hip_count_table + chicdiff_hip_count_join_inner
 ##   s_j / s_i / tblb / tlb / Tmean collection  chicdiff.R:656-692   .hipBackgroundTables (R: reads the Chicago objects)
 ##   .chicEstimateDistFun, .estimateBMean       chicdiff.R:538-573, 695-702   R lm() refit, then chicdiff_hip_fragment_background
@@ -161,8 +161,8 @@
     dOE <- .hipCall("chicdiff_hip_upload", ctx, csr$otherEndID)
     on.exit({ .hipCall("chicdiff_hip_release", dBait); .hipCall("chicdiff_hip_release", dOE) }, add = TRUE)
     if (haveChinput) {
-      fragN <- .hipCall("chicdiff_hip_alloc", ctx, "integer", as.double(csr$nfrag) * S)
-      for (i in seq_len(S)) .hipCall("chicdiff_hip_count_join", ctx, dBait, dOE, tables[[i]], fragN, as.double(i - 1L))
+      ## the loop over the replicates of chicdiff.R:843-858 as ONE pass over the RU rows (every replicate's merge() read them again)
+      fragN <- .hipCall("chicdiff_hip_count_join_multi", ctx, dBait, dOE, tables)
     } else {
       message("Merging countData")                                     # chicdiff.R:789-805: inner merge over the replicates
       fragN <- .hipCall("chicdiff_hip_count_join_inner", ctx, dBait, dOE, tables)

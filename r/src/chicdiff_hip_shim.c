@@ -21,6 +21,7 @@
  *   chicdiff_hip_region_universe chicdiff.R:376-401
  *   chicdiff_hip_chinput_table chicdiff.R:828-831, 849              fread(chinput), RU baits only, keyed (baitID, otherEndID)
  *   chicdiff_hip_count_join    chicdiff.R:843-858                   N per RU row and replicate, 0 where unobserved
+ *   chicdiff_hip_count_join_multi   chicdiff.R:843-858 (the whole replicate loop)   the same for all replicates from one read of the RU rows
  *   chicdiff_hip_bait_flags    chicdiff.R:775                       sort(unique(RU$baitID)) as a device flag table, built once
  *   chicdiff_hip_count_table / chicdiff_hip_count_join_inner  chicdiff.R:742-747, 774-807   the same without chinput files
  *   chicdiff_hip_region_avdist chicdiff.R:868-882, 1965             avDist = mean(distSign) by region for IHWcorrection()
@@ -594,11 +595,11 @@ SEXP chicdiff_hip_count_table(SEXP ctx, SEXP bait, SEXP oe, SEXP N, SEXP baits) 
     return out;
 }
 
-/* .Call(chicdiff_hip_count_join_inner, ctx, ru_bait, ru_oe (device or host integer nru), tables (list of S key tables))
- * -> device integer nru x S.  mergedFiles <- Reduce(merge, tempForCounts) (an inner join over the replicates), then
- * merge(x, temp, all.x = TRUE); x[is.na(N), N := 0] per replicate (chicdiff.R:779-803) */
-SEXP chicdiff_hip_count_join_inner(SEXP ctx, SEXP ru_bait, SEXP ru_oe, SEXP tables) {
-    if (TYPEOF(tables) != VECSXP || LENGTH(tables) < 1 || LENGTH(tables) > 64) Rf_error("chicdiff_hip_count_join_inner: a list of 1..64 key tables expected");
+/* the replicates' key tables (a list of S list(keys, vals, nkeys, ...) as chicdiff_hip_count_table / chicdiff_hip_chinput_table return
+ * them) against the RU rows: inner = 1 the no-chinput branch (Reduce(merge) first), 0 the chinput branch (S independent left joins
+ * from one read of the RU rows) -> device integer nru x S */
+static SEXP join_over_tables(SEXP ctx, SEXP ru_bait, SEXP ru_oe, SEXP tables, int inner, const char *who) {
+    if (TYPEOF(tables) != VECSXP || LENGTH(tables) < 1 || LENGTH(tables) > 64) Rf_error("%s: a list of 1..64 key tables expected", who);
     const int S = LENGTH(tables);
     const R_xlen_t nru = TYPEOF(ru_bait) == EXTPTRSXP ? devbuf_of(ru_bait, INTSXP, -1, "ru_bait")->len : XLENGTH(ru_bait);
     const int64_t *keys[64];
@@ -606,22 +607,39 @@ SEXP chicdiff_hip_count_join_inner(SEXP ctx, SEXP ru_bait, SEXP ru_oe, SEXP tabl
     int64_t nkeys[64];
     for (int s = 0; s < S; s++) {
         SEXP t = VECTOR_ELT(tables, s);
-        if (TYPEOF(t) != VECSXP || LENGTH(t) < 3) Rf_error("chicdiff_hip_count_join_inner: table %d does not come from chicdiff_hip_count_table", s + 1);
+        if (TYPEOF(t) != VECSXP || LENGTH(t) < 3) Rf_error("%s: table %d does not come from chicdiff_hip_count_table", who, s + 1);
         devbuf *k = devbuf_of(VECTOR_ELT(t, 0), REALSXP, -1, "table$keys"), *v = devbuf_of(VECTOR_ELT(t, 1), INTSXP, -1, "table$vals");
         nkeys[s] = (int64_t)Rf_asReal(VECTOR_ELT(t, 2));
-        if (nkeys[s] < 0 || nkeys[s] > k->len || nkeys[s] > v->len) Rf_error("chicdiff_hip_count_join_inner: table$nkeys does not fit table %d", s + 1);
+        if (nkeys[s] < 0 || nkeys[s] > k->len || nkeys[s] > v->len) Rf_error("%s: table$nkeys does not fit table %d", who, s + 1);
         keys[s] = (const int64_t *)k->d;
         vals[s] = (const int32_t *)v->d;
     }
     SEXP dB = as_device(ctx, ru_bait, INTSXP, nru, "ru_bait"), dO = as_device(ctx, ru_oe, INTSXP, nru, "ru_oe");
     SEXP res = devbuf_new(ctx, INTSXP, nru * S);
-    check_rc(ctx, chicdiff_hip_count_join_inner_dev(ctx_of(ctx), (const int32_t *)dptr(dB), (const int32_t *)dptr(dO), (int64_t)nru, S, keys, vals, nkeys,
-                                                    (int32_t *)dptr(res)),
-             "chicdiff_hip_count_join_inner");
+    check_rc(ctx, inner ? chicdiff_hip_count_join_inner_dev(ctx_of(ctx), (const int32_t *)dptr(dB), (const int32_t *)dptr(dO), (int64_t)nru, S, keys, vals, nkeys,
+                                                            (int32_t *)dptr(res))
+                        : chicdiff_hip_count_join_multi_dev(ctx_of(ctx), (const int32_t *)dptr(dB), (const int32_t *)dptr(dO), (int64_t)nru, S, keys, vals, nkeys,
+                                                            (int32_t *)dptr(res)),
+             who);
     release_if_temp(dB, ru_bait);
     release_if_temp(dO, ru_oe);
     UNPROTECT(3);
     return res;
+}
+
+/* .Call(chicdiff_hip_count_join_inner, ctx, ru_bait, ru_oe (device or host integer nru), tables (list of S key tables))
+ * -> device integer nru x S.  mergedFiles <- Reduce(merge, tempForCounts) (an inner join over the replicates), then
+ * merge(x, temp, all.x = TRUE); x[is.na(N), N := 0] per replicate (chicdiff.R:779-803) */
+SEXP chicdiff_hip_count_join_inner(SEXP ctx, SEXP ru_bait, SEXP ru_oe, SEXP tables) {
+    return join_over_tables(ctx, ru_bait, ru_oe, tables, 1, "chicdiff_hip_count_join_inner");
+}
+
+/* .Call(chicdiff_hip_count_join_multi, ctx, ru_bait, ru_oe (device or host integer nru), tables (list of S tables of
+ *       chicdiff_hip_chinput_table)) -> device integer nru x S: the loop over the replicates of chicdiff.R:843-858 —
+ * `merge(x, temp, all.x = TRUE); x[is.na(N), N := 0]` for every replicate — from ONE read of the RU rows; column s equals
+ * chicdiff_hip_count_join with table s bit for bit */
+SEXP chicdiff_hip_count_join_multi(SEXP ctx, SEXP ru_bait, SEXP ru_oe, SEXP tables) {
+    return join_over_tables(ctx, ru_bait, ru_oe, tables, 0, "chicdiff_hip_count_join_multi");
 }
 
 /* .Call(chicdiff_hip_region_avdist, ctx, ru_bait, ru_oe (device or host integer, (regionID, otherEndID) order), region_ptr
@@ -779,6 +797,7 @@ static const R_CallMethodDef call_methods[] = {{"chicdiff_hip_open", (DL_FUNC)&c
                                                {"chicdiff_hip_chinput_table", (DL_FUNC)&chicdiff_hip_chinput_table, 3},
                                                {"chicdiff_hip_count_table", (DL_FUNC)&chicdiff_hip_count_table, 5},
                                                {"chicdiff_hip_count_join_inner", (DL_FUNC)&chicdiff_hip_count_join_inner, 4},
+                                               {"chicdiff_hip_count_join_multi", (DL_FUNC)&chicdiff_hip_count_join_multi, 4},
                                                {"chicdiff_hip_region_avdist", (DL_FUNC)&chicdiff_hip_region_avdist, 7},
                                                {"chicdiff_hip_count_join", (DL_FUNC)&chicdiff_hip_count_join, 6},
                                                {"chicdiff_hip_fragment_background", (DL_FUNC)&chicdiff_hip_fragment_background, 12},

@@ -325,6 +325,53 @@ def test_count_join_window_boundary(ctx, oracle):
             assert np.array_equal(got, oracle.count_join(qb, oe, keys, vals)), (start, width)
 
 
+def test_count_join_all_replicates_in_one_pass(ctx, oracle):
+    """chicdiff_hip_count_join_multi_dev (the replicate loop of chicdiff.R:843-858 as ONE pass over the RU rows) against S single joins and
+    the oracle, bit for bit: row counts in every residue mod 4 (a replicate's column of the S x nru result starts 16-byte aligned for one
+    nru in four: the shifted store), ragged last tiles, tables of very different sizes incl. an empty one, more replicates than one
+    launch takes (16), unaligned query pointers, unsorted callers, and tiles on both sides of the 768-key window."""
+    import torch
+    rng = np.random.default_rng(4242)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(ctx.device)
+    rb = np.repeat(rng.integers(1000, 1400, 6000), 11).astype(np.int32)
+    ro = (np.repeat(rng.integers(20, 29000, 6000), 11) + np.tile(np.arange(11), 6000)).astype(np.int32)
+    o2 = np.argsort(rb, kind="stable")                                     # setkey(RU, baitID)
+    rb, ro = rb[o2], ro[o2]
+    allk = np.unique((rng.integers(1000, 1400, 1500000).astype(np.int64) << 32) | rng.integers(0, 30000, 1500000))
+
+    def tables(S):
+        out = []
+        for s in range(S):
+            kk = allk[rng.uniform(size=len(allk)) < (0.9, 0.5, 0.02, 0.0, 0.3)[s % 5]]   # dense (global-search tiles), medium, sparse, EMPTY
+            out.append((kk, rng.integers(1, 500, len(kk)).astype(np.int32)))
+        return out
+
+    for S, nq, off in ((8, len(rb), 0), (8, len(rb) - 1, 0), (8, len(rb) - 2, 0), (8, len(rb) - 3, 0), (3, 513, 0), (2, 1, 0), (1, 7, 0),
+                       (20, 4099, 0), (5, 30001, 1), (5, 30001, 3), (4, 512, 0), (4, 1024, 2)):
+        tabs = tables(S)
+        qb, qo = rb[off:nq], ro[off:nq]
+        db, do = t(rb)[off:nq], t(ro)[off:nq]
+        dt = [(t(k), t(v)) for k, v in tabs]
+        got = ctx.count_join_multi(db, do, dt).cpu().numpy()
+        assert got.shape == (S, len(qb))
+        for s, (k, v) in enumerate(tabs):
+            assert np.array_equal(got[s], oracle.count_join(qb, qo, k, v)), (S, nq, off, s)
+            assert np.array_equal(got[s], ctx.count_join(db, do, dt[s][0], dt[s][1]).cpu().numpy()), (S, nq, off, s)
+        assert (got > 0).any() or len(qb) < 8
+    # an unsorted caller (every tile spans the whole table: the global search) and extreme IDs
+    perm = rng.permutation(20000)
+    tabs = tables(3)
+    dt = [(t(k), t(v)) for k, v in tabs]
+    got = ctx.count_join_multi(t(rb[perm]), t(ro[perm]), dt).cpu().numpy()
+    for s, (k, v) in enumerate(tabs):
+        assert np.array_equal(got[s], oracle.count_join(rb[perm], ro[perm], k, v)), s
+    xb = np.array([2**31 - 1, 1000, -5, 1200, 1200], dtype=np.int32)
+    xo = np.array([-1, 5, 7, 2**31 - 1, 17], dtype=np.int32)
+    got = ctx.count_join_multi(t(xb), t(xo), dt).cpu().numpy()
+    for s, (k, v) in enumerate(tabs):
+        assert np.array_equal(got[s], oracle.count_join(xb, xo, k, v)), s
+
+
 def test_theta_grid(ctx, oracle):
     d = synth.make(6000, 8, fragments=3)
     keep = d["counts"].sum(1) > 0

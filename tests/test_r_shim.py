@@ -76,8 +76,8 @@ def test_every_dot_call_is_registered_with_matching_arity():
             seen.add(name)
     for must in ("chicdiff_hip_open", "chicdiff_hip_window_sums", "chicdiff_hip_size_factors", "chicdiff_hip_theta_grid",
                  "chicdiff_hip_wald_test", "chicdiff_hip_fit", "chicdiff_hip_release", "chicdiff_hip_chinput_table",
-                 "chicdiff_hip_count_join", "chicdiff_hip_fragment_background", "chicdiff_hip_alloc", "chicdiff_hip_region_universe",
-                 "chicdiff_hip_ihw_apply", "chicdiff_hip_bait_flags", "chicdiff_hip_count_table", "chicdiff_hip_count_join_inner",
+                 "chicdiff_hip_fragment_background", "chicdiff_hip_region_universe",
+                 "chicdiff_hip_ihw_apply", "chicdiff_hip_bait_flags", "chicdiff_hip_count_table", "chicdiff_hip_count_join_inner", "chicdiff_hip_count_join_multi",
                  "chicdiff_hip_region_avdist", "chicdiff_hip_download", "chicdiff_hip_upload"):
         assert must in seen, must
 
@@ -93,7 +93,7 @@ def test_shim_uses_only_declared_library_entry_points():
                  "chicdiff_hip_wald_test_dev", "chicdiff_hip_nbglm_fit_dev", "chicdiff_hip_cooks_filter_dev",
                  "chicdiff_hip_independent_filtering_dev", "chicdiff_hip_chinput_read", "chicdiff_hip_chinput_table_dev",
                  "chicdiff_hip_count_join_dev", "chicdiff_hip_fragment_background_dev", "chicdiff_hip_count_table_dev",
-                 "chicdiff_hip_count_join_inner_dev", "chicdiff_hip_region_avdist_dev"):
+                 "chicdiff_hip_count_join_inner_dev", "chicdiff_hip_count_join_multi_dev", "chicdiff_hip_region_avdist_dev"):
         assert must in used, must
 
 

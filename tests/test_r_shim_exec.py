@@ -4,7 +4,7 @@ r/src/chicdiff_hip_shim.c had never run: R is absent from the authoring image an
 small FUNCTIONAL stand-in for the slice of R's C API the shim uses (vectors, lists with names, PROTECT as a counted stack,
 external pointers with tag / protected slot, finalizers as a list the test runs in the order it likes, Rf_error as a longjmp to
 the harness); tests/r_stub/build_harness.sh links the REAL shim against it and the REAL libchicdiff_hip.so.  Here every one of
-the 22 registered routines is driven with the inputs the ctypes tests use: results equal to the ctypes path (chicdiff_amd/hip.py)
+the 23 registered routines is driven with the inputs the ctypes tests use: results equal to the ctypes path (chicdiff_amd/hip.py)
 bit for bit, PROTECT depth unchanged after every call, device allocations balanced — also after an Rf_error forced at every
 allocation site of every routine and at the shim's own argument checks (wrong length, NA count, S = 65) — and finalizers run
 in registration order, reversed, contexts first and contexts last.
@@ -33,7 +33,10 @@ SEXP = C.c_void_p
 def build_harness():
     stale = not os.path.exists(HARNESS) or any(os.path.getmtime(s) > os.path.getmtime(HARNESS) for s in SOURCES if os.path.exists(s))
     if stale:
-        subprocess.run(["sh", os.path.join(ROOT, "tests", "r_stub", "build_harness.sh")], check=True, capture_output=True)
+        r = subprocess.run(["sh", os.path.join(ROOT, "tests", "r_stub", "build_harness.sh")], capture_output=True, text=True,
+                           env=dict(os.environ, CHICDIFF_HARNESS_WERROR="1"))
+        if r.returncode != 0:
+            pytest.fail("the R-stub harness did not build:\n" + r.stderr, pytrace=False)
     return HARNESS
 
 
@@ -130,12 +133,12 @@ class RStub:
 
 
 def test_harness_loads_and_registers_every_routine_with_dynamic_lookup_off():
-    """CPU: the harness links (shim + stand-in + the real library), R_init_chicdiffhip registers 22 .Call routines whose arities
+    """CPU: the harness links (shim + stand-in + the real library), R_init_chicdiffhip registers 23 .Call routines whose arities
     are the ones the R sources use (tests/test_r_shim.py parses those), R_useDynamicSymbols(FALSE) was called, and without a GPU
     chicdiff_hip_open ends in an Rf_error that leaves the PROTECT stack where it was."""
     import re
     r = RStub()
-    assert r.nroutines == 22, r.nroutines  # (negative: dynamic lookup left on)
+    assert r.nroutines == 23, r.nroutines  # (negative: dynamic lookup left on)
     src = open(SOURCES[0]).read()
     reg = {m.group(1): int(m.group(2)) for m in re.finditer(r'\{"(chicdiff_hip_\w+)", \(DL_FUNC\)&\1, (\d+)\}', src)}
     got = {r.L.rstub_routine_name(i).decode(): r.L.rstub_routine_nargs(i) for i in range(r.nroutines)}
@@ -356,6 +359,14 @@ def test_every_call_routine_matches_the_ctypes_path_bit_for_bit(rs, hctx, tmp_pa
     ji_ref = hctx.count_join_inner(_t(hctx, qb, np.int32), _t(hctx, qo, np.int32), tabs_ref)
     assert np.array_equal(r.download(ji), ji_ref.cpu().numpy().ravel()) and (ji_ref > 0).sum() > 10
     call("chicdiff_hip_count_join_inner", ctx, r.int(qb), r.int(qo), r.list([r.int([1])]), expect_error="does not come from chicdiff_hip_count_table")
+    # the chinput branch for all replicates in one pass: S left joins from one read of the RU rows (same table lists)
+    jm = call("chicdiff_hip_count_join_multi", ctx, r.int(qb), r.int(qo), r.list(tabs))
+    jm_ref = hctx.count_join_multi(_t(hctx, qb, np.int32), _t(hctx, qo, np.int32), tabs_ref)
+    assert np.array_equal(r.download(jm), jm_ref.cpu().numpy().ravel()) and (jm_ref > 0).sum() > (ji_ref > 0).sum()
+    for s_, (kr, vr) in enumerate(tabs_ref):
+        assert np.array_equal(jm_ref[s_].cpu().numpy(), hctx.count_join(_t(hctx, qb, np.int32), _t(hctx, qo, np.int32), kr, vr).cpu().numpy())
+    call("chicdiff_hip_count_join_multi", ctx, r.int(qb), r.int(qo), r.list([]), expect_error="a list of 1..64 key tables expected")
+    call("chicdiff_hip_release", jm)
 
     # ---- a3 fragment background ------------------------------------------------------------------------------------------------------------------
     from test_oracle import _a3_inputs
