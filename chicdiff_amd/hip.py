@@ -470,6 +470,8 @@ class HipContext:
                                                               ro.data_ptr(), cap, C.byref(total)))
         self.last_region_universe_ms = self.kernel_times().get("region_universe", (0.0, 0))[0]
         rb, rr, ro = rb[: total.value], rr[: total.value], ro[: total.value]
+        if 2 * total.value < cap:  # (a view would pin the whole upper-bound allocation for as long as the universe lives)
+            rb, rr, ro = rb.clone(), rr.clone(), ro.clone()
         return dict(region_ptr=ptr, minOE=mn, maxOE=mx, baitID=rb, regionID=rr, otherEndID=ro)
 
     # -- a6 + a7 ----------------------------------------------------------------------------

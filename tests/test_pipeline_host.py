@@ -79,6 +79,14 @@ def test_peak_filter_background_tables_and_distance_function(tmp_path):
                                          s["outprefix"])
     assert np.array_equal(x["baitID"].to_numpy(), truth["peak_bait"]) and np.array_equal(x["oeID"].to_numpy(), truth["peak_oe"])
     assert os.path.exists(s["outprefix"] + "_filteredBaits.txt") and 0 < len(x) < 1200
+    # the file's layout, pinned: chicdiff.R:272-274 is fwrite(list(filtered_baits), file) on an UNNAMED list — bare IDs,
+    # one per line, no header line (data.table >= 1.9.8's fwrite writes column names only when names(x) is a character vector; read
+    # from fwriteR.c from memory: no R here, so this pins the mirror's behaviour against silent flips, not data.table's)
+    lines = open(s["outprefix"] + "_filteredBaits.txt").read().split("\n")
+    assert lines[-1] == "" and all(re.fullmatch(r"[0-9]+", ln) for ln in lines[:-1]), lines[:3]
+    import pandas as pd
+    every = pd.unique(pd.concat([pd.read_csv(f, sep="\t") for f in (s["peakfiles"] if isinstance(s["peakfiles"], (list, tuple)) else [s["peakfiles"]])])["baitID"])
+    assert sorted(int(v) for v in lines[:-1]) == sorted(int(b) for b in every if b not in set(x["baitID"]))
     bg = pipeline.background_tables(truth["xs"], truth["id_min"], truth["nid"])
     for j, t in enumerate(truth["tables"]):
         xs = truth["xs"][j]
