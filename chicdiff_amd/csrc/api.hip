@@ -45,8 +45,9 @@ struct chicdiff_hip_ctx {
     bool no_persistent_trend = false;  // set after a grid-barrier timeout (see fit_dev_impl)
     // tuning / test options (chicdiff_hip_set_option); the defaults are what the benchmarks run
     int opt_chunk = 0;  // line search: rows per dequeue (0 = automatic)
+    int opt_prio = 0;   // line search: s_setprio by search age (0 = off)
     int opt_classes_a = 0;  // gene-wise line search: classes of the schedule dealt out statically (0 = default)
-    int opt_spread = 1, opt_min_waves = 2, opt_select_rounds = 0, opt_trend_multilaunch = 0, opt_schedule = 1, opt_deal = 0;
+    int opt_spread = 1, opt_min_waves = 0, opt_select_rounds = 0, opt_trend_multilaunch = 0, opt_schedule = 1, opt_deal = 0;
     int opt_trend_gather = 1;  // sharded fits: gather the rows of the trend on every rank (two collectives) instead of one all-reduce per IRLS pass
     char *tg_buf = nullptr;    // ... the gathered rows (grow-only)
     size_t tg_bytes = 0;
@@ -183,8 +184,9 @@ void chicdiff_hip_default_opts(chicdiff_nbglm_opts *o) {
 int chicdiff_hip_set_option(chicdiff_hip_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return CHICDIFF_E_INVALID;
     const std::string k(name);
-    if (k == "line_search_spread" && value >= 0 && value <= 2) c->opt_spread = (int)value;  // 2: samples across lanes without the lean tick of the launch's end (bit-identity tests)
-    else if (k == "line_search_min_waves" && value >= 2 && value <= 4) c->opt_min_waves = (int)value;
+    if (k == "line_search_spread" && value >= 0 && value <= 3) c->opt_spread = (int)value;  // 2: samples across lanes without the lean tick of the launch's end (bit-identity tests)
+    else if (k == "line_search_min_waves" && (value == 0 || (value >= 2 && value <= 4))) c->opt_min_waves = (int)value;
+    else if (k == "line_search_prio" && value >= 0 && value <= 100) c->opt_prio = (int)value;
     else if (k == "line_search_chunk" && (value == 0 || (value >= 8 && value <= 64))) c->opt_chunk = (int)value;
     else if (k == "line_search_classes_a" && value >= 0 && value <= 6) c->opt_classes_a = (int)value;
     else if (k == "line_search_schedule" && (value == 0 || value == 1)) c->opt_schedule = (int)value;
@@ -480,7 +482,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
         c->ws = nullptr;
     }
     const size_t nd = align256(sizeof(double) * (size_t)n), ni = align256(sizeof(int32_t) * (size_t)n);
-    const size_t n_double_arrays = 15, n_int_arrays = 8;
+    const size_t n_double_arrays = 15, n_int_arrays = 9;
     const size_t partials = align256(sizeof(double) * ((size_t)kRedBlocks * 72 + 128));
     const size_t hist = align256(sizeof(double) * (size_t)kMaxS * 2 * kSelBins);
     const size_t nfbytes = align256(sizeof(double) * (size_t)n * S);
@@ -501,6 +503,7 @@ static int ensure_workspace(chicdiff_hip_ctx *c, int64_t n, int S) {
     takeI(w.allZero); takeI(w.geneIter); takeI(w.mapIter); takeI(w.outlier); takeI(w.betaIter); takeI(w.optimConv);
     takeI(w.order);
     { int32_t *q; takeI(q); w.cls = (uint8_t *)q; }
+    takeI(w.gridlist);
     w.partials = (double *)p; p += partials;
     w.hist = (double *)p; p += hist;
     w.hist_local = (double *)p; p += hist;
@@ -744,6 +747,7 @@ static Opts make_opts(const chicdiff_hip_ctx *c, const chicdiff_nbglm_opts *in, 
     r.fit_type = o.fitType;
     r.spread = c->opt_spread;
     r.min_waves = c->opt_min_waves;
+    r.prio = c->opt_prio;
     r.schedule = c->opt_schedule;
     r.deal = c->opt_deal;
     r.chunk = c->opt_chunk;
@@ -1647,6 +1651,7 @@ int chicdiff_hip_theta_grid_dev(chicdiff_hip_ctx *c, const int32_t *d_counts, co
         chicdiff_hip_ctx *l = c->lanes[k];
         l->opt_spread = c->opt_spread;
         l->opt_min_waves = c->opt_min_waves;
+        l->opt_prio = c->opt_prio;
         l->opt_schedule = c->opt_schedule ? 2 : 0;  // concurrent fits: class order through the queue, nothing dealt out statically
         l->opt_deal = c->opt_deal;
         l->opt_chunk = c->opt_chunk;

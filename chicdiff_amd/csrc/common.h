@@ -24,6 +24,7 @@ struct FitWork {
     int32_t *allZero, *geneIter, *mapIter, *outlier, *betaIter, *optimConv;
     int32_t *order;               // schedule of the gene-wise line search: row indices, likely-long rows first (disp_kernels.hip)
     uint8_t *cls;                 // ... and the class each row was put in (255 = all-zero row: not scheduled)
+    int32_t *gridlist;            // rows whose dispersion line search did not converge (fitDispGrid runs in disp_grid_kernel); their number: queue[16] gene-wise, queue[24] MAP
     char *rowpack;                // row-major copy of the fit's inputs, row i at rowpack + i * row_stride(S): a 32-byte header (kRowHdr), nf[S]
                                   // doubles, counts[S] int32 (written by prep): the row-queue kernels visit rows out of order, and a row that
                                   // is 32 + 12 S contiguous bytes costs one or two cache lines instead of 2 S + 4
@@ -35,7 +36,7 @@ struct FitWork {
     double *hist;                 // kMaxS*2 x kSelBins doubles (f64 so it can ride the all-reduce)
     double *hist_local;           // same size: this rank's round-2 histogram, kept aside for the sharded shortcut
     double *selcnt;               // kSelMaxWorld x kMaxS*2 doubles: per-rank candidate counts
-    unsigned long long *queue;    // work-queue heads (kQueueBytes): [0] gene-wise, [1] MAP, [8..15] spare, [32 + 8 h] the IRLS's eight heads, 64 bytes apart, [192 + 8 h] the MAP line search's
+    unsigned long long *queue;    // work-queue heads (kQueueBytes): [0] gene-wise, [1] MAP, [8..15] spare, [16] / [24] lengths of the gene-wise / MAP grid lists, [32 + 8 h] the IRLS's eight heads, 64 bytes apart, [192 + 8 h] the MAP line search's
     unsigned int *barrier;        // 9 x 64 B: grid-barrier counters of the persistent trend kernel
     FitScalars *sc;
     const double *logfact;        // log(k!) for k < kLogFactN
@@ -57,11 +58,12 @@ struct Opts {
     int32_t fit_type = 0;  // 0 parametric trend, 1 mean (chicdiff_nbglm_opts.fitType)
     // tuning (chicdiff_hip_set_option): not part of the algorithm, results do not depend on them
     int32_t spread = 1;     // line search: samples-across-lanes evaluation for straggler waves (0 = row per lane only)
-    int32_t min_waves = 2;  // line search: waves per SIMD the kernel variant is built for
+    int32_t min_waves = 0;  // line search: waves per SIMD (2 .. 4; 0 = by launch_disp's rule)
     int32_t schedule = 1;   // gene-wise line search / IRLS: visit the rows likely-long first (0 = natural order; 2 = class order through the queue only)
     int32_t deal = 0;       // ... entries per group of its static deal (0 = chosen from the number of entries per wave)
     int32_t chunk = 0;      // line search: rows per dequeue (0 = chosen from the row count; 8 .. 64)
     int32_t classes_a = 0;  // gene-wise line search: score classes dealt out statically (0 = the default, 2; 1 .. 6)
+    int32_t prio = 0;       // line search: issue priority by search age, one level per `prio` iterations (0 = off); option "line_search_prio"
     int32_t trend_blocks = 0;  // persistent trend kernel: at most this many workgroups (0 = one per CU); option "trend_persistent_blocks"
 };
 

@@ -49,6 +49,20 @@ __device__ __forceinline__ void dd_add(DD &a, const DD &b) {
     a.hi = s;
 }
 
+// The row's count profile: c_i = #{j : y_j > i} for i = 0..9, one byte each (S <= 64), in three ints.  It depends on the counts alone,
+// so it is formed once per fit, by prep, and kept in the spare half of the row record's header (bytes 16..27; first version of round 6:
+// formed when a lane stages its row — ~100 integer instructions that, like the whole refill, every lane of a wave executes on
+// nearly every tick of the bulk: gene-wise 1.34 -> 1.41 ms); the sum over the samples of the harmonic sums H_n = sum_{i<n} 1/(r+i), n = min(y_j, nr),
+// that the derivative needs is then sum_{i<nr} c_i / (r+i) — a ROW-level sum of ten terms per tick instead of a tabulated H_n per
+// sample (round 6: the per-tick prefix table shrinks from 22 to 10 LDS slots per lane, which is what lets a third wave per SIMD in).
+struct CountProfile { unsigned int w0 = 0, w1 = 0, w2 = 0; };
+__device__ __forceinline__ void profile_add(CountProfile &c, int y) {
+    const unsigned int m = (unsigned int)(y < 10 ? y : 10);      // bytes [0, m) get + 1
+    const unsigned int a = m < 4u ? m : 4u, b = m < 4u ? 0u : (m < 8u ? m - 4u : 4u), d = m < 8u ? 0u : m - 8u;
+    c.w0 += 0x01010101u & (a == 4u ? 0xffffffffu : ((1u << (8u * a)) - 1u));
+    c.w1 += 0x01010101u & (b == 4u ? 0xffffffffu : ((1u << (8u * b)) - 1u));
+    c.w2 += 0x00000101u & ((1u << (8u * d)) - 1u);
+}
 __device__ __forceinline__ void prep_store(FitDims d, FitWork w, int64_t i, double s, double g0, double g1, double v,
                                            double est, int64_t tot) {
     w.baseMean[i] = s / d.S;
@@ -90,8 +104,9 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
             double s = 0, g0 = 0, g1 = 0;
             int64_t tot = 0;
             int32_t sign = 0;
+            CountProfile cprof;
             uint32_t *row = s_tile + tid * ldw;
-            for (int k = 4; k < 8; k++) row[k] = 0;                           // second half of the header (start values: the kernels' init passes)
+            row[7] = 0;                                                        // second half of the header: the count profile (three words, below) + one spare
             for (int k = 8 + 3 * S; k < (int)(stride / 4); k++) row[k] = 0;  // the pad behind the row
             double fv[16];
             if (FUSED) {  // the row's normalisation factors from FullMean (offsets_row16: the function offsets16_kernel runs)
@@ -111,6 +126,7 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
                     row[8 + 2 * j] = (uint32_t)__double2loint(f);
                     row[8 + 2 * j + 1] = (uint32_t)__double2hiint(f);
                     row[8 + 2 * S + j] = (uint32_t)k;
+                    profile_add(cprof, k);
                     sign |= k;
                     q[j] = (double)k / f;
                     tot += k;
@@ -125,6 +141,9 @@ __global__ __launch_bounds__(256) void prep16_kernel(const int32_t *__restrict__
             row[1] = (uint32_t)__double2hiint(g0) | (tot == 0 ? 0x80000000u : 0u);  // sign bit of the (never negative) mean: the row is all zero — the row-queue kernels read the flag with the record
             row[2] = (uint32_t)__double2loint(g1);
             row[3] = (uint32_t)__double2hiint(g1);
+            row[4] = cprof.w0;
+            row[5] = cprof.w1;
+            row[6] = cprof.w2;
             s_live[tid] = tot != 0;
             const double m0 = fmax(1.0, g0), m1 = fmax(1.0, g1);
             const double i0 = 1.0 / (m0 * m0), i1 = 1.0 / (m1 * m1);  // two divisions per row instead of one per sample
@@ -175,9 +194,11 @@ __global__ __launch_bounds__(256) void prep_kernel(const int32_t *__restrict__ c
         int64_t tot = 0;
         double *rp_nf = reinterpret_cast<double *>(w.rowpack + i * row_stride(S) + kRowHdr);
         int32_t *rp_y = reinterpret_cast<int32_t *>(rp_nf + S);
+        CountProfile cprof;
         for (int j = 0; j < S; j++) {
             const int32_t k = counts[(int64_t)j * n + i];
             if (k < 0) w.sc->neg_counts = 1;
+            profile_add(cprof, k);
             rp_nf[j] = nf[(int64_t)j * n + i];
             rp_y[j] = k;
             const double q = (double)k / nf[(int64_t)j * n + i];
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const int32_t *__restrict__ c
         g0 /= d.nA;
         if (d.p == 2) g1 /= d.nB;
         reinterpret_cast<double2 *>(row_hdr(w.rowpack, i, S))[0] = make_double2(tot == 0 ? -0.0 : g0, g1);  // first half of the row's header; sign bit = all-zero row
+        reinterpret_cast<uint4 *>(row_hdr(w.rowpack, i, S))[1] = make_uint4(cprof.w0, cprof.w1, cprof.w2, 0u);  // second half: the count profile
         const double m0 = fmax(1.0, g0), m1 = fmax(1.0, g1);
         double v = 0, est = 0;
         for (int j = 0; j < S; j++) {
@@ -459,13 +481,16 @@ __global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Op
             reinterpret_cast<double2 *>(w.start)[2 * i] = make_double2(dg > 0.1 * df ? log(dg) : ldf, ldf);  // start value, prior mean
             reinterpret_cast<double2 *>(w.start)[2 * i + 1] = make_double2(dg, (double)is_out);  // ... and what the search hands through: the gene-wise estimate, the outlier flag
             w.outlier[i] = is_out;
+            if (is_out) w.disp[i] = dg;  // an outlier keeps its gene-wise estimate (A4): written HERE, so that the search carries one bit for it, not the value
         }
     }
     if (!MAP && tile > 0) order_hist_store(mine, hist);
 }
 
 constexpr int kChunk = 64;   // rows a wave takes from the global queue per atomic (at most: DispArgs::chunk)
-enum Phase : int { PH_NEED = 0, PH_INIT = 1, PH_SEARCH = 2, PH_GRID1 = 3, PH_GRID2 = 4, PH_DONE = 5 };
+constexpr int kTabSlots = 10;  // LDS slots (64 doubles each) of a wave's prefix table = its samples-across-lanes exchange area (128 entries of 36 bytes)
+static inline size_t disp_lds_per_wave(int S) { return (size_t)kTabSlots * 64 * 8 + (size_t)S * 64 * 12 + 3 * 64 * 4; }
+enum Phase : int { PH_NEED = 0, PH_INIT = 1, PH_SEARCH = 2, PH_DONE = 5 };
 
 // One row of FitWork::rowpack -> the lane's LDS column, with mu_j = max(nf_j * groupmean_g, minmu) formed on the way (what the
 // line search needs of nf_j).  All of the record's 16-byte loads are in flight before the first is used (S a multiple of four up
@@ -481,6 +506,7 @@ __device__ __forceinline__ bool load_row_mu_fixed(const char *row, double *s_nf,
     const double2 *p = reinterpret_cast<const double2 *>(row);
     const int4 *py = reinterpret_cast<const int4 *>(row + kRowHdr + 32 * Q);
     const double2 h0 = p[0];  // the two group means; sign bit of the first: all-zero row
+    const int4 prof = *reinterpret_cast<const int4 *>(row + 16);  // the count profile (prep)
     double2 f[2 * Q];
     int4 y[Q];
 #pragma unroll
@@ -503,6 +529,9 @@ __device__ __forceinline__ bool load_row_mu_fixed(const char *row, double *s_nf,
         s_y[(4 * k) * 64 + lane] = y[k].x; s_y[(4 * k + 1) * 64 + lane] = y[k].y;
         s_y[(4 * k + 2) * 64 + lane] = y[k].z; s_y[(4 * k + 3) * 64 + lane] = y[k].w;
     }
+    s_y[(4 * Q) * 64 + lane] = prof.x;
+    s_y[(4 * Q + 1) * 64 + lane] = prof.y;
+    s_y[(4 * Q + 2) * 64 + lane] = prof.z;
     return __double2hiint(h0.x) >= 0;
 }
 __device__ __forceinline__ bool load_row_mu(const char *row, int S, double *s_nf, int *s_y, int lane, uint64_t gmask, double minmu) {
@@ -518,10 +547,14 @@ __device__ __forceinline__ bool load_row_mu(const char *row, int S, double *s_nf
     if (__double2hiint(hdr[0]) < 0) return false;
     const double *pf = reinterpret_cast<const double *>(row + kRowHdr);
     const int *py = reinterpret_cast<const int *>(row + kRowHdr + 8 * S);
+    const int4 prof = *reinterpret_cast<const int4 *>(row + 16);  // the count profile (prep)
     for (int j = 0; j < S; j++) {
         s_nf[j * 64 + lane] = max_num(pf[j] * (((gmask >> j) & 1) ? hdr[1] : hdr[0]), minmu);
         s_y[j * 64 + lane] = py[j];
     }
+    s_y[S * 64 + lane] = prof.x;
+    s_y[(S + 1) * 64 + lane] = prof.y;
+    s_y[(S + 2) * 64 + lane] = prof.z;
     return true;
 }
 
@@ -537,6 +570,9 @@ struct DispArgs {
     int deal;                    // entries per group of the static deal (0 = by the number of entries per wave)
     int prefetch;                // 1 = warm the cache lines of the rows handed out next
     int chunk;                   // rows per dequeue (<= kChunk)
+    int32_t *gridlist;           // rows whose line search did not converge: fitDispGrid's two stages run in disp_grid_kernel (round 6)
+    unsigned int *gridcount;     // ... and their number
+    int prio;                    // > 0: a wave raises its issue priority (s_setprio) by one level per `prio` iterations of its oldest search
 };
 // make ISA_MARK=1 (tools/isa_account.py): comment lines in the generated assembly that delimit the parts of a tick; a volatile asm
 // statement also keeps the compiler from moving code across it, so the marked build is for counting, not for running
@@ -564,7 +600,9 @@ constexpr int kStampSlots = 34;  // start, queue-empty, exit (s_memrealtime), li
 //     lgS = Stirling's series (valid as both arguments are >= 10); likewise for digamma with the
 //     derivative of the product.  Samples with y <= nr need no Stirling term, samples on rows
 //     with alpha <= 0.1 need no product;
-//     The nr+1 prefix products and harmonic sums are tabulated once per row and tick in LDS;
+//     The nr prefix products P_1 .. P_nr are tabulated once per row and tick in LDS (P_0 = 1); the harmonic sums are not: summed
+//     over the samples they are sum_{i<nr} c_i / (r+i) with the row's count profile c_i = #{j : y_j > i} (CountProfile above),
+//     ten terms at row level (round 6; before: H_n tabulated beside P_n, 22 LDS slots per lane instead of 10);
 //   * the products of all samples are multiplied up (mantissa/exponent) and logged ONCE per row.
 // mu_j = max(nf_j * groupmean_g, minmu) sits in LDS (formed when the row is staged).
 struct RowConsts {  // what depends only on the evaluation point a = log(alpha)
@@ -594,11 +632,11 @@ struct SampleVals {
     double wj, pm, tll, tsd;
     int pe;
 };
-// P = prod_{i<n}(r+i), H = sum_{i<n} 1/(r+i) for n = min(y, nr)
+// P = prod_{i<n}(r+i) for n = min(y, nr) (the harmonic sums H_n of the derivative are added at row level: harmonic_row)
 // mu = max(nf_j * groupmean_g, minmu) does not change during a row's search: it is formed once, when the row is staged, and kept in
 // the LDS column in place of nf_j (round 3: five instructions per sample and tick less, two shuffled operands less per
 // samples-across-lanes tick; same product, same bits)
-__device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double mu, int yi, double P, double H, const LogEntry *lt) {
+__device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double mu, int yi, double P, const LogEntry *lt) {
     SampleVals v;
     const double y = (double)yi;
     const double ma = mu * c.alpha;
@@ -606,7 +644,7 @@ __device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double m
     const double rt = rcp(t);
     const double L = tlog1p_from(ma, t, rt, lt);
     v.wj = mu * rt;  // 1 / (1/mu + alpha)
-    double dlg = 0.0, ddg = H;
+    double dlg = 0.0, ddg = 0.0;
     v.pe = __builtin_amdgcn_frexp_exp(P);
     v.pm = __builtin_amdgcn_frexp_mant(P);
     // (Measured, round 4: the two halves of a sample — log1p(mu alpha) with its reciprocal, the Stirling difference at z = y + r
@@ -618,7 +656,7 @@ __device__ __forceinline__ SampleVals sample_values(const RowConsts &c, double m
         double lgz, dgz;
         stirling(z, tlog(z, lt), rcp(z), lgz, dgz);
         dlg = lgz - c.lgS0;
-        ddg += dgz - c.dgS0;
+        ddg = dgz - c.dgS0;
     }
     v.tll = fma(-c.r, L, fma(-y, L - c.a, dlg));          // dlg - y (L - a) - r L
     v.tsd = fma(y * c.alpha, rt, fma(-ma, rt, L - ddg));  // L - ddg - ma/t + y alpha/t
@@ -638,7 +676,40 @@ __device__ __forceinline__ void accumulate(Acc &acc, const SampleVals &v, bool g
     acc.ll += v.tll;
     acc.sd += v.tsd;
 }
-__device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c, bool p2, bool use_prior,
+// sum over the samples of H_{min(y_j, nr)} = sum_{i < nr} c_i / (r + i), i ascending, from the row's count profile (three ints, ten
+// bytes).  TABLE: the same ten steps also leave the prefix products P_1 .. P_10 in the lane's LDS column (entries beyond the lane's nr
+// are never read; all ten steps in every lane, no trip count: round 4).  Both evaluation layouts call this with the same operands —
+// same bits.  r < 6e30 keeps r^10 finite.
+template <bool TABLE>
+__device__ __forceinline__ double harmonic_row(const RowConsts &c, unsigned int w0, unsigned int w1, unsigned int w2, double *s_tab, int lane) {
+    // bytes i >= nr of the profile do not count
+    const unsigned int nr = (unsigned int)c.nr;
+    const unsigned int a = nr < 4u ? nr : 4u, b = nr < 4u ? 0u : (nr < 8u ? nr - 4u : 4u), d = nr < 8u ? 0u : nr - 8u;
+    w0 &= a == 4u ? 0xffffffffu : ((1u << (8u * a)) - 1u);
+    w1 &= b == 4u ? 0xffffffffu : ((1u << (8u * b)) - 1u);
+    w2 &= (1u << (8u * d)) - 1u;
+    double P = 1.0, Hr = 0.0, zz = c.r;
+#ifdef HR_ROLLED
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+    for (int i = 0; i < 10; i++) {
+        const unsigned int w = i < 4 ? w0 : (i < 8 ? w1 : w2);
+        const double ci = (double)((w >> (8 * (i & 3))) & 0xffu);
+        Hr = fma(ci, rcp(zz), Hr);
+        if (TABLE) {
+            P *= zz;
+            s_tab[i * 64 + lane] = P;
+        }
+        zz += 1.0;
+#ifdef HR_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    return Hr;
+}
+__device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c, double Hrow, bool p2, bool use_prior,
                                              double prior_mean, double prior_isig, double &lp, double &dlp,
                                              const LogEntry *lt) {
     const double ll = acc.ll + fma((double)acc.pe, 0.69314718055994530942, tlog(acc.pm, lt));
@@ -657,7 +728,7 @@ __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c,
         dpr = -dd * prior_isig;
     }
     lp = ll + pr + cr;
-    dlp = (c.r * c.r * acc.sd + dcr) * c.alpha + dpr;
+    dlp = (c.r * c.r * (acc.sd - Hrow) + dcr) * c.alpha + dpr;
 }
 
 // Row-per-lane evaluation: all S samples of the row in LDS column `slot` (the lane's own row, or — grid burst —
@@ -673,26 +744,12 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
     alpha_out = c.alpha;
     MARK("row:row_consts_end");
     DIAG(tm[1] = __builtin_amdgcn_s_memtime();)
-    // per-tick table (LDS, [entry][lane]): P_n and H_n for n = 0..nr
-    // (All ten steps in every lane, no trip count: entries beyond a lane's nr are never read, and a loop that stops at the lane's
-    // own nr runs — in SIMD — to the wave's largest, which is 9 or 10 on nearly every tick; worse, the compiler unrolled it by
-    // eight with a remainder loop, so a wave holding nr = 10 and nr = 7 ran 8 + 7 steps.  In-kernel timers, round 4: 2 200 of a
-    // bulk tick's 16 000 cycles were spent here.  r < 6e30 keeps r^10 finite.)
-    {
-        double P = 1.0, H = 0.0, zz = c.r;
-        s_tab[lane] = 1.0;
-        s_tab[11 * 64 + lane] = 0.0;
-        if (__ballot(c.nr > 0) != 0ull) {
-#pragma unroll
-            for (int i = 1; i <= 10; i++) {
-                P *= zz;
-                H += rcp(zz);
-                zz += 1.0;
-                s_tab[i * 64 + lane] = P;
-                s_tab[(11 + i) * 64 + lane] = H;
-            }
-        }
-    }
+    // per-tick table (LDS, [entry][lane]): P_n for n = 1..10, and the row-level harmonic sum from the count profile of the row in
+    // column `slot` (harmonic_row: ten unconditional steps — in-kernel timers, round 4: a loop to the lane's own nr ran, in SIMD, to the
+    // wave's largest, and unrolled by eight plus a remainder loop)
+    double Hrow = 0.0;
+    if (__ballot(c.nr > 0) != 0ull)
+        Hrow = harmonic_row<true>(c, (unsigned int)s_y[S * 64 + slot], (unsigned int)s_y[(S + 1) * 64 + slot], (unsigned int)s_y[(S + 2) * 64 + slot], s_tab, lane);
     MARK("row:table_end");
     DIAG(tm[2] = __builtin_amdgcn_s_memtime();)
     Acc acc;
@@ -700,11 +757,12 @@ __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, d
         const int yi = s_y[j * 64 + slot];
         const int n = yi < c.nr ? yi : c.nr;
         const bool g = (gmask >> j) & 1;
-        accumulate(acc, sample_values(c, s_nf[j * 64 + slot], yi, s_tab[n * 64 + lane], s_tab[(11 + n) * 64 + lane], lt), g);
+        const double Pt = s_tab[((n > 0 ? n : 1) - 1) * 64 + lane];  // (n = 0: P_0 = 1; the entry read instead is never used)
+        accumulate(acc, sample_values(c, s_nf[j * 64 + slot], yi, n > 0 ? Pt : 1.0, lt), g);
     }
     MARK("row:samples_end");
     DIAG(tm[3] = __builtin_amdgcn_s_memtime();)
-    finish_point(acc, c, p2, use_prior, prior_mean, prior_isig, lp, dlp, lt);
+    finish_point(acc, c, Hrow, p2, use_prior, prior_mean, prior_isig, lp, dlp, lt);
     MARK("row:finish_end");
     DIAG(tm[4] = __builtin_amdgcn_s_memtime();)
 }
@@ -743,13 +801,15 @@ __device__ __forceinline__ SpreadMap spread_map(double *s_x, int lane, int lg, u
     // g (one LDS round trip instead of a walk over the set bits: ~50 instructions per tick of a launch's latency-bound end)
     const int nact = __popcll(actmask);
     const int myrank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(actmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)actmask, 0u));
-    int *s_own = reinterpret_cast<int *>(s_x + 4 * 256) + 256;  // behind the exchange area
+    int *s_own = reinterpret_cast<int *>(s_x);  // in the exchange area itself: read here, before an evaluation writes the area again (a wave's LDS operations execute in order)
+    __builtin_amdgcn_wave_barrier();            // (every lane has read the last evaluation's values)
     if (active) s_own[myrank] = lane;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     m.has = grp < nact;
     m.owner = m.has ? s_own[grp] : 0;
+    __builtin_amdgcn_wave_barrier();            // (... and the look-up is over before the area is written again)
     m.src = (active ? myrank : 0) << lg;  // an active lane's group is its rank among the active lanes
     m.pm_o = use_prior ? __shfl(prior_mean, m.owner) : 0.0;
     return m;
@@ -775,60 +835,79 @@ __device__ __forceinline__ void eval_point_spread(const double *s_nf, const int 
     MARK("spread:row_consts_end");
     DIAG(tm[2] = __builtin_amdgcn_s_memtime();)
     // the five values of every sample pass through the wave's prefix-table area (idle in this layout), [value][sample R + group]:
-    // each lane then reads its group's S samples — four samples' loads in flight at a time, same address within a group (a
+    // each lane then reads its group's samples — four samples' loads in flight at a time, same address within a group (a
     // broadcast), neighbouring banks across groups — and folds them in sample order.  (Round 2 fetched them with nine
     // ds_bpermute per sample inside the fold loop: one LDS round trip per sample on the critical path of a tick that is all
-    // latency.)  S R <= 256 entries: 4 x 256 doubles + 256 ints of the 22 x 64 doubles.
-    int *s_xe = reinterpret_cast<int *>(s_x + 4 * 256);
-    for (int j = jj; j < S; j += L) {  // (the same trip count in every lane of a group up to the guard)
-        const int yi = has ? s_y[j * 64 + owner] : 0;
-        const double nfj = has ? s_nf[j * 64 + owner] : 1.0;
-        double P = 1.0, H = 0.0;
-        {
-            const int n = yi < c.nr ? yi : c.nr;
-            double zz = c.r;
-            for (int i = 0; i < n; i++) {  // the same recurrence as the table of eval_point(), stopped at entry n
-                P *= zz;
-                H += rcp(zz);
-                zz += 1.0;
-            }
-        }
-        MARK("spread:prefix_walk_end");
-        const SampleVals v = sample_values(c, nfj, yi, P, H, lt);
-        MARK("spread:sample_end");
-        const int e = j * R + grp;
-        s_x[e] = v.wj;
-        s_x[256 + e] = v.pm;
-        s_x[512 + e] = v.tll;
-        s_x[768 + e] = v.tsd;
-        s_xe[e] = v.pe;
+    // latency.)  The area holds 128 entries (4 x 128 doubles + 128 ints of the 10 x 64 doubles: round 6, when the table lost its
+    // harmonic half); a layout of S R <= 256 entries goes through it in two rounds of ceil(S / 2) samples each, folded in sample
+    // order as before: same bits.
+    // the row-level harmonic sum from the owner's count profile (every lane of the group: same instructions, no extra cost in SIMD);
+    // skipped — profile reads included — when no row of the wave has r < 10 (the flat-likelihood rows of a launch's end never have)
+    double Hrow = 0.0;
+    if (__ballot(c.nr > 0) != 0ull) {
+        const unsigned int w0 = has ? (unsigned int)s_y[S * 64 + owner] : 0u, w1 = has ? (unsigned int)s_y[(S + 1) * 64 + owner] : 0u;
+        const unsigned int w2 = has ? (unsigned int)s_y[(S + 2) * 64 + owner] : 0u;
+        Hrow = harmonic_row<false>(c, w0, w1, w2, nullptr, lane);
     }
-    MARK("spread:exchange_store_end");
-    DIAG(tm[3] = __builtin_amdgcn_s_memtime();)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int *s_xe = reinterpret_cast<int *>(s_x + 4 * 128);
     Acc acc;
-    for (int j0 = 0; j0 < S; j0 += 4) {
-        SampleVals u[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int src = (j0 + t < S ? j0 + t : j0) * R + grp;
-            u[t].wj = s_x[src];
-            u[t].pm = s_x[256 + src];
-            u[t].tll = s_x[512 + src];
-            u[t].tsd = s_x[768 + src];
-            u[t].pe = s_xe[src];
+    // one round of the exchange: the samples [j0, j1) of every group's row
+    auto round = [&](const int j0, const int j1, const int js) {
+        for (int j = js; j < j1; j += L) {  // (the same trip count in every lane of a group up to the guard)
+            const int yi = has ? s_y[j * 64 + owner] : 0;
+            const double nfj = has ? s_nf[j * 64 + owner] : 1.0;
+            double P = 1.0;
+            {
+                const int n = yi < c.nr ? yi : c.nr;
+                double zz = c.r;
+                for (int i = 0; i < n; i++) {  // the same recurrence as the table of eval_point(), stopped at entry n
+                    P *= zz;
+                    zz += 1.0;
+                }
+            }
+            MARK("spread:prefix_walk_end");
+            const SampleVals v = sample_values(c, nfj, yi, P, lt);
+            MARK("spread:sample_end");
+            const int e = (j - j0) * R + grp;
+            s_x[e] = v.wj;
+            s_x[128 + e] = v.pm;
+            s_x[256 + e] = v.tll;
+            s_x[384 + e] = v.tsd;
+            s_xe[e] = v.pe;
         }
+        MARK("spread:exchange_store_end");
+        DIAG(if (j0 == 0) tm[3] = __builtin_amdgcn_s_memtime();)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int q0 = j0; q0 < j1; q0 += 4) {
+            SampleVals u[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-            if (j0 + t < S) accumulate(acc, u[t], (gmask >> (j0 + t)) & 1);
+            for (int t = 0; t < 4; t++) {
+                const int src = ((q0 + t < j1 ? q0 + t : q0) - j0) * R + grp;
+                u[t].wj = s_x[src];
+                u[t].pm = s_x[128 + src];
+                u[t].tll = s_x[256 + src];
+                u[t].tsd = s_x[384 + src];
+                u[t].pe = s_xe[src];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (q0 + t < j1) accumulate(acc, u[t], (gmask >> (q0 + t)) & 1);
+        }
+        __builtin_amdgcn_wave_barrier();  // (the area is written again only after every lane has read it)
+    };
+    if (S * R <= 128) {  // (the usual case at a launch's end: one round, as before round 6)
+        round(0, S, jj);
+    } else {
+        const int Sh = (S + 1) >> 1;
+        round(0, Sh, jj);
+        round(Sh, S, jj >= Sh ? jj : jj + (((Sh - jj + L - 1) >> lg) << lg));  // (this lane's first sample of the second round)
     }
-    __builtin_amdgcn_wave_barrier();  // (the area is written again only after every lane has read it)
     MARK("spread:fold_end");
     DIAG(tm[4] = __builtin_amdgcn_s_memtime();)
     double lp_g, dlp_g;
-    finish_point(acc, c, p2, use_prior, pm_o, prior_isig, lp_g, dlp_g, lt);
+    finish_point(acc, c, Hrow, p2, use_prior, pm_o, prior_isig, lp_g, dlp_g, lt);
     MARK("spread:finish_end");
     DIAG(tm[5] = __builtin_amdgcn_s_memtime();)
     const int src = map.src;
@@ -850,16 +929,19 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (tells the compiler it is wave-uniform: what derives from it — LDS bases, the wave's place in the deal — stays in scalar registers)
     const int S = A.d.S;
     const int64_t n = A.d.n;
-    // per wave: 22*64 doubles (prefix table) + S*64 doubles (nf) + S*64 ints (counts)
-    double *s_tab = smem + (size_t)wave * (22 * 64 + S * 96);
-    double *s_nf = s_tab + 22 * 64;
+    // per wave: 10*64 doubles (prefix products P_1..P_10; the samples-across-lanes exchange) + S*64 doubles (mu) + (S + 3)*64 ints (counts, count profile)
+    double *s_tab = smem + (size_t)wave * (kTabSlots * 64 + S * 96 + 96);
+    double *s_nf = s_tab + kTabSlots * 64;
     int *s_y = reinterpret_cast<int *>(s_nf + S * 64);
     const uint64_t gmask = A.d.gmask;
     const bool p2 = A.d.p == 2;
     const Opts o = A.o;
     const double min_log_alpha = log(o.minDisp / 10.0);
-    const double glo = log(1e-8), ghi = log(o.maxDisp), gstep = (ghi - glo) / 19.0;
+#ifdef EXP_NO_SPREAD
+    int spread_lg = -1;
+#else
     int spread_lg = A.spread ? 1 : -1;  // log2(lanes per row) of the samples-across-lanes layout; -1 = never
+#endif
     while (spread_lg >= 0 && (1 << spread_lg) < S) spread_lg++;
     FitScalars *sc = A.w.sc;
     // fit-wide scalars (uniform)
@@ -873,11 +955,10 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     unsigned int heads_left = MAP ? 0xffu : 0x1u;
     constexpr unsigned long long kHeads = MAP ? 8ull : 1ull;
 
-    int phase = PH_NEED, iter = 0, iacc = 0, gt = 0, gbi = 0;
+    int phase = PH_NEED, iter = 0, iacc = 0;
     int row = -1;
     double a = 0, lp = 0, dlp = 0, kappa = 0, init_lp = 0, a0 = 0, prior_mean = 0;
-    double gbest = 0, ghat = 0, dgene = 0, a_new = 0, alpha_cur = 0;
-    int is_outlier = 0;
+    double a_new = 0, alpha_cur = 0;
     bool queue_empty = false;
     // the open chunk (wave-uniform): entries [chunk_pos, chunk_len) of it are still to be handed out; lane l holds the row of entry l
     uint32_t chunk_base = 0, chunk_pos = 0, chunk_len = 0;
@@ -919,10 +1000,15 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             result = alpha_cur;
         }
         if (grid) {
-            phase = PH_GRID1;
-            gt = 0;
-            gbest = -INFINITY;
-            gbi = 0;
+            // fitDispGrid (A2.7 / A4) is not this kernel's business any more (round 6): the row goes on a list, and a small launch behind
+            // this one evaluates the 20 points of each of its two stages ACROSS LANES (disp_grid_kernel).  The stages' state (point
+            // counter, best value and index, centre of the second stage) and their code were carried by every wave of this kernel
+            // for the 1.7 % of the rows that use them — registers that the three-waves-per-SIMD build had to spill —, and a row
+            // inside a stage held its lane for 40 more serial evaluations (the end of a small fit's launch: ~105 + 40 ticks).
+            const unsigned int at = atomicAdd(A.gridcount, 1u);
+            A.gridlist[at] = MAP ? (row & 0x7fffffff) : row;
+            if (!MAP) A.w.geneIter[row] = iter; else A.w.mapIter[row & 0x7fffffff] = iter;
+            phase = queue_empty ? (int)PH_DONE : (int)PH_NEED;
         } else {
             have_result = true;
         }
@@ -933,12 +1019,18 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             A.w.dispGene[row] = dd;
             A.w.geneIter[row] = iter;
         } else {
-            A.w.dispMAP[row] = dd;
-            A.w.disp[row] = is_outlier ? dgene : dd;
-            A.w.mapIter[row] = iter;
+            // (the outlier flag rides in the sign bit of `row`, and an outlier's final dispersion — its gene-wise estimate — was written
+            // by disp_init: rounds 4-5 carried estimate and flag through the search in three registers, the three the three-waves-per-
+            // SIMD build was short of; a first version of round 6 read them back here, a dependent global load on nearly every tick of
+            // the bulk: + 230 cycles per tick)
+            const int r_ = row & 0x7fffffff;
+            A.w.dispMAP[r_] = dd;
+            if (row >= 0) A.w.disp[r_] = dd;
+            A.w.mapIter[r_] = iter;
         }
     };
-    const bool lean_on = A.spread == 1;  // (option line_search_spread = 2: samples across lanes, but every tick through the general path)
+    const int lg_depth = A.spread == 3 ? 1 : 2;  // (option line_search_spread = 3: no layout of more than 128 exchange entries — an experiment of round 6)
+    const bool lean_on = A.spread == 1 || A.spread == 3;  // (option line_search_spread = 2: samples across lanes, but every tick through the general path)
     SpreadMap lmap;
     lmap.mask = 0ull;
     lmap.lg = -1;
@@ -963,7 +1055,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             if (srch != 0ull && __ballot(phase != PH_SEARCH && phase != PH_DONE) == 0ull) {
                 const bool active = phase == PH_SEARCH;
                 if (srch != lmap.mask) {
-                    const int nact = __popcll(srch), lg_min = spread_lg - 2 > 1 ? spread_lg - 2 : 1;
+                    const int nact = __popcll(srch), lg_min = spread_lg - lg_depth > 1 ? spread_lg - lg_depth : 1;
                     int lg_t = spread_lg;
                     while (lg_t >= lg_min && (nact << lg_t) > 64) lg_t--;
                     if (lg_t < lg_min) {
@@ -1034,6 +1126,19 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                     continue;
                 }
             }
+        }
+        // ---- issue priority by the age of the wave's oldest search (round 6) --------------------------------------------------------
+        // The launch ends with its longest rows: ~105 dependent evaluations each, at the pace of a wave that shares its SIMD — with
+        // three waves per SIMD a bulk tick takes ~12 us instead of ~9, and 105 of them are the whole launch.  A wave that holds an old
+        // search asks the instruction arbiter for precedence over its neighbours (which lose what it gains: throughput is unchanged,
+        // the critical path is shorter).
+        if (A.prio > 0) {
+            const int t1 = A.prio;
+            const bool in_s = phase == PH_SEARCH;
+            if (__ballot(in_s && iter >= 3 * t1) != 0ull) __builtin_amdgcn_s_setprio(3);
+            else if (__ballot(in_s && iter >= 2 * t1) != 0ull) __builtin_amdgcn_s_setprio(2);
+            else if (__ballot(in_s && iter >= t1) != 0ull) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
         }
         MARK("tick:begin");
         DIAG(const bool sec_on = !queue_empty; const unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();)
@@ -1108,10 +1213,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             chunk_pos += take;
             if (phase == PH_NEED && rank < take) {
                 const double2 st = reinterpret_cast<const double2 *>(A.w.start)[2 * (int64_t)r];  // start values (disp_init_kernel)
-                double2 st1 = make_double2(0.0, 0.0);
-                if (MAP) st1 = reinterpret_cast<const double2 *>(A.w.start)[2 * (int64_t)r + 1];  // gene-wise estimate, outlier flag
-                const double dg = st1.x;
-                const int ol = st1.y != 0.0;
+                double ol = 0.0;
+                if (MAP) ol = A.w.start[4 * (int64_t)r + 3];  // outlier flag
                 if (!load_row_mu(A.w.rowpack + (int64_t)r * rstride, S, s_nf, s_y, lane, gmask, o.minmu)) {
                     if (!MAP) {
                         A.w.dispGene[r] = NAN;
@@ -1124,15 +1227,13 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
                         A.w.outlier[r] = 0;
                     }
                 } else {
-                    row = r;
+                    row = (MAP && ol != 0.0) ? (r | (int)0x80000000) : r;
                     if (!MAP) {
                         a0 = st.x;
                         a = st.y;
                     } else {
                         a = st.x;
                         prior_mean = st.y;
-                        dgene = dg;
-                        is_outlier = ol;
                     }
                     phase = PH_INIT;
                 }
@@ -1167,8 +1268,6 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         // profiles/r05_lone_wave_latency.txt — and the if / else-if chains over the six phases, here and in the state machine below,
         // were a dozen of them per tick.  Same operations on the same operands: same bits.)
         const bool in_search = phase == PH_SEARCH, in_init = phase == PH_INIT;
-        const bool in_grid = phase == PH_GRID1 || phase == PH_GRID2;
-        const unsigned long long gridmask = __ballot(in_grid);
         iter += in_search ? 1 : 0;
         {
             const double a_prop = a + kappa * dlp;
@@ -1178,42 +1277,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             }
         }
         a_new = in_search ? a + kappa * dlp : a_new;
-        double a_eval = in_search ? a_new : a;
-        if (gridmask != 0ull) {
-            if (phase == PH_GRID1) a_eval = (gt == 19) ? ghi : glo + gt * gstep;
-            else if (phase == PH_GRID2) a_eval = (gt == 19) ? ghat + gstep : (ghat - gstep) + gt * (2.0 * gstep / 19.0);
-        }
-
-        // ---- grid burst -------------------------------------------------------------------------
-        // The 20 points of a fitDispGrid stage are independent evaluations.  Once the queue is empty, lanes of the wave
-        // that have nothing left to do evaluate the next points of the lowest lane that is inside a stage (its row sits
-        // in that lane's LDS column) while it evaluates its current point itself: with 19 idle lanes the 40 serial
-        // ticks of a straggler become 2.  Same eval_point(), same first-maximum rule: identical bits.
-        int burst_owner = -1, slot = lane, hk = 0, nhelp = 0;
-        bool helper = false;
-        double pm_e = prior_mean;
-        if (queue_empty && A.spread) {
-            const unsigned long long ingrid = gridmask;
-            const unsigned long long idle = __ballot(phase == PH_DONE);
-            if (ingrid && idle) {
-                burst_owner = __ffsll((long long)ingrid) - 1;
-                const int ph_o = __shfl(phase, burst_owner), gt_o = __shfl(gt, burst_owner);
-                const double ghat_o = __shfl(ghat, burst_owner);
-                const double pmo = __shfl(prior_mean, burst_owner);
-                const int nidle = __popcll(idle);
-                nhelp = 19 - gt_o < nidle ? 19 - gt_o : nidle;  // points gt_o+1 .. gt_o+nhelp go to idle lanes
-                const int r = __popcll(idle & ((1ull << lane) - 1ull));
-                if (phase == PH_DONE && r < nhelp) {
-                    helper = true;
-                    hk = gt_o + r + 1;
-                    slot = burst_owner;
-                    pm_e = pmo;
-                    a_eval = ph_o == PH_GRID1 ? ((hk == 19) ? ghi : glo + hk * gstep)
-                                              : ((hk == 19) ? ghat_o + gstep : (ghat_o - gstep) + hk * (2.0 * gstep / 19.0));
-                }
-                if (nhelp == 0) burst_owner = -1;  // the owner is on its last point
-            }
-        }
+        const double a_eval = in_search ? a_new : a;
 
         // ---- evaluate -------------------------------------------------------------------------
         MARK("tick:choose_point_end");
@@ -1223,8 +1287,8 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         // samples-across-lanes layout for this tick: the most lanes per row that still hold every live row (S = 8: eight lanes
         // for up to 8 rows, four for up to 16, two for up to 32); -1 = row per lane
         int lg_t = -1;
-        if (burst_owner < 0 && queue_empty && spread_lg >= 0) {
-            const int nact = __popcll(actmask), lg_min = spread_lg - 2 > 1 ? spread_lg - 2 : 1;
+        if (queue_empty && spread_lg >= 0) {
+            const int nact = __popcll(actmask), lg_min = spread_lg - lg_depth > 1 ? spread_lg - lg_depth : 1;
             lg_t = spread_lg;
             while (lg_t >= lg_min && (nact << lg_t) > 64) lg_t--;
             if (lg_t < lg_min) lg_t = -1;
@@ -1236,8 +1300,7 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             tk_all++;
             tk_kind = -1;
             if (queue_empty) {
-                if (burst_owner >= 0) { tk_burst++; tk_kind = 2; }
-                else if (lg_t >= 0) { tk_spread++; tk_kind = 1; }
+                if (lg_t >= 0) { tk_spread++; tk_kind = 1; }
                 else { tk_row++; tk_kind = 0; }
             }
         })
@@ -1247,31 +1310,14 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
             const SpreadMap map = spread_map(s_tab, lane, lg_t, actmask, active, MAP, prior_mean);
             eval_point_spread(s_nf, s_y, s_tab, lane, S, map, gmask, p2, a_eval, MAP, prior_isig, l_new, dl_new, alpha_new, s_logtab, s_exptab DIAG(, tms));
             DIAG(for (int q = 0; q < 6; q++) cy_sp[q] += tms[q + 1] - tms[q]; cy_sp[6] += tms[0] - sec_t0; cy_sp[7]++; sp_t6 = tms[6]; sp_on = true;)
-        } else if (active || helper) {
+        } else if (active) {
             DIAG(unsigned long long tm[5];)
-            eval_point(s_nf, s_y, s_tab, lane, slot, S, gmask, p2, a_eval, MAP, pm_e, prior_isig, l_new,
+            eval_point(s_nf, s_y, s_tab, lane, lane, S, gmask, p2, a_eval, MAP, prior_mean, prior_isig, l_new,
                        dl_new, alpha_new, s_logtab, s_exptab DIAG(, tm));
             DIAG(if (sec_on) for (int q = 0; q < 4; q++) cy_ev[q] += tm[q + 1] - tm[q];)
         }
         MARK("tick:evaluate_end");
         DIAG(const unsigned long long sec_t3 = __builtin_amdgcn_s_memtime();)
-        bool burst_done = false;  // this lane owns the burst: l_new / hk now describe the best of the 20 points
-        if (burst_owner >= 0) {
-            const bool part = helper || lane == burst_owner;
-            double bl = (part && l_new == l_new) ? l_new : -INFINITY;  // NaN never beats anything (l_new > gbest is false)
-            int bk = part ? (helper ? hk : gt) : 99;                     // the owner evaluated its point gt
-            for (int off = 1; off < 64; off <<= 1) {
-                const double ol = __shfl_xor(bl, off);
-                const int ok = __shfl_xor(bk, off);
-                if (ol > bl || (ol == bl && ok < bk)) { bl = ol; bk = ok; }  // first maximum
-            }
-            if (lane == burst_owner) {
-                burst_done = true;
-                l_new = bl;
-                hk = bk < 20 ? bk : gt;
-            }
-        }
-
         // ---- advance the per-lane state machine ---------------------------------------------
         MARK("tick:burst_reduce_end");
         double result = 0;
@@ -1302,36 +1348,6 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
         phase = in_init ? (int)PH_SEARCH : phase;
         if (__ballot(finished) != 0ull) {
             if (finished) search_over(result, have_result);
-        }
-        if (gridmask != 0ull) {
-            if (in_grid) {  // (the lanes that were inside a grid stage when the tick began: one that has just entered is not)
-                if (burst_done) {  // points gt .. gt+nhelp at once; an earlier point keeps a tie (strict >, as one by one)
-                    if (l_new > gbest) {
-                        gbest = l_new;
-                        gbi = hk;
-                    }
-                    gt += nhelp + 1;
-                } else {
-                    if (l_new > gbest) {
-                        gbest = l_new;
-                        gbi = gt;
-                    }
-                    gt++;
-                }
-                if (gt == 20) {
-                    if (phase == PH_GRID1) {
-                        ghat = (gbi == 19) ? ghi : glo + gbi * gstep;
-                        phase = PH_GRID2;
-                        gt = 0;
-                        gbest = -INFINITY;
-                        gbi = 0;
-                    } else {
-                        const double fa = (gbi == 19) ? ghat + gstep : (ghat - gstep) + gbi * (2.0 * gstep / 19.0);
-                        result = exp(fa);
-                        have_result = true;
-                    }
-                }
-            }
         }
         if (__ballot(have_result) != 0ull) {
             if (have_result) {
@@ -1371,6 +1387,92 @@ __global__ __launch_bounds__(256, MINW) void disp_fit_kernel(DispArgs A) {
     })
 }
 
+// ---- fitDispGrid (A2.7 gene-wise, A4 MAP) for the rows whose line search did not converge --------------------------------------
+// DESeq2's fallback: the log posterior at 20 points log(1e-8) .. log(maxDisp), then at 20 points around the first maximum, +- one
+// coarse step; the first maximum of the second stage is the estimate.  The 2 x 20 evaluations of a row are independent, so a
+// wave takes THREE listed rows at a time — lanes 20 k .. 20 k + 19 evaluate the points of row k, whose counts and means sit in LDS
+// column k — and a row is done in two evaluations instead of 40 serial ones.  eval_point() is the function the line search uses
+// (the prefix table in the lane's own column, the row's operands read from column k: a broadcast within the 20 lanes): the value at
+// a point has the bits it had when the line-search kernel walked the grid itself (rounds 1-5, row per lane or as a "grid burst").
+// Rows per launch: ~1.7 % of a gene-wise fit's, fewer for MAP; the launch reads their number from the device (no host stop), an
+// empty list costs one launch of idle waves.
+template <bool MAP>
+__global__ __launch_bounds__(128) void disp_grid_kernel(DispArgs A) {
+    extern __shared__ double smem[];
+    __shared__ LogEntry s_logtab[64];
+    __shared__ ExpEntry s_exptab[64];
+    exp_table_to_lds(s_exptab);
+    log_table_to_lds(s_logtab);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int S = A.d.S;
+    double *s_tab = smem + (size_t)wave * (kTabSlots * 64 + S * 96 + 96);
+    double *s_nf = s_tab + kTabSlots * 64;
+    int *s_y = reinterpret_cast<int *>(s_nf + S * 64);
+    const uint64_t gmask = A.d.gmask;
+    const bool p2 = A.d.p == 2;
+    const Opts o = A.o;
+    const double glo = log(1e-8), ghi = log(o.maxDisp), gstep = (ghi - glo) / 19.0;
+    const double prior_isig = MAP ? 1.0 / A.w.sc->dispPriorVar : 0.0;
+    const unsigned int count = *A.gridcount;
+    const int64_t rstride = row_stride(S);
+    const unsigned int nwaves = gridDim.x * (blockDim.x >> 6), mywave = blockIdx.x * (blockDim.x >> 6) + (unsigned int)wave;
+    const int k = lane / 20 < 3 ? lane / 20 : 2, pt = lane - 20 * (lane / 20);  // row of the triple, point (lanes 60-63: idle copies of row 2's first points, never looked at)
+    for (unsigned int g0 = 3u * mywave; g0 < count; g0 += 3u * nwaves) {
+        const int nrow = count - g0 < 3u ? (int)(count - g0) : 3;
+        __builtin_amdgcn_wave_barrier();
+        int r_mine = 0;
+        if (lane < nrow) {
+            r_mine = A.gridlist[g0 + (unsigned int)lane];
+            load_row_mu(A.w.rowpack + (int64_t)r_mine * rstride, S, s_nf, s_y, lane, gmask, o.minmu);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool live = lane < 60 && k < nrow;
+        const int r_k = __shfl(r_mine, k);
+        double prior_mean = 0.0;
+        if (MAP) prior_mean = reinterpret_cast<const double2 *>(A.w.start)[2 * (int64_t)(live ? r_k : __shfl(r_mine, 0))].y;
+        double ghat = 0.0;
+        int gbi = 0;
+        for (int stage = 0; stage < 2; stage++) {
+            const double a_eval = stage == 0 ? ((pt == 19) ? ghi : glo + pt * gstep)
+                                             : ((pt == 19) ? ghat + gstep : (ghat - gstep) + pt * (2.0 * gstep / 19.0));
+            double l_new = 0, dl_new = 0, alpha_new = 0;
+            DIAG(unsigned long long tm[5];)
+            eval_point(s_nf, s_y, s_tab, lane, live ? k : 0, S, gmask, p2, a_eval, MAP, prior_mean, prior_isig, l_new, dl_new, alpha_new, s_logtab, s_exptab DIAG(, tm));
+            // first maximum over the row's 20 points, in point order, NaN never beats anything: what `if (l_new > gbest)` did one by one
+            __builtin_amdgcn_wave_barrier();
+            s_tab[lane] = l_new;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double gbest = -INFINITY;
+            gbi = 0;
+            for (int t = 0; t < 20; t++) {
+                const double v = s_tab[20 * k + t];
+                if (v > gbest) {
+                    gbest = v;
+                    gbi = t;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (stage == 0) ghat = (gbi == 19) ? ghi : glo + gbi * gstep;
+        }
+        if (live && pt == 0) {
+            const double fa = (gbi == 19) ? ghat + gstep : (ghat - gstep) + gbi * (2.0 * gstep / 19.0);
+            const double dd = fmin(fmax(exp(fa), o.minDisp), o.maxDisp);
+            if (!MAP) {
+                A.w.dispGene[r_k] = dd;
+            } else {
+                const double2 st1 = reinterpret_cast<const double2 *>(A.w.start)[2 * (int64_t)r_k + 1];  // gene-wise estimate, outlier flag
+                A.w.dispMAP[r_k] = dd;
+                A.w.disp[r_k] = st1.y != 0.0 ? st1.x : dd;
+            }
+        }
+    }
+}
+
 // w.cls[] -> w.order[], sc->ord_na (entries of classes < classesA), sc->ord_n; w.hist is idle between the selects
 void order_tiles(int64_t n, int64_t &nblk, int64_t &tile) {
     nblk = (n + 255) / 256;
@@ -1397,7 +1499,7 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
         order_tiles(d.n, nblk, tile);
         disp_init_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(d, w, o, tile, reinterpret_cast<unsigned int *>(w.hist));
     }
-    const size_t lds_per_wave = (size_t)d.S * 64 * 12 + 22 * 64 * 8;
+    const size_t lds_per_wave = disp_lds_per_wave(d.S);
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks
     int threads = 128;
     while (threads > 64 && lds_per_wave * (threads / 64) > 40 * 1024) threads >>= 1;
@@ -1409,10 +1511,17 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     // wave that starts only when another has left finds the queue empty at best, and at worst owns dealt-out rows that then
     // start late (S = 4: LDS would allow 10 waves per CU, the registers allow 8; 200 k x 4 went from 0.57 to 0.72 ms)
     const int waves_per_block = threads / 64;
-    int64_t blocks_per_cu = (int64_t)(160 * 1024 / (lds > 0 ? lds : 1));
-    // the 168-register build (three waves per SIMD) pays where LDS lets a third wave in and the launch has no static deal: the MAP
-    // search at S <= 4 (ten waves per CU: 0.73 -> 0.68 ms at 2 M x 4; the gene-wise launch loses 7 % with it, round 4)
-    const int min_waves = (map && o.min_waves == 2 && d.S <= 4) ? 3 : (o.min_waves >= 2 && o.min_waves <= 4 ? o.min_waves : 2);
+    int64_t blocks_per_cu = (int64_t)(160 * 1024 / (lds + 2048));  // (+ the workgroup's log and exp tables)
+    // Waves per SIMD (option "line_search_min_waves"; 0 = this rule).  Round 6: the kernel fits 168 registers without scratch (fitDispGrid
+    // and its state left for disp_grid_kernel, the MAP search's outlier value for disp_init) and its LDS lets twelve waves into a CU at
+    // S <= 8 (the harmonic half of the prefix table became a row-level sum).  Measured on one box (profiles/r06_ab_three_waves.txt):
+    // the BULK of a launch gains ~10 % (queue empty at 1.04 instead of 1.17 ms, gene-wise, 2 M x 8), and the MAP launch keeps it
+    // (1.09 -> 0.97 ms at 2 M x 8, 0.60 -> 0.53 at 1 M); the gene-wise launch does not: its end is the ~105 dependent evaluations of the
+    // flat-likelihood rows, each at the pace of a wave that now shares its SIMD with two others (bulk tick 10.7 instead of 8.0 us,
+    // drain 160 / 430 us median / longest instead of 130 / 250) — 1.34 -> 1.36 ms, and worse for fits of <= 500 k rows, which are
+    // all drain (250 k x 8: 0.50 -> 0.63).  So: three waves for the MAP search of >= 750 k rows, two otherwise.
+    const bool lds3 = (int64_t)(160 * 1024 / (lds + 2048)) * waves_per_block >= 12;
+    const int min_waves = (o.min_waves >= 2 && o.min_waves <= 4) ? o.min_waves : ((map && lds3 && d.n >= 750000) ? 3 : 2);
     const int64_t by_regs = (int64_t)(4 * min_waves) / waves_per_block;
     if (blocks_per_cu > by_regs) blocks_per_cu = by_regs;
     if (blocks_per_cu > 8) blocks_per_cu = 8;
@@ -1436,7 +1545,8 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     const bool deal_most = !map && o.schedule == 1 && o.classes_a == 0 && rows_per_lane >= 1.8 && rows_per_lane <= 8.0;
     const int classes_a = o.schedule == 2 ? 0 : (o.classes_a > 0 ? o.classes_a : (deal_most ? 5 : kSchedClassesA));
     if (sched) launch_order_build(d, w, classes_a, true, st);
-    DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, (deal_most && o.deal == 0) ? 4 : o.deal, 1, kChunk};
+    DispArgs A{counts, nf, d, w, o, nullptr, o.spread, sched ? w.order : nullptr, (deal_most && o.deal == 0) ? 4 : o.deal, 1, kChunk,
+               w.gridlist, reinterpret_cast<unsigned int *>(w.queue + (map ? 24 : 16)), o.prio};
 #ifdef CHICDIFF_DIAG
     const char *stamp_file = getenv("CHICDIFF_DISP_STAMPS");  // diagnostic build only: blocking, never timed
     const size_t stamp_words = (size_t)blocks * (threads / 64) * kStampSlots;
@@ -1460,6 +1570,14 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
         if (variant >= 4) LAUNCH(false, 4); else if (variant == 3) LAUNCH(false, 3); else LAUNCH(false, 2);
     }
 #undef LAUNCH
+    {   // fitDispGrid for the rows the searches have listed; the list's length stays on the device.  Waves: what ~2 % of the rows need at
+        // three rows per wave and pass, at most one resident round
+        int64_t gblocks = (d.n / 50 / 3 + 1 + 1) / 2;
+        if (gblocks > 1024) gblocks = 1024;
+        if (gblocks < 1) gblocks = 1;
+        if (map) disp_grid_kernel<true><<<(unsigned)gblocks, 128, 2 * lds_per_wave, st>>>(A);
+        else disp_grid_kernel<false><<<(unsigned)gblocks, 128, 2 * lds_per_wave, st>>>(A);
+    }
 #ifdef CHICDIFF_DIAG
     if (stamp_file) {
         (void)hipStreamSynchronize(st);

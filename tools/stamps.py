@@ -3,7 +3,7 @@ make -C chicdiff_amd/csrc DIAG=1).  Usage on the GPU box: python tools/stamps.py
 import os, sys, numpy as np
 sys.path.insert(0, '.')
 os.environ["CHICDIFF_DISP_STAMPS"] = "gpurun_out/stamps.bin"
-os.environ["CHICDIFF_HIP_LIB"] = "chicdiff_amd/lib/libchicdiff_hip_diag.so"
+os.environ["CHICDIFF_HIP_LIB"] = os.environ.get("STAMPS_LIB", "chicdiff_amd/lib/libchicdiff_hip_diag.so")
 from chicdiff_amd import hip, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -30,6 +30,10 @@ while pos < len(raw):
     print("  q-empty us: min %.1f p10 %.1f med %.1f p90 %.1f max %.1f" % tuple(np.percentile(us(st[qe, 1]), [0, 10, 50, 90, 100])))
     print("  exit   us: min %.1f p10 %.1f med %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(us(st[ran, 2]), [0, 10, 50, 90, 99, 100])))
     print("  live rows at q-empty: mean %.1f max %d" % (st[qe, 3].mean(), st[qe, 3].max()))
+    late = np.argsort(-st[:, 2])[:8]  # the waves that leave last: what they did after their queue ran dry
+    for wv in late:
+        print("    late wave %4d: q-empty %.1f exit %.1f us, live rows at q-empty %d, ticks after q-empty row/spread/burst %d/%d/%d, all ticks %d, lean %d" %
+              (wv, us(st[wv, 1]), us(st[wv, 2]), st[wv, 3], st[wv, 4], st[wv, 5], st[wv, 6], st[wv, 7], st[wv, 33]))
     dr = us(st[qe, 2]) - us(st[qe, 1])
     print("  drain (exit - q-empty) us: med %.1f p90 %.1f max %.1f" % tuple(np.percentile(dr, [50, 90, 100])))
     tk = st[qe, 4:7]
