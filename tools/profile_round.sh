@@ -29,7 +29,10 @@ g.to_csv("$OUT/${TAG}_pmc_sq_bench_2Mx8.csv")
 print(g.to_string())
 import json
 tj = json.load(open("$OUT/pmc_traffic.json"))
-names = {"disp_gene": "disp_fit_kernel<false, 2>", "disp_map": "disp_fit_kernel<true, 2>", "wald_irls": "wald_irls_kernel"}
+def pick(index, prefix):  # the line-search variant that ran (disp_fit_kernel<false, 2>, <true, 3>, ...)
+    hit = [k for k in index if k.startswith(prefix)]
+    return hit[0] if hit else prefix
+names = {"disp_gene": pick(g.index, "disp_fit_kernel<false"), "disp_map": pick(g.index, "disp_fit_kernel<true"), "wald_irls": "wald_irls_kernel"}
 for k, kn in names.items():
     key = k + ":2000000x8"
     if key in tj and kn in g.index:

@@ -50,6 +50,12 @@ while pos < len(raw):
     print("  s_memtime cycles per tick (tick start to next tick start): row-per-lane %.0f, spread %.0f, burst %.0f  (100 MHz clock? ratio to us: %.1f)" % (*per, np.nansum(cy) / max(dr.sum(), 1e-9)))
     bulk = us(st[qe, 1]) / np.maximum(st[qe, 7] - tot, 1)
     print("  us per tick before q-empty: med %.2f; total ticks per wave: med %d" % (np.median(bulk), np.median(st[qe, 7])))
+    if os.environ.get("STAMPS_SPLIT3"):  # (experiment: every third workgroup's waves run at s_setprio(3): option line_search_prio = 100)
+        wv = np.nonzero(qe)[0]
+        hi = (wv // 2) % 3 == 0
+        for nm, m in (("workgroups 0 mod 3", hi), ("the others", ~hi)):
+            print("    %s: us per bulk tick med %.2f, ticks per wave med %d, q-empty med %.1f us, exit med %.1f max %.1f" %
+                  (nm, np.median(bulk[m]), np.median(st[qe, 7][m]), np.median(us(st[qe, 1])[m]), np.median(us(st[qe, 2])[m]), us(st[qe, 2])[m].max()))
     sec = st[qe, 11:16].astype(float)
     tot_sec = sec[:, :4].sum()
     print("  bulk ticks (queue not empty), s_memtime cycles per tick: refill %.0f, choose point %.0f, evaluate %.0f, state machine %.0f (of %.0f); shares %.1f / %.1f / %.1f / %.1f %%" % (
