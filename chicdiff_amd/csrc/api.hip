@@ -1003,10 +1003,12 @@ static int fit_dev_impl(chicdiff_hip_ctx *c, const int32_t *d_counts, const doub
         if ((rc = do_allreduce(c, slots, (int64_t)(slot_doubles * world)))) return rc;
     } else if ((rc = do_allreduce(c, w.sc->colsum, kMaxS + 1)))  // colsum[kMaxS] + nnz are contiguous
         return rc;
-    launch_xim(d, w, slots, world, st);
+    if (c->allreduce) launch_xim(d, w, slots, world, st);  // (the ranks' column sums, exchanged above, added in rank order -> xim)
     {
         Scope t(c, "disp_gene");
-        launch_disp_gene(d_counts, d_nf, d, w, o, st);
+        Opts og = o;
+        og.xim_here = c->allreduce ? 0 : 1;  // single rank: disp_init forms xim from the column sums itself (one dependent launch less)
+        launch_disp_gene(d_counts, d_nf, d, w, og, st);
     }
     // trend: fit_driver.h runs batches of IRLS passes and polls the finished flag between batches
     bool mad_in_kernel = false;  // the persistent trend kernel went on to the residuals, their median and MAD, and the closed-form prior variance

@@ -63,9 +63,36 @@ struct Opts {
     int32_t deal = 0;       // ... entries per group of its static deal (0 = chosen from the number of entries per wave)
     int32_t chunk = 0;      // line search: rows per dequeue (0 = chosen from the row count; 8 .. 64)
     int32_t classes_a = 0;  // gene-wise line search: score classes dealt out statically (0 = the default, 2; 1 .. 6)
+    int32_t xim_here = 0;   // (set by the fit driver, not an option) single rank: disp_init forms xim from the column sums itself, no xim_kernel launch
     int32_t prio = 0;       // line search: issue priority by search age, one level per `prio` iterations (0 = off); option "line_search_prio"
     int32_t trend_blocks = 0;  // persistent trend kernel: at most this many workgroups (0 = one per CU); option "trend_persistent_blocks"
 };
+
+// ---- schedule of a row-queue kernel (disp_kernels.hip order_*): rows in class order; the class counts per tile of rows come from
+// the kernel that writes the classes (disp_init for the gene-wise search; wald_prep, for fits of one row per thread, for the IRLS)
+constexpr int kSchedClasses = 6, kSchedBlocks = 1024;
+inline void order_tiles(int64_t n, int64_t &nblk, int64_t &tile) {
+    nblk = (n + 255) / 256;
+    if (nblk > kSchedBlocks) nblk = kSchedBlocks;
+    tile = ((n + nblk - 1) / nblk + 255) / 256 * 256;
+    nblk = (n + tile - 1) / tile;
+}
+#ifdef __HIPCC__
+// per-thread class counts -> hist[class][block] (wave shuffles, then one LDS add per wave and class)
+__device__ __forceinline__ void order_hist_store(const unsigned int (&mine)[kSchedClasses], unsigned int *hist) {
+    __shared__ unsigned int s_cnt[kSchedClasses];
+    if (threadIdx.x < kSchedClasses) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSchedClasses; k++) {
+        unsigned int v = mine[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < kSchedClasses) hist[threadIdx.x * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
+}
+#endif
 
 // ---- launchers (defined in the .hip files; all enqueue on `st` and never synchronise) -------
 // fm != NULL (S <= 16): the offsets are formed here, from FullMean — sc(theta) of chicdiff.R:1635-1638 / M3 of :1583-1589, the very

@@ -326,25 +326,11 @@ void launch_xim(FitDims d, FitWork w, const double *slots, int world, hipStream_
 // long row (~ 105 serial ticks at 3.6-4 us in the samples-across-lanes layout): 0.79 -> 0.74 ms.
 // Within a class rows keep their natural order (neighbouring lanes read neighbouring rows).  Results never depend on
 // the schedule (tests/test_gpu_parity.py::test_line_search_layouts_agree_bit_for_bit runs both).
-constexpr int kSchedClasses = 6, kSchedClassesA = 2, kSchedDeal = 8, kSchedBlocks = 1024;
+constexpr int kSchedClassesA = 2, kSchedDeal = 8;  // (kSchedClasses, kSchedBlocks, order_tiles(), order_hist_store(): common.h — wald_prep builds the IRLS's class counts too)
 __device__ __forceinline__ int sched_class(double a0, double gmin, double minDisp) {
     if (!(a0 > 1.5 * minDisp)) return 5;
     const double s = a0 * gmin;
     return s < 0.1 ? 0 : (s < 0.316 ? 1 : (s < 1.0 ? 2 : (s < 3.16 ? 3 : (s < 10.0 ? 4 : 5))));
-}
-// per-thread class counts -> hist[class][block] (wave shuffles, then one LDS add per wave and class)
-__device__ __forceinline__ void order_hist_store(const unsigned int (&mine)[kSchedClasses], unsigned int *hist) {
-    __shared__ unsigned int s_cnt[kSchedClasses];
-    if (threadIdx.x < kSchedClasses) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kSchedClasses; k++) {
-        unsigned int v = mine[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[k], v);
-    }
-    __syncthreads();
-    if (threadIdx.x < kSchedClasses) hist[threadIdx.x * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
 }
 // per-block class counts over contiguous tiles of rows: hist[class][block]
 __global__ __launch_bounds__(256) void order_hist_kernel(const uint8_t *__restrict__ cls, int64_t n, int64_t tile, unsigned int *hist) {
@@ -422,9 +408,22 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t *__res
 // tile > 0 (gene-wise launch with the schedule on): block b owns rows [b tile, (b + 1) tile) and leaves its class counts in
 // hist (the first half of order_*); tile == 0: rows grid-strided
 template <bool MAP>
-__global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Opts o, int64_t tile, unsigned int *hist) {
+__global__ __launch_bounds__(256) void disp_init_kernel(FitDims d, FitWork w, Opts o, int64_t tile, unsigned int *hist, int xim_here) {
     const FitScalars *sc = w.sc;
-    const double xim = sc->xim, c0 = sc->coefs[0], c1 = sc->coefs[1];
+    const double c0 = sc->coefs[0], c1 = sc->coefs[1];
+    // xim = mean_j 1 / (colsum_j / nnz) (momentsDispEstimate).  xim_here (single rank, round 6): formed here from the column sums, by every
+    // thread with xim_kernel's own operations (same bits), instead of by a one-thread launch of its own in front of this one (~4 us)
+    double xim = 0.0;
+    if (!MAP) {
+        if (xim_here) {
+            double x = 0;
+            for (int j = 0; j < d.S; j++) x += 1.0 / (sc->colsum[j] / sc->nnz);
+            xim = x / d.S;
+            if (blockIdx.x == 0 && threadIdx.x == 0) w.sc->xim = xim;
+        } else {
+            xim = sc->xim;
+        }
+    }
     const double out_thr = MAP ? o.outlierSD * sqrt(sc->varLogDispEsts) : 0.0;
     unsigned int mine[kSchedClasses] = {0, 0, 0, 0, 0, 0};
     const int64_t lo = tile > 0 ? (int64_t)blockIdx.x * tile : (int64_t)blockIdx.x * 256;
@@ -1474,12 +1473,6 @@ __global__ __launch_bounds__(128) void disp_grid_kernel(DispArgs A) {
 }
 
 // w.cls[] -> w.order[], sc->ord_na (entries of classes < classesA), sc->ord_n; w.hist is idle between the selects
-void order_tiles(int64_t n, int64_t &nblk, int64_t &tile) {
-    nblk = (n + 255) / 256;
-    if (nblk > kSchedBlocks) nblk = kSchedBlocks;
-    tile = ((n + nblk - 1) / nblk + 255) / 256 * 256;
-    nblk = (n + tile - 1) / tile;
-}
 // have_hist: the class counts per tile are in w.hist already (left there by the kernel that wrote w.cls)
 void launch_order_build(FitDims d, FitWork w, int classesA, bool have_hist, hipStream_t st) {
     int64_t nblk, tile;
@@ -1492,12 +1485,12 @@ void launch_order_build(FitDims d, FitWork w, int classesA, bool have_hist, hipS
 static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                         hipStream_t st) {
     const bool sched = !map && o.schedule;
-    if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o, 0, nullptr);
-    else if (!sched) disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o, 0, nullptr);
+    if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o, 0, nullptr, 0);
+    else if (!sched) disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o, 0, nullptr, o.xim_here);
     else {
         int64_t nblk, tile;
         order_tiles(d.n, nblk, tile);
-        disp_init_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(d, w, o, tile, reinterpret_cast<unsigned int *>(w.hist));
+        disp_init_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(d, w, o, tile, reinterpret_cast<unsigned int *>(w.hist), o.xim_here);
     }
     const size_t lds_per_wave = disp_lds_per_wave(d.S);
     // 128-thread blocks while two waves' rows fit comfortably in LDS, else 64-thread blocks

@@ -19,15 +19,21 @@ namespace cd {
 
 constexpr double kLog2e = 1.4426950408889634074;
 
+// tile > 0 (a fit of at most one row per thread, schedule on; round 6): workgroup b owns rows [b tile, (b + 1) tile) and leaves its class
+// counts in hist — what order_hist_kernel did in a launch of its own behind this one (~5 us of a small fit's step); tile == 0: grid-strided
 __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restrict__ counts,
-                                                        const double *__restrict__ nf, FitDims d, FitWork w, int sched) {
+                                                        const double *__restrict__ nf, FitDims d, FitWork w, int sched, int64_t tile, unsigned int *hist) {
     __shared__ double s_logfact[kLogFactN];  // log(y!) for ordinary counts: a look-up instead of a Stirling difference
     __shared__ LogEntry s_lt[64];
     for (int k = threadIdx.x; k < kLogFactN; k += 256) s_logfact[k] = w.logfact[k];
     log_table_to_lds(s_lt);  // (ends with the barrier)
     const int64_t n = d.n;
     const int S = d.S;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    unsigned int mine[kSchedClasses] = {0, 0, 0, 0, 0, 0};
+    const int64_t lo = tile > 0 ? (int64_t)blockIdx.x * tile : (int64_t)blockIdx.x * 256;
+    const int64_t hi = tile > 0 ? (lo + tile < n ? lo + tile : n) : n;
+    const int64_t step = tile > 0 ? 256 : (int64_t)gridDim.x * 256;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += step) {
         if (w.allZero[i]) {
             reinterpret_cast<double2 *>(w.start)[2 * i] = make_double2(NAN, 0.0);  // alpha = NaN: how the IRLS learns that the row is all zero
             if (sched) {  // not scheduled (order_*): the IRLS kernel never sees the row
@@ -44,7 +50,10 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
             // synthetic rows: `smaller group mean < 2` is 10 % of the rows and holds every row with >= 30 steps and 98.8 % of
             // those with >= 20; the rest have alpha > 1.5).  Those rows go first, so that a 20-100 step row never starts late.
             const double gmin = fmin(w.gm0[i], w.gm1[i]);
-            w.cls[i] = gmin < 0.5 ? 0 : (gmin < 1.0 ? 1 : ((gmin < 2.0 || alpha > 1.5) ? 2 : 3));
+            const int cl = gmin < 0.5 ? 0 : (gmin < 1.0 ? 1 : ((gmin < 2.0 || alpha > 1.5) ? 2 : 3));
+            w.cls[i] = (uint8_t)cl;
+#pragma unroll
+            for (int k = 0; k < kSchedClasses; k++) mine[k] += (cl == k);
         }
         const LgrCtx cs = lgr_make_t(rcp(alpha), s_lt), c1 = lgr_one();
         double lA = 0, lB = 0, c = 0, cst = 0;
@@ -76,6 +85,7 @@ __global__ __launch_bounds__(256) void wald_prep_kernel(const int32_t *__restric
         h[0] = make_double2(alpha, c + cst);
         h[1] = make_double2(lA, lB - lA);
     }
+    if (tile > 0) order_hist_store(mine, hist);
 }
 
 
@@ -812,7 +822,14 @@ __global__ void dev_sum_kernel(FitWork w, const int32_t *carry, const double *sf
 }
 
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
-    wald_prep_kernel<<<1536, 256, 0, st>>>(counts, nf, d, w, o.schedule);  // one resident round: 80 VGPRs = 6 workgroups per CU
+    int64_t nblk, tile;
+    order_tiles(d.n, nblk, tile);
+    if (o.schedule && tile == 256) {  // at most one row per thread: the schedule's class counts ride along (no order_hist launch)
+        wald_prep_kernel<<<(unsigned)nblk, 256, 0, st>>>(counts, nf, d, w, o.schedule, tile, reinterpret_cast<unsigned int *>(w.hist));
+        launch_order_build(d, w, 0, true, st);
+        return;
+    }
+    wald_prep_kernel<<<1536, 256, 0, st>>>(counts, nf, d, w, o.schedule, 0, nullptr);  // one resident round: 80 VGPRs = 6 workgroups per CU
     if (o.schedule) launch_order_build(d, w, 0, false, st);
 }
 void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
