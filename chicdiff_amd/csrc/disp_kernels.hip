@@ -1484,7 +1484,9 @@ void launch_order_build(FitDims d, FitWork w, int classesA, bool have_hist, hipS
 
 static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o,
                         hipStream_t st) {
-    const bool sched = !map && o.schedule;
+    // (no schedule for a fit every row of which starts at once — n <= 65 536 is half the lanes of two waves per SIMD —: the order then
+    // decides nothing, and building it is a launch and a pass: 30 k x 4 gene-wise stage 0.309 -> 0.301 ms, round 6)
+    const bool sched = !map && o.schedule && (d.n > 65536 || o.schedule == 2);
     if (map) disp_init_kernel<true><<<kRedBlocks, 256, 0, st>>>(d, w, o, 0, nullptr, 0);
     else if (!sched) disp_init_kernel<false><<<kRedBlocks, 256, 0, st>>>(d, w, o, 0, nullptr, o.xim_here);
     else {

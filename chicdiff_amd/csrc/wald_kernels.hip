@@ -821,7 +821,12 @@ __global__ void dev_sum_kernel(FitWork w, const int32_t *carry, const double *sf
     if (sf_dev && (int)threadIdx.x < S) w.sc->final_sf[threadIdx.x] = sf_dev[threadIdx.x];
 }
 
+// The IRLS's schedule (slow rows first) decides when a row STARTS; in a fit of n <= 131 072 rows — two thirds of the lanes three waves per
+// SIMD hold — every row starts at once whatever the order, and building the order costs a launch and the class counts (round 6, 100 k x 8:
+// wald_prep 0.028 -> 0.018 ms, IRLS 0.147 -> 0.135; 250 k x 8 still wants it: gene-wise and IRLS + 5 ... 13 % without)
+static bool irls_schedule(const FitDims &d, const Opts &o) { return o.schedule && d.n > 131072; }
 void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
+    o.schedule = irls_schedule(d, o) ? o.schedule : 0;
     int64_t nblk, tile;
     order_tiles(d.n, nblk, tile);
     if (o.schedule && tile == 256) {  // at most one row per thread: the schedule's class counts ride along (no order_hist launch)
@@ -833,7 +838,7 @@ void launch_wald_prep(const int32_t *counts, const double *nf, FitDims d, FitWor
     if (o.schedule) launch_order_build(d, w, 0, false, st);
 }
 void launch_wald_irls(const int32_t *counts, const double *nf, FitDims d, FitWork w, Opts o, hipStream_t st) {
-    WaldArgs A{counts, nf, d, w, o, 64, o.schedule ? w.order : nullptr, o.spread};
+    WaldArgs A{counts, nf, d, w, o, 64, irls_schedule(d, o) ? w.order : nullptr, o.spread};
     const size_t lds_per_wave = (size_t)d.S * 64 * 12;
     int threads = 256;
     while (threads > 64 && lds_per_wave * (threads / 64) > 40 * 1024) threads >>= 1;
