@@ -1175,7 +1175,21 @@ def test_line_search_layouts_agree_bit_for_bit(ctx, n, S, group):
             deals[f"chunk {ch}"] = run()
         finally:
             ctx.set_option("line_search_chunk", 0)
-    assert (a["dispGeneIter"] >= 100).sum() > 10  # the stragglers this is about are present
+    # round 6: waves per SIMD (the three-waves build — 168 registers, no scratch — runs the MAP search of >= 750 k rows; by option: both
+    # searches at any size), the exchange layouts of <= 128 entries only, and issue priority by search age: the same bits
+    for mw in (2, 3):
+        ctx.set_option("line_search_min_waves", mw)
+        try:
+            deals[f"{mw} waves per SIMD"] = run()
+        finally:
+            ctx.set_option("line_search_min_waves", 0)
+    for name, val in (("line_search_spread", 3), ("line_search_prio", 20)):
+        ctx.set_option(name, val)
+        try:
+            deals[f"{name} = {val}"] = run()
+        finally:
+            ctx.set_option(name, 1 if name == "line_search_spread" else 0)
+    assert (a["dispGeneIter"] >= 100).sum() > 10  # the stragglers this is about are present (their fitDispGrid stages run in disp_grid_kernel)
     for deal, f in deals.items():
         for k in a:
             assert np.array_equal(a[k], f[k], equal_nan=True), f"{k}: deal {deal} differs"
