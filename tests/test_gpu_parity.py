@@ -1582,6 +1582,32 @@ def test_fit_edge_shapes(ctx, oracle, n, S, nB):
     explain_fit(f"edge shape {n} x {S} ({S - nB}v{nB})", oracle, counts, nf, group, got, sc)
 
 
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 64, 193])
+def test_fitDispGrid_list_lengths(ctx, oracle, m):
+    """disp_grid_kernel (round 6) takes the rows whose line search did not converge THREE per wave and pass: fits whose gene-wise
+    search lists exactly m such rows, m around that boundary and around a wave's and a launch's share — every listed row's two grid
+    stages against the oracle's fitDispGrid (dispGeneEst to 1e-6 or refereed, same iteration count), beside 300 ordinary rows that
+    carry the trend.  The rows are picked by the oracle: dispGeneIter = 100 and an estimate above 10 minDisp (DESeq2's refit rule)."""
+    d = synth.make(120000, 8)
+    ref_all = oracle.nbglm_fit(d["counts"], d["nf"], d["group"], nthreads=min(16, os.cpu_count() or 1))
+    grid_rows = np.flatnonzero((ref_all["dispGeneIter"] >= 100) & (ref_all["dispGeneEst"] > 1e-7) & (ref_all["allZero"] == 0))
+    plain = np.flatnonzero((ref_all["dispGeneIter"] < 30) & (ref_all["dispGeneIter"] > 1) & (ref_all["allZero"] == 0))[:300]
+    assert len(grid_rows) >= 193, len(grid_rows)
+    rng = np.random.default_rng(m)
+    rows = np.concatenate([grid_rows[:m], plain])
+    rows = rows[rng.permutation(len(rows))]
+    counts, nf = d["counts"][rows].copy(), d["nf"][rows].copy()
+    ref = oracle.nbglm_fit(counts, nf, d["group"])
+    got, sc = run_fit(ctx, dict(counts=counts, nf=nf), d["group"])
+    is_grid = np.isin(rows, grid_rows[:m])
+    # (xim — the one global the gene-wise search sees — differs between the sub-matrix and the full one in its 3rd digit: a listed
+    # row may start elsewhere; what must hold is GPU = oracle on THIS matrix, row by row)
+    assert (ref["dispGeneIter"][is_grid] >= 100).sum() >= max(1, m // 2), "the picked rows no longer reach the grid under this matrix's xim"
+    assert np.array_equal(got["dispGeneIter"][is_grid], ref["dispGeneIter"][is_grid])
+    assert (sc["status"] & 17) == (ref["status"] & 17)
+    explain_fit(f"fitDispGrid list of {m} rows", oracle, counts, nf, d["group"], got, sc)
+
+
 def _extreme_matrix():
     """4000 x 6 synthetic rows, 300 of them with counts up to 2^30 next to zeros and offsets over four decades."""
     rng = np.random.default_rng(17)
