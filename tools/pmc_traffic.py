@@ -61,10 +61,14 @@ def main():
         cal["WRITE_SIZE on offsets kernel (8*S*n bytes known)"] = 8.0 * S * n / (ok * 1024)
     corr = cal.get("prep kernel (4+8 B/lane)", 2.0)
     out = {}
-    for name, prefix in (("disp_gene", "disp_fit_kernel<false"), ("disp_map", "disp_fit_kernel<true"), ("wald_irls", "wald_irls_kernel")):
+    # (a line-search stage = its launch + the fitDispGrid launch behind it, round 6: both inside the scope bench.py times)
+    for name, prefix, extra in (("disp_gene", "disp_fit_kernel<false", "disp_grid_kernel<false"), ("disp_map", "disp_fit_kernel<true", "disp_grid_kernel<true"),
+                                ("wald_irls", "wald_irls_kernel", None)):
         fk, wk = find(fm, prefix), find(wm, prefix)
         if fk is None or wk is None:
             continue
+        if extra and find(fm, extra) is not None and find(wm, extra) is not None:
+            fk, wk = fk + find(fm, extra), wk + find(wm, extra)
         out[f"{name}:{n}x{S}"] = {
             "hbm_bytes_per_launch": int(fk * 1024 * corr + wk * 1024),
             "fetch_size_kib_raw": fk, "write_size_kib": wk, "fetch_correction": round(corr, 3),
