@@ -10,11 +10,13 @@
 //     registers;
 //   * every loop trip ("tick") each lane evaluates the Cox-Reid adjusted profile
 //     log-likelihood AND its derivative at one point of its own search — the proposal of the
-//     Armijo step, the start point, or a grid point of the fitDispGrid fallback — so lanes in
-//     different phases still execute the same instruction stream;
-//   * iteration counts are heavy-tailed (median ~7, 1.7 % of rows run 100 + 40 grid points),
-//     so a finished lane immediately pulls the next row from a global queue (wave-private chunks
+//     Armijo step or the start point — so lanes in different phases still execute the same
+//     instruction stream;
+//   * iteration counts are heavy-tailed (median ~7, 1.7 % of rows run all 100 steps), so a
+//     finished lane immediately pulls the next row from a global queue (wave-private chunks
 //     of 64 rows, one atomic per chunk) instead of idling until its 63 neighbours finish;
+//   * a row whose search does not converge goes on a list; the 2 x 20 points of its fitDispGrid
+//     fallback are evaluated across lanes by disp_grid_kernel, three rows per wave (round 6);
 //   * at the end of the launch, waves left with a few stragglers evaluate them with the samples
 //     spread across lanes (eval_point_spread), bit-identical to the row-per-lane evaluation.
 #include <stdio.h>
@@ -730,8 +732,8 @@ __device__ __forceinline__ void finish_point(const Acc &acc, const RowConsts &c,
     dlp = (c.r * c.r * (acc.sd - Hrow) + dcr) * c.alpha + dpr;
 }
 
-// Row-per-lane evaluation: all S samples of the row in LDS column `slot` (the lane's own row, or — grid burst —
-// another lane's), the prefix table in the lane's own column.
+// Row-per-lane evaluation: all S samples of the row in LDS column `slot` (the lane's own row; in disp_grid_kernel the column of
+// the row whose grid point the lane evaluates), the prefix table in the lane's own column.
 __device__ __forceinline__ void eval_point(const double *s_nf, const int *s_y, double *s_tab, int lane, int slot, int S, uint64_t gmask,
                                            bool p2, double a,
                                            bool use_prior, double prior_mean, double prior_isig,
