@@ -1570,7 +1570,7 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     {   // fitDispGrid for the rows the searches have listed; the list's length stays on the device.  Waves: what ~2 % of the rows need at
         // three rows per wave and pass, at most one resident round
         int64_t gblocks = (d.n / 50 / 3 + 1 + 1) / 2;
-        if (gblocks > 1024) gblocks = 1024;
+        if (gblocks > 1536) gblocks = 1536;  // (six workgroups per CU — 150 VGPRs, 26 KB of LDS each: one resident round; 1024 / 1536 / 2048: 75 / 71 / 77 us at 2 M x 8)
         if (gblocks < 1) gblocks = 1;
         if (map) disp_grid_kernel<true><<<(unsigned)gblocks, 128, 2 * lds_per_wave, st>>>(A);
         else disp_grid_kernel<false><<<(unsigned)gblocks, 128, 2 * lds_per_wave, st>>>(A);
