@@ -1875,16 +1875,17 @@ extern "C" int chicdiff_hip_region_universe_dev(chicdiff_hip_ctx *c, const int32
         return fail(c, CHICDIFF_E_INVALID, "region_universe: room for n max(2 RUexpand + 1, 2) = %lld rows needed, %lld given",
                     (long long)(n * per_peak), (long long)capacity);
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t scan = ru_scan_bytes(n);
-    int rc = ensure_aux(c, 256 + scan);
+    const size_t scan = (ru_scan_bytes(n) + 255) / 256 * 256;
+    int rc = ensure_aux(c, 256 + scan + sizeof(unsigned int) * (size_t)n);
     if (rc) return rc;
     int *bad = (int *)c->aux;
+    unsigned int *masks = reinterpret_cast<unsigned int *>(c->aux + 256 + scan);  // which candidates each region keeps: counted once, read by the fill
     timing_reset(c);
     {
         Scope t(c, "region_universe");
-        if (launch_ru_count(d_bait, d_oe, n, RUexpand, d_chr_of, maxfrag, d_region_ptr, d_minOE, d_maxOE, bad, c->aux + 256, scan, c->stream))
+        if (launch_ru_count(d_bait, d_oe, n, RUexpand, d_chr_of, maxfrag, d_region_ptr, d_minOE, d_maxOE, bad, c->aux + 256, scan, c->stream, masks))
             return fail(c, CHICDIFF_E_HIP, "region_universe: scan failed");
-        launch_ru_fill(d_bait, d_oe, n, RUexpand, d_chr_of, maxfrag, d_region_ptr, d_ru_bait, d_ru_region, d_ru_oe, c->stream);
+        launch_ru_fill(d_bait, d_oe, n, RUexpand, d_chr_of, maxfrag, d_region_ptr, d_ru_bait, d_ru_region, d_ru_oe, c->stream, masks);
     }
     int h_bad = 0;
     HIPCHK(c, hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));

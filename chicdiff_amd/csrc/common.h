@@ -190,9 +190,11 @@ int launch_count_table(const int32_t *bait, const int32_t *oe, const int32_t *N,
                        int64_t *keys_out, int32_t *vals_out, char *ws, hipStream_t st);
 size_t ru_scan_bytes(int64_t n);
 int launch_ru_count(const int32_t *bait, const int32_t *oe, int64_t n, int s, const int32_t *chr_of, int maxfrag,
-                    int64_t *region_ptr, int32_t *minOE, int32_t *maxOE, int *bad, void *tmp, size_t tmp_bytes, hipStream_t st);
+                    int64_t *region_ptr, int32_t *minOE, int32_t *maxOE, int *bad, void *tmp, size_t tmp_bytes, hipStream_t st,
+                    unsigned int *mask_out = nullptr);  // mask_out (n words, may be NULL): per region, which candidates of its window are kept
 void launch_ru_fill(const int32_t *bait, const int32_t *oe, int64_t n, int s, const int32_t *chr_of, int maxfrag,
-                    const int64_t *region_ptr, int32_t *ru_bait, int32_t *ru_region, int32_t *ru_oe, hipStream_t st);
+                    const int64_t *region_ptr, int32_t *ru_bait, int32_t *ru_region, int32_t *ru_oe, hipStream_t st,
+                    const unsigned int *mask_in = nullptr);  // mask_in: launch_ru_count's masks (NULL: recomputed)
 void launch_region_avdist(const int32_t *bait, const int32_t *oe, const int64_t *ptr, int64_t n, int32_t id_min, int32_t nid,
                           const int64_t *midsum, const int32_t *chr, double *avDist, hipStream_t st);
 size_t count_join_multi_scratch_bytes(int S, const int64_t *nkeys);

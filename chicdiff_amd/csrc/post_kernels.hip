@@ -222,21 +222,37 @@ __device__ __forceinline__ bool ru_keep(int id, int bait_chr, const int32_t *chr
 }
 __global__ __launch_bounds__(256) void ru_count_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe, int64_t n,
                                                        int s, const int32_t *__restrict__ chr_of, int maxfrag, int64_t *len,
-                                                       int32_t *minOE, int32_t *maxOE, int *bad) {
+                                                       int32_t *minOE, int32_t *maxOE, int *bad, unsigned int *mask_out) {
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         int lo, hi, cnt = 0, mn = INT32_MAX, mx = INT32_MIN;
+        unsigned int mask = 0;  // bit (id - lo): candidate id is kept (windows of <= 32 candidates; what the fill kernel reads instead of walking)
         const int b = bait[i];
         if (!expand_range(b, oe[i], s, lo, hi)) {
             atomicExch(bad, 1);
         } else {
             const int bc = (b >= 1 && b <= maxfrag) ? chr_of[b] : -1;
-            for (int id = lo; id <= hi; id++)
-                if (bc >= 0 && ru_keep(id, bc, chr_of, maxfrag)) {
-                    cnt++;
-                    mn = id < mn ? id : mn;
-                    mx = id > mx ? id : mx;
+            // (four candidates' chromosome look-ups in flight at a time: the window is a run of consecutive IDs, the look-ups are independent,
+            // and as `ru_keep(id, ...)` inside the loop's condition each was a load the next iteration waited for)
+            for (int id0 = lo; id0 <= hi; id0 += 4) {
+                int cc[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int id = id0 + q;
+                    cc[q] = (id <= hi && id >= 1 && id <= maxfrag) ? chr_of[id] : -1;
                 }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int id = id0 + q;
+                    if (bc >= 0 && cc[q] >= 0 && cc[q] == bc) {  // ru_keep()
+                        cnt++;
+                        mn = id < mn ? id : mn;
+                        mx = id > mx ? id : mx;
+                        if (id - lo < 32) mask |= 1u << (id - lo);
+                    }
+                }
+            }
         }
+        if (mask_out) mask_out[i] = mask;
         len[i] = cnt;
         if (minOE) minOE[i] = cnt ? mn : INT32_MIN;
         if (maxOE) maxOE[i] = cnt ? mx : INT32_MIN;
@@ -249,9 +265,14 @@ __global__ __launch_bounds__(256) void ru_count_kernel(const int32_t *__restrict
 __global__ __launch_bounds__(256) void ru_fill_kernel(const int32_t *__restrict__ bait, const int32_t *__restrict__ oe, int64_t n,
                                                       int s, const int32_t *__restrict__ chr_of, int maxfrag,
                                                       const int64_t *__restrict__ ptr, int32_t *ru_bait, int32_t *ru_region,
-                                                      int32_t *ru_oe) {
+                                                      int32_t *ru_oe, const unsigned int *__restrict__ mask_in) {
+    // (round 6: which of a region's <= 2 s + 1 candidates are kept is worked out ONCE per region, by the region's thread — a bit mask
+    // in LDS —, and a row picks the k-th set bit; before, every ROW walked its region's candidates, a dependent gather from chr_of per
+    // step: ~6 gathers per output row on average, the kernel at a tenth of the HBM roof.  Windows wider than 32 candidates
+    // (RUexpand > 15) keep the walk.)
     __shared__ int64_t s_ptr[257];
     __shared__ int s_lo[256], s_hi[256], s_bait[256], s_chr[256];
+    __shared__ unsigned int s_mask[256];
     for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
         const int nreg = n - i0 < 256 ? (int)(n - i0) : 256;
         __syncthreads();
@@ -261,10 +282,17 @@ __global__ __launch_bounds__(256) void ru_fill_kernel(const int32_t *__restrict_
             int lo = 0, hi = -1;
             const int b = bait[i0 + threadIdx.x];
             (void)expand_range(b, oe[i0 + threadIdx.x], s, lo, hi);
+            const int bc = (b >= 1 && b <= maxfrag) ? chr_of[b] : -1;
+            unsigned int mask = 0;
+            if (mask_in) mask = mask_in[i0 + threadIdx.x];  // (left by ru_count_kernel in the one-call entry point: no gathers here at all)
+            else if (hi - lo < 32)
+                for (int id = lo; id <= hi; id++)
+                    if (ru_keep(id, bc, chr_of, maxfrag)) mask |= 1u << (id - lo);
             s_lo[threadIdx.x] = lo;
             s_hi[threadIdx.x] = hi;
             s_bait[threadIdx.x] = b;
-            s_chr[threadIdx.x] = (b >= 1 && b <= maxfrag) ? chr_of[b] : -1;
+            s_chr[threadIdx.x] = bc;
+            s_mask[threadIdx.x] = mask;
         }
         __syncthreads();
         const int64_t r0 = s_ptr[0], r1 = s_ptr[nreg];
@@ -275,10 +303,16 @@ __global__ __launch_bounds__(256) void ru_fill_kernel(const int32_t *__restrict_
                 if (s_ptr[mid] <= r) a = mid; else e = mid;
             }
             int k = (int)(r - s_ptr[a]);  // the k-th kept candidate of region a
-            const int bc = s_chr[a];
             int id = s_lo[a];
-            for (; id <= s_hi[a]; id++)
-                if (ru_keep(id, bc, chr_of, maxfrag) && k-- == 0) break;
+            if (s_hi[a] - id < 32) {
+                unsigned int m = s_mask[a];
+                for (int q = 0; q < k; q++) m &= m - 1u;  // drop the k lowest set bits
+                id += __ffs((int)m) - 1;
+            } else {
+                const int bc = s_chr[a];
+                for (; id <= s_hi[a]; id++)
+                    if (ru_keep(id, bc, chr_of, maxfrag) && k-- == 0) break;
+            }
             ru_bait[r] = s_bait[a];
             ru_region[r] = (int32_t)(i0 + a + 1);  // regionID <- 1:nrow
             ru_oe[r] = id;
@@ -293,24 +327,24 @@ size_t ru_scan_bytes(int64_t n) {
 }
 // region_ptr (n+1): first used as the lengths (entry n = 0), then scanned in place
 int launch_ru_count(const int32_t *bait, const int32_t *oe, int64_t n, int s, const int32_t *chr_of, int maxfrag,
-                    int64_t *region_ptr, int32_t *minOE, int32_t *maxOE, int *bad, void *tmp, size_t tmp_bytes, hipStream_t st) {
+                    int64_t *region_ptr, int32_t *minOE, int32_t *maxOE, int *bad, void *tmp, size_t tmp_bytes, hipStream_t st, unsigned int *mask_out) {
     int blocks = (int)((n + 255) / 256);
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     if (hipMemsetAsync(bad, 0, sizeof(int), st) != hipSuccess) return 1;
     if (hipMemsetAsync(region_ptr + n, 0, sizeof(int64_t), st) != hipSuccess) return 1;
-    ru_count_kernel<<<blocks, 256, 0, st>>>(bait, oe, n, s, chr_of, maxfrag, region_ptr, minOE, maxOE, bad);
+    ru_count_kernel<<<blocks, 256, 0, st>>>(bait, oe, n, s, chr_of, maxfrag, region_ptr, minOE, maxOE, bad, mask_out);
     size_t need = 0;
     (void)rocprim::exclusive_scan(nullptr, need, region_ptr, region_ptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), st);
     if (need > tmp_bytes) return 2;
     return rocprim::exclusive_scan(tmp, need, region_ptr, region_ptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), st) == hipSuccess ? 0 : 1;
 }
 void launch_ru_fill(const int32_t *bait, const int32_t *oe, int64_t n, int s, const int32_t *chr_of, int maxfrag,
-                    const int64_t *region_ptr, int32_t *ru_bait, int32_t *ru_region, int32_t *ru_oe, hipStream_t st) {
+                    const int64_t *region_ptr, int32_t *ru_bait, int32_t *ru_region, int32_t *ru_oe, hipStream_t st, const unsigned int *mask_in) {
     int blocks = (int)((n + 255) / 256);
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
-    ru_fill_kernel<<<blocks, 256, 0, st>>>(bait, oe, n, s, chr_of, maxfrag, region_ptr, ru_bait, ru_region, ru_oe);
+    ru_fill_kernel<<<blocks, 256, 0, st>>>(bait, oe, n, s, chr_of, maxfrag, region_ptr, ru_bait, ru_region, ru_oe, mask_in);
 }
 
 

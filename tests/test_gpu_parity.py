@@ -1366,9 +1366,10 @@ def test_ihw_application_on_device_reproduces_golden_table(ctx, golden, oracle):
         ctx.ihw_apply(dev(av), dev(pv), breaks[::-1].copy(), w)
 
 
-@pytest.mark.parametrize("s", [5, 0, 12])
+@pytest.mark.parametrize("s", [5, 0, 12, 15, 16, 20])
 def test_region_universe_on_device(ctx, oracle, s):
-    """f4: getRegionUniverse window mode, bit-exact against the oracle on the reference's chr19 fragment IDs."""
+    """f4: getRegionUniverse window mode, bit-exact against the oracle on the reference's chr19 fragment IDs (RUexpand 16 and 20: windows of
+    more than 32 candidates, which the fill kernel walks instead of reading off a per-region bit mask)."""
     import torch
     from post_inputs import region_universe_case
     bait, oe, chr_of = region_universe_case()
