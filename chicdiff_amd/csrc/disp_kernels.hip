@@ -1516,9 +1516,12 @@ static void launch_disp(bool map, const int32_t *counts, const double *nf, FitDi
     // (1.09 -> 0.97 ms at 2 M x 8, 0.60 -> 0.53 at 1 M); the gene-wise launch does not: its end is the ~105 dependent evaluations of the
     // flat-likelihood rows, each at the pace of a wave that now shares its SIMD with two others (bulk tick 10.7 instead of 8.0 us,
     // drain 160 / 430 us median / longest instead of 130 / 250) — 1.34 -> 1.36 ms, and worse for fits of <= 500 k rows, which are
-    // all drain (250 k x 8: 0.50 -> 0.63).  So: three waves for the MAP search of >= 750 k rows, two otherwise.
+    // all drain (250 k x 8: 0.50 -> 0.63).  So: three waves for the MAP search of >= 750 k rows; for the gene-wise search only where the
+    // launch is long against that chain (105 ticks of ~2 + 1.1 S us): from 3 M rows (3 M x 8 1.85 -> 1.82 ms, 4 M 2.39 -> 2.25, 6 M 3.45 ->
+    // 3.20), at S <= 4 from 1.5 M (2 M x 4 1.16 -> 1.13, 4 M x 4 1.97 -> 1.91); two otherwise.
     const bool lds3 = (int64_t)(160 * 1024 / (lds + 2048)) * waves_per_block >= 12;
-    const int min_waves = (o.min_waves >= 2 && o.min_waves <= 4) ? o.min_waves : ((map && lds3 && d.n >= 750000) ? 3 : 2);
+    const bool three = lds3 && (map ? d.n >= 750000 : (d.n >= 3000000 || (d.S <= 4 && d.n >= 1500000)));
+    const int min_waves = (o.min_waves >= 2 && o.min_waves <= 4) ? o.min_waves : (three ? 3 : 2);
     const int64_t by_regs = (int64_t)(4 * min_waves) / waves_per_block;
     if (blocks_per_cu > by_regs) blocks_per_cu = by_regs;
     if (blocks_per_cu > 8) blocks_per_cu = 8;
