@@ -330,6 +330,7 @@ class HipContext:
         S, nru = len(tables), d_bait.numel()
         if out is None:
             out = self.torch.empty((S, nru), dtype=self.torch.int32, device=self.device)
+        assert out.shape == (S, nru) and out.dtype == self.torch.int32 and out.is_contiguous() and S >= 1
         kp = (C.c_void_p * S)(*[k.data_ptr() for k, _ in tables])
         vp_ = (C.c_void_p * S)(*[v.data_ptr() for _, v in tables])
         nk = (C.c_int64 * S)(*[k.numel() for k, _ in tables])
